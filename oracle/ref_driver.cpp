@@ -1,0 +1,340 @@
+// ref_driver.cpp -- ORACLE TOOLING (test infrastructure, not product code).
+//
+// A command-line harness that is LINKED AGAINST THE REFERENCE'S OWN OBJECT FILES
+// (compiled in place from /root/reference by oracle/Makefile into oracle/_ref/; no
+// reference source is copied into this repository).  It exposes the reference's
+// compilable primitives on binary files so that tests/golden/make_golden.py can
+// produce golden vectors and tests can pin oracle/tfhe_oracle.c against the real
+// thing:
+//
+//   spqlios core       fft / ifft / new_*_table      CB/spqlios/spqlios-fft.h:46-53
+//   FFT plugin         FFT_Processor_Spqlios::*      CB/spqlios/lagrangehalfc_impl.h:8-36
+//   AddMul             LagrangeHalfCPolynomialAddMulASM   lagrangehalfc_impl.h:36
+//   PoC functions      tGswTorus64PolynomialDecompH, preKeySwitch, preModSwitch,
+//                      circuitPrivKS, circuitBootstrapWoKS
+//                      CB/poc_CircuitBootstrapping.cpp:437-698
+//   Karatsuba          torus32/64PolynomialMultKaratsuba_lvl1/2   CB/poc_karatsuba.cpp:60-76,168-185
+//
+// usage: ref_driver <op> <in.bin> <out.bin> [int args...]
+// Synthetic key tables are filled from a seed with consecutive splitmix64 outputs
+// (high 32 bits), the same rule tests/oracle_py.py:fill32() implements in numpy.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "poc_types.h"  // reference header (defines `k` as a macro!)
+#include "spqlios/lagrangehalfc_impl.h"
+#include "spqlios/spqlios-fft.h"
+
+// functions defined (without a header) in CB/poc_CircuitBootstrapping.cpp / poc_karatsuba.cpp
+void preKeySwitch(LweSample32 *result, const LweSample32 *x, const Globals *env);
+void preModSwitch(int *result, const LweSample32 *x, const Globals *env);
+void tGswTorus64PolynomialDecompH(IntPolynomial *result, const Torus64Polynomial *sample, const Globals *env);
+void circuitBootstrapWoKS(LweSample64 *result, const Torus64 mu, const int *abar, const Globals *env);
+void circuitPrivKS(TLweSample32 *result, const int u, const LweSample64 *x, const Globals *env);
+void torus32PolynomialMultKaratsuba_lvl1(Torus32Polynomial *result, const IntPolynomial *poly1,
+                                         const Torus32Polynomial *poly2, const Globals *env);
+void torus64PolynomialMultKaratsuba_lvl2(Torus64Polynomial *result, const IntPolynomial *poly1,
+                                         const Torus64Polynomial *poly2, const Globals *env);
+
+namespace {
+
+std::vector<uint8_t> slurp(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); exit(2); }
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> buf((size_t)sz);
+    if (sz && fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { perror("fread"); exit(2); }
+    fclose(f);
+    return buf;
+}
+void spill(const char *path, const void *p, size_t bytes) {
+    FILE *f = fopen(path, "wb");
+    if (!f) { perror(path); exit(2); }
+    if (bytes && fwrite(p, 1, bytes, f) != bytes) { perror("fwrite"); exit(2); }
+    fclose(f);
+}
+
+struct SplitMix {
+    uint64_t s;
+    explicit SplitMix(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    int32_t next32() { return (int32_t)(uint32_t)(next() >> 32); }
+};
+
+// mirror of the (anonymous-namespace) FFT_PRECOMP of CB/spqlios/spqlios-fft-impl.cpp:48-53
+struct PrecompView {
+    uint64_t n;
+    double *trig;
+    double *data;
+    void *buf;
+};
+
+// A Globals object WITHOUT running Globals::Globals() (which would spend ~75 s generating
+// 2.7 GB of keys, poc:342-423): raw storage, fields filled by hand.
+Globals *bare_globals() {
+    Globals *env = (Globals *)calloc(1, sizeof(Globals));
+    env->N_lvl1 = Globals::n_lvl1;
+    env->N_lvl2 = Globals::n_lvl2;
+    env->t_lvl0 = Globals::kslength_lvl10 * Globals::ksbasebit_lvl10;
+    env->t_lvl1 = Globals::kslength_lvl21 * Globals::ksbasebit_lvl21;
+    env->torusDecompOffset = 0;  // poc:349-350
+    for (int i = 0; i <= Globals::ell_lvl2; ++i)
+        env->torusDecompOffset |= (UINT64_C(1) << (63 - i * Globals::bgbit_lvl2));
+    env->torusDecompBuf = new uint64_t[env->N_lvl2];
+    return env;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 4) {
+        fprintf(stderr, "usage: %s <op> <in.bin> <out.bin> [args]\n", argv[0]);
+        return 2;
+    }
+    const std::string op = argv[1];
+    const char *inp = argv[2], *outp = argv[3];
+    auto arg = [&](int i) -> long { return (argc > 4 + i) ? atol(argv[4 + i]) : 0; };
+
+    if (op == "params") {  // the PoC's compiled-in parameter block (poc:70-85)
+        int32_t p[11] = {Globals::n_lvl0, Globals::n_lvl1, Globals::n_lvl2, Globals::bgbit_lvl1,
+                         Globals::ell_lvl1, Globals::bgbit_lvl2, Globals::ell_lvl2,
+                         Globals::kslength_lvl10, Globals::ksbasebit_lvl10,
+                         Globals::kslength_lvl21, Globals::ksbasebit_lvl21};
+        spill(outp, p, sizeof(p));
+        return 0;
+    }
+    if (op == "tables") {  // args: N -> [fft_trig | ifft_trig], each 2N-8 doubles
+        const int N = (int)arg(0);
+        const size_t len = (size_t)2 * N - 8;
+        PrecompView *f = (PrecompView *)new_fft_table(N);
+        PrecompView *r = (PrecompView *)new_ifft_table(N);
+        std::vector<double> out(2 * len);
+        memcpy(out.data(), f->trig, len * 8);
+        memcpy(out.data() + len, r->trig, len * 8);
+        spill(outp, out.data(), out.size() * 8);
+        return 0;
+    }
+    if (op == "ifft" || op == "fft") {  // args: N ; in/out: count*N doubles, raw core transform
+        const int N = (int)arg(0);
+        auto in = slurp(inp);
+        const size_t cnt = in.size() / 8 / N;
+        void *tab = (op == "ifft") ? new_ifft_table(N) : new_fft_table(N);
+        double *buf = (op == "ifft") ? ifft_table_get_buffer(tab) : fft_table_get_buffer(tab);
+        std::vector<double> out(cnt * N);
+        for (size_t c = 0; c < cnt; c++) {
+            memcpy(buf, in.data() + c * N * 8, (size_t)N * 8);
+            if (op == "ifft") ifft(tab, buf); else fft(tab, buf);
+            memcpy(out.data() + c * N, buf, (size_t)N * 8);
+        }
+        spill(outp, out.data(), out.size() * 8);
+        return 0;
+    }
+    if (op == "rev_int" || op == "rev_t32") {  // int32 -> Lagrange
+        const int N = (int)arg(0);
+        FFT_Processor_Spqlios &P = (N == 1024) ? fftp1024 : fftp2048;
+        auto in = slurp(inp);
+        const size_t cnt = in.size() / 4 / N;
+        std::vector<double> out(cnt * N);
+        for (size_t c = 0; c < cnt; c++) {
+            if (op == "rev_int") P.execute_reverse_int(out.data() + c * N, (const int *)in.data() + c * N);
+            else P.execute_reverse_torus32(out.data() + c * N, (const int32_t *)in.data() + c * N);
+        }
+        spill(outp, out.data(), out.size() * 8);
+        return 0;
+    }
+    if (op == "rev_t64") {  // int64 -> Lagrange
+        const int N = (int)arg(0);
+        FFT_Processor_Spqlios &P = (N == 1024) ? fftp1024 : fftp2048;
+        auto in = slurp(inp);
+        const size_t cnt = in.size() / 8 / N;
+        std::vector<double> out(cnt * N);
+        for (size_t c = 0; c < cnt; c++) P.execute_reverse_torus64(out.data() + c * N, (const int64_t *)in.data() + c * N);
+        spill(outp, out.data(), out.size() * 8);
+        return 0;
+    }
+    if (op == "dir_t32") {  // Lagrange -> Torus32.  ONE N per process (static _2sN, fft_processor_spqlios.cpp:78)
+        const int N = (int)arg(0);
+        FFT_Processor_Spqlios &P = (N == 1024) ? fftp1024 : fftp2048;
+        auto in = slurp(inp);
+        const size_t cnt = in.size() / 8 / N;
+        std::vector<int32_t> out(cnt * N);
+        for (size_t c = 0; c < cnt; c++) P.execute_direct_torus32(out.data() + c * N, (const double *)in.data() + c * N);
+        spill(outp, out.data(), out.size() * 4);
+        return 0;
+    }
+    if (op == "dir_t64") {  // Lagrange -> Torus64.  ONE N per process (static _2sN, :106)
+        const int N = (int)arg(0);
+        FFT_Processor_Spqlios &P = (N == 1024) ? fftp1024 : fftp2048;
+        auto in = slurp(inp);
+        const size_t cnt = in.size() / 8 / N;
+        std::vector<int64_t> out(cnt * N);
+        for (size_t c = 0; c < cnt; c++) P.execute_direct_torus64(out.data() + c * N, (const double *)in.data() + c * N);
+        spill(outp, out.data(), out.size() * 8);
+        return 0;
+    }
+    if (op == "addmul") {  // args: N ; in: count * [res|a|b] (3N doubles) ; out: count*N doubles
+        const int N = (int)arg(0);
+        auto in = slurp(inp);
+        const size_t cnt = in.size() / 8 / (3 * (size_t)N);
+        std::vector<double> out(cnt * N);
+        for (size_t c = 0; c < cnt; c++) {
+            double *base = (double *)in.data() + c * 3 * N;
+            LagrangeHalfCPolynomialAddMulASM(base, base + N, base + 2 * N, N / 2);
+            memcpy(out.data() + c * N, base, (size_t)N * 8);
+        }
+        spill(outp, out.data(), out.size() * 8);
+        return 0;
+    }
+    if (op == "karat32" || op == "karat64") {  // in: count*[int32 poly1 (N) | torus poly2 (N)]
+        Globals *env = bare_globals();
+        auto in = slurp(inp);
+        if (op == "karat32") {
+            const int N = env->N_lvl1;
+            const size_t cnt = in.size() / (8 * (size_t)N);
+            std::vector<int32_t> out(cnt * N);
+            IntPolynomial a(N);
+            Torus32Polynomial b(N), r(N);
+            for (size_t c = 0; c < cnt; c++) {
+                memcpy(a.coefs, in.data() + c * 8 * N, 4 * (size_t)N);
+                memcpy(b.coefs, in.data() + c * 8 * N + 4 * N, 4 * (size_t)N);
+                torus32PolynomialMultKaratsuba_lvl1(&r, &a, &b, env);
+                memcpy(out.data() + c * N, r.coefs, 4 * (size_t)N);
+            }
+            spill(outp, out.data(), out.size() * 4);
+        } else {
+            const int N = env->N_lvl2;
+            const size_t cnt = in.size() / (12 * (size_t)N);
+            std::vector<int64_t> out(cnt * N);
+            IntPolynomial a(N);
+            Torus64Polynomial b(N), r(N);
+            for (size_t c = 0; c < cnt; c++) {
+                memcpy(a.coefs, in.data() + c * 12 * N, 4 * (size_t)N);
+                memcpy(b.coefs, in.data() + c * 12 * N + 4 * N, 8 * (size_t)N);
+                torus64PolynomialMultKaratsuba_lvl2(&r, &a, &b, env);
+                memcpy(out.data() + c * N, r.coefs, 8 * (size_t)N);
+            }
+            spill(outp, out.data(), out.size() * 8);
+        }
+        return 0;
+    }
+    if (op == "decomp64") {  // in: count*N2 int64 ; out: count*[l2][N2] int32
+        Globals *env = bare_globals();
+        const int N = env->N_lvl2, l = Globals::ell_lvl2;
+        auto in = slurp(inp);
+        const size_t cnt = in.size() / 8 / N;
+        std::vector<int32_t> out(cnt * l * N);
+        IntPolynomial *res = new_array1<IntPolynomial>(l, N);
+        Torus64Polynomial s(N);
+        for (size_t c = 0; c < cnt; c++) {
+            memcpy(s.coefs, in.data() + c * N * 8, (size_t)N * 8);
+            tGswTorus64PolynomialDecompH(res, &s, env);
+            for (int p = 0; p < l; p++) memcpy(out.data() + (c * l + p) * N, res[p].coefs, (size_t)N * 4);
+        }
+        spill(outp, out.data(), out.size() * 4);
+        return 0;
+    }
+    if (op == "premodswitch") {  // in: count*(n0+1) int32 ; out: count*(n0+1) int32
+        Globals *env = bare_globals();
+        const int n0 = Globals::n_lvl0;
+        auto in = slurp(inp);
+        const size_t cnt = in.size() / 4 / (n0 + 1);
+        std::vector<int32_t> out(cnt * (n0 + 1));
+        LweSample32 x(n0);
+        for (size_t c = 0; c < cnt; c++) {
+            memcpy(x.a, in.data() + c * (n0 + 1) * 4, (size_t)(n0 + 1) * 4);
+            preModSwitch((int *)out.data() + c * (n0 + 1), &x, env);
+        }
+        spill(outp, out.data(), out.size() * 4);
+        return 0;
+    }
+    if (op == "preks") {  // args: seed ; in: count*(N1+1) int32 ; out: count*(n0+1) int32
+        Globals *env = bare_globals();
+        const int n0 = Globals::n_lvl0, n1 = Globals::n_lvl1, t = Globals::kslength_lvl10;
+        const int base = 1 << Globals::ksbasebit_lvl10;
+        env->preKS = new_array3<LweSample32>(n1, t, base, n0);
+        SplitMix rng((uint64_t)arg(0));
+        for (int i = 0; i < n1; i++)
+            for (int j = 0; j < t; j++)
+                for (int u = 0; u < base; u++)
+                    for (int h = 0; h <= n0; h++) env->preKS[i][j][u].a[h] = rng.next32();
+        auto in = slurp(inp);
+        const size_t cnt = in.size() / 4 / (n1 + 1);
+        std::vector<int32_t> out(cnt * (n0 + 1));
+        LweSample32 x(n1), r(n0);
+        for (size_t c = 0; c < cnt; c++) {
+            memcpy(x.a, in.data() + c * (n1 + 1) * 4, (size_t)(n1 + 1) * 4);
+            preKeySwitch(&r, &x, env);
+            memcpy(out.data() + c * (n0 + 1), r.a, (size_t)(n0 + 1) * 4);
+        }
+        spill(outp, out.data(), out.size() * 4);
+        return 0;
+    }
+    if (op == "privks") {  // args: seed, u ; in: count*(n2+1) int64 ; out: count*[2][N1] int32
+        Globals *env = bare_globals();
+        const int n2 = Globals::n_lvl2, N1 = Globals::n_lvl1, t = Globals::kslength_lvl21;
+        const int base = 1 << Globals::ksbasebit_lvl21;
+        const int u = (int)arg(1);
+        // only plane u is touched by circuitPrivKS(.., u, ..): build that plane, alias the other
+        TLweSample32 ***plane = new_array3<TLweSample32>(n2 + 1, t, base, N1);
+        env->privKS = new TLweSample32 ***[2];
+        env->privKS[0] = env->privKS[1] = plane;
+        SplitMix rng((uint64_t)arg(0));
+        for (int i = 0; i <= n2; i++)
+            for (int j = 0; j < t; j++)
+                for (int d = 0; d < base; d++)
+                    for (int q = 0; q <= 1; q++)
+                        for (int p = 0; p < N1; p++) plane[i][j][d].a[q].coefs[p] = rng.next32();
+        auto in = slurp(inp);
+        const size_t cnt = in.size() / 8 / (n2 + 1);
+        std::vector<int32_t> out(cnt * 2 * N1);
+        LweSample64 x(n2);
+        TLweSample32 r(N1);
+        for (size_t c = 0; c < cnt; c++) {
+            memcpy(x.a, in.data() + c * (n2 + 1) * 8, (size_t)(n2 + 1) * 8);
+            circuitPrivKS(&r, u, &x, env);
+            for (int q = 0; q <= 1; q++) memcpy(out.data() + (c * 2 + q) * N1, r.a[q].coefs, (size_t)N1 * 4);
+        }
+        spill(outp, out.data(), out.size() * 4);
+        return 0;
+    }
+    if (op == "cbwoks") {
+        // The PoC blind rotation as written (always bkFFT[0], wrong sign, X^{+bbar});
+        // defined behaviour only while every abar[i] < N2.
+        // in: [int64 mu][int32 abar (n0+1)][pad to 8][double bkFFT0: [2*l2][2][N2]] ; out: int64 (N2+1)
+        Globals *env = bare_globals();
+        const int n0 = Globals::n_lvl0, N = Globals::n_lvl2, l = Globals::ell_lvl2;
+        auto in = slurp(inp);
+        const uint8_t *p = in.data();
+        int64_t mu;
+        memcpy(&mu, p, 8);
+        p += 8;
+        std::vector<int> abar(n0 + 1);
+        memcpy(abar.data(), p, (size_t)(n0 + 1) * 4);
+        p += (((size_t)(n0 + 1) * 4 + 7) / 8) * 8;
+        for (int i = 0; i < n0; i++)
+            if (abar[i] >= N) { fprintf(stderr, "cbwoks: abar[%d] >= N2 is out of bounds in the PoC\n", i); return 3; }
+        env->bkFFT = new_array1<TGswSampleFFT>(1, l, N);
+        for (int r = 0; r < 2 * l; r++)
+            for (int q = 0; q <= 1; q++) {
+                memcpy(env->bkFFT[0].allsamples[r].a[q].values, p, (size_t)N * 8);
+                p += (size_t)N * 8;
+            }
+        LweSample64 res(N);
+        circuitBootstrapWoKS(&res, mu, abar.data(), env);
+        spill(outp, res.a, (size_t)(N + 1) * 8);
+        return 0;
+    }
+    fprintf(stderr, "unknown op %s\n", op.c_str());
+    return 2;
+}
