@@ -1,0 +1,378 @@
+"""experimental-tfhe_amd: MI355X-native TFHE bootstrapping engine (thin ctypes binding).
+
+The product is the HIP shared library `libtfhe_amd.so` (built in-tree by build.py from
+csrc/) behind the C ABI of include/tfhe_amd.h.  This module only loads it and wraps the
+calls; it holds no arithmetic and has NO CPU fallback: if the library is missing, or no
+GPU is present, construction raises.
+
+The directory name contains a hyphen, so import it with
+    importlib.import_module("experimental-tfhe_amd")
+(the repo root on sys.path), as tests/conftest.py, bench.py and __graft_entry__.py do.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libtfhe_amd.so")
+
+OK, ERR_PARAM, ERR_DEVICE, ERR_STATE, ERR_ALLOC = range(5)
+
+# every symbol include/tfhe_amd.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "tfhe_amd_ctx_create", "tfhe_amd_ctx_destroy", "tfhe_amd_last_error", "tfhe_amd_version",
+    "tfhe_amd_set_stream", "tfhe_amd_sync", "tfhe_amd_get_tables",
+    "tfhe_amd_malloc", "tfhe_amd_free", "tfhe_amd_memcpy_h2d", "tfhe_amd_memcpy_d2h",
+    "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
+    "tfhe_amd_set_bootstrap_key", "tfhe_amd_load_keyswitch_key",
+    "tfhe_amd_ifft_int32", "tfhe_amd_ifft_torus64", "tfhe_amd_fft_torus32", "tfhe_amd_fft_torus64",
+    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_mux_rotate",
+    "tfhe_amd_blind_rotate", "tfhe_amd_blind_rotate_extract", "tfhe_amd_bootstrap_woks",
+    "tfhe_amd_keyswitch", "tfhe_amd_bootstrap", "tfhe_amd_bootstrap_streamed", "tfhe_amd_bootstrap_host",
+    "tfhe_amd_cb_bootstrap_woks", "tfhe_amd_modswitch",
+    "tfhe_amd_keygen_binary", "tfhe_amd_lwe_encrypt32", "tfhe_amd_lwe_phase32",
+    "tfhe_amd_keygen_bk_torus32", "tfhe_amd_keygen_bk_torus64", "tfhe_amd_keygen_ks32",
+]
+
+
+class Params(C.Structure):
+    """mirror of tfhe_amd_params (include/tfhe_amd.h)"""
+    _fields_ = [("torus_bits", C.c_int32), ("n", C.c_int32), ("N", C.c_int32), ("k", C.c_int32),
+                ("l", C.c_int32), ("Bgbit", C.c_int32), ("ks_t", C.c_int32), ("ks_basebit", C.c_int32),
+                ("ks_n_out", C.c_int32)]
+
+
+class TfheAmdError(RuntimeError):
+    pass
+
+
+_libs = {}
+
+
+def load_library(path=None):
+    """dlopen the HIP library.  Fails loudly when it has not been built."""
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise TfheAmdError(
+            f"{path} not found: build it with `python experimental-tfhe_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, i32p, i64p, f64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
+    lib.tfhe_amd_ctx_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp)]
+    lib.tfhe_amd_ctx_destroy.argtypes = [vp]
+    lib.tfhe_amd_ctx_destroy.restype = None
+    lib.tfhe_amd_last_error.argtypes = [vp]
+    lib.tfhe_amd_last_error.restype = C.c_char_p
+    lib.tfhe_amd_version.restype = C.c_char_p
+    lib.tfhe_amd_set_stream.argtypes = [vp, vp]
+    lib.tfhe_amd_sync.argtypes = [vp]
+    lib.tfhe_amd_get_tables.argtypes = [vp, f64p, f64p]
+    lib.tfhe_amd_malloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
+    lib.tfhe_amd_free.argtypes = [vp, vp]
+    lib.tfhe_amd_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.tfhe_amd_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.tfhe_amd_gsw_from_fft.argtypes = [vp, f64p, C.c_int, C.POINTER(vp)]
+    lib.tfhe_amd_gsw_from_torus.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    lib.tfhe_amd_gsw_free.argtypes = [vp]
+    lib.tfhe_amd_gsw_free.restype = None
+    lib.tfhe_amd_gsw_export_fft.argtypes = [vp, vp, C.c_int, f64p]
+    lib.tfhe_amd_set_bootstrap_key.argtypes = [vp, vp]
+    lib.tfhe_amd_load_keyswitch_key.argtypes = [vp, i32p]
+    lib.tfhe_amd_ifft_int32.argtypes = [vp, f64p, i32p, C.c_int]
+    lib.tfhe_amd_ifft_torus64.argtypes = [vp, f64p, i64p, C.c_int]
+    lib.tfhe_amd_fft_torus32.argtypes = [vp, i32p, f64p, C.c_int]
+    lib.tfhe_amd_fft_torus64.argtypes = [vp, i64p, f64p, C.c_int]
+    lib.tfhe_amd_lagrange_addmul.argtypes = [vp, f64p, f64p, f64p, C.c_int, C.c_int]
+    lib.tfhe_amd_extern_mul.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+    lib.tfhe_amd_mux_rotate.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
+    lib.tfhe_amd_blind_rotate.argtypes = [vp, vp, i32p, C.c_int]
+    lib.tfhe_amd_blind_rotate_extract.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
+    lib.tfhe_amd_bootstrap_woks.argtypes = [vp, i32p, C.c_int32, i32p, C.c_int]
+    lib.tfhe_amd_keyswitch.argtypes = [vp, i32p, i32p, C.c_int]
+    lib.tfhe_amd_bootstrap.argtypes = [vp, i32p, C.c_int32, i32p, C.c_int]
+    lib.tfhe_amd_bootstrap_streamed.argtypes = [vp, i32p, C.c_int32, i32p, C.c_int]
+    lib.tfhe_amd_bootstrap_host.argtypes = [vp, i32p, C.c_int32, i32p, C.c_int]
+    lib.tfhe_amd_cb_bootstrap_woks.argtypes = [vp, i64p, C.c_int64, i32p, C.c_int]
+    lib.tfhe_amd_modswitch.argtypes = [vp, i32p, i32p, C.c_int]
+    lib.tfhe_amd_keygen_binary.argtypes = [i32p, C.c_int, C.c_uint64, C.c_uint64]
+    lib.tfhe_amd_lwe_encrypt32.argtypes = [i32p, C.c_int32, C.c_double, i32p, C.c_int, C.c_uint64, C.c_uint64]
+    lib.tfhe_amd_lwe_phase32.argtypes = [i32p, i32p, C.c_int]
+    lib.tfhe_amd_lwe_phase32.restype = C.c_int32
+    lib.tfhe_amd_keygen_bk_torus32.argtypes = [i32p, i32p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                               C.c_uint64, C.c_uint64]
+    lib.tfhe_amd_keygen_bk_torus64.argtypes = list(lib.tfhe_amd_keygen_bk_torus32.argtypes)
+    lib.tfhe_amd_keygen_ks32.argtypes = [i32p, i32p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                         C.c_uint64, C.c_uint64]
+    _libs[path] = lib
+    return lib
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer:
+    """a hipMalloc'd buffer owned through the C ABI (tfhe_amd_malloc / tfhe_amd_free)"""
+
+    def __init__(self, eng, nbytes):
+        self.eng, self.nbytes = eng, int(nbytes)
+        p = C.c_void_p()
+        eng._chk(eng.lib.tfhe_amd_malloc(eng.ctx, C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.eng._chk(self.eng.lib.tfhe_amd_memcpy_h2d(self.eng.ctx, self.ptr, _np_ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.eng._chk(self.eng.lib.tfhe_amd_memcpy_d2h(self.eng.ctx, _np_ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.eng.lib.tfhe_amd_free(self.eng.ctx, self.ptr)
+            self.ptr = None
+
+
+class Engine:
+    """One context = one device + one stream + one parameter set (tfhe_amd_ctx)."""
+
+    def __init__(self, torus_bits=32, n=630, N=1024, l=2, Bgbit=10, ks_t=8, ks_basebit=2, ks_n_out=None,
+                 device=0, lib_path=None):
+        self.lib = load_library(lib_path)
+        self.params = Params(torus_bits, n, N, 1, l, Bgbit, ks_t, ks_basebit,
+                             (n if ks_n_out is None else ks_n_out) if ks_t else 0)
+        self.ctx = C.c_void_p()
+        rc = self.lib.tfhe_amd_ctx_create(C.byref(self.params), device, C.byref(self.ctx))
+        if rc != OK:
+            raise TfheAmdError(f"tfhe_amd_ctx_create failed with status {rc} "
+                               "(2 = no usable HIP device; this library has no CPU path)")
+        self.torus = np.int32 if torus_bits == 32 else np.int64
+        self._bufs = []
+        self._gsw = []
+
+    # -- plumbing
+    def _chk(self, rc):
+        if rc != OK:
+            raise TfheAmdError(f"status {rc}: {self.lib.tfhe_amd_last_error(self.ctx).decode()}")
+
+    def close(self):
+        if self.ctx:
+            for g in self._gsw:
+                self.lib.tfhe_amd_gsw_free(g)
+            for b in self._bufs:
+                b.free()
+            self.lib.tfhe_amd_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc(self, nbytes):
+        b = DeviceBuffer(self, nbytes)
+        self._bufs.append(b)
+        return b
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return self.alloc(max(arr.nbytes, 1)).upload(arr)
+
+    def sync(self):
+        self._chk(self.lib.tfhe_amd_sync(self.ctx))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.tfhe_amd_set_stream(self.ctx, stream_ptr))
+
+    def tables(self):
+        n = 2 * self.params.N - 8
+        f, r = np.empty(n), np.empty(n)
+        self._chk(self.lib.tfhe_amd_get_tables(self.ctx, _np_ptr(f), _np_ptr(r)))
+        return f, r
+
+    # -- keys
+    def gsw_from_fft(self, host_fft):
+        a = np.ascontiguousarray(host_fft, dtype=np.float64)
+        count = a.size // (2 * self.params.l * 2 * self.params.N)
+        g = C.c_void_p()
+        self._chk(self.lib.tfhe_amd_gsw_from_fft(self.ctx, _np_ptr(a), count, C.byref(g)))
+        self._gsw.append(g)
+        return g
+
+    def gsw_from_torus(self, host_torus):
+        a = np.ascontiguousarray(host_torus, dtype=self.torus)
+        count = a.size // (2 * self.params.l * 2 * self.params.N)
+        g = C.c_void_p()
+        self._chk(self.lib.tfhe_amd_gsw_from_torus(self.ctx, _np_ptr(a), count, C.byref(g)))
+        self._gsw.append(g)
+        return g
+
+    def gsw_export_fft(self, g, index):
+        out = np.empty((2 * self.params.l, 2, self.params.N))
+        self._chk(self.lib.tfhe_amd_gsw_export_fft(self.ctx, g, index, _np_ptr(out)))
+        return out
+
+    def set_bootstrap_key(self, g):
+        self._chk(self.lib.tfhe_amd_set_bootstrap_key(self.ctx, g))
+
+    def load_keyswitch_key(self, ks):
+        ks = np.ascontiguousarray(ks, dtype=np.int32)
+        self._chk(self.lib.tfhe_amd_load_keyswitch_key(self.ctx, _np_ptr(ks)))
+
+    # -- host-array convenience wrappers around the device-pointer ABI (tests, smoke)
+    def _roundtrip(self, fn, inp, out_dtype, out_shape, *extra):
+        d_in = self.to_device(inp)
+        out_nbytes = int(np.prod(out_shape)) * np.dtype(out_dtype).itemsize
+        d_out = self.alloc(max(out_nbytes, 1))
+        self._chk(fn(self.ctx, d_out.ptr, d_in.ptr, *extra))
+        res = d_out.download(out_dtype, out_shape)
+        d_in.free()
+        d_out.free()
+        return res
+
+    def ifft_int32(self, a):
+        a = np.ascontiguousarray(a, np.int32).reshape(-1, self.params.N)
+        return self._roundtrip(self.lib.tfhe_amd_ifft_int32, a, np.float64, a.shape, a.shape[0])
+
+    def ifft_torus64(self, a):
+        a = np.ascontiguousarray(a, np.int64).reshape(-1, self.params.N)
+        return self._roundtrip(self.lib.tfhe_amd_ifft_torus64, a, np.float64, a.shape, a.shape[0])
+
+    def fft_torus32(self, a):
+        a = np.ascontiguousarray(a, np.float64).reshape(-1, self.params.N)
+        return self._roundtrip(self.lib.tfhe_amd_fft_torus32, a, np.int32, a.shape, a.shape[0])
+
+    def fft_torus64(self, a):
+        a = np.ascontiguousarray(a, np.float64).reshape(-1, self.params.N)
+        return self._roundtrip(self.lib.tfhe_amd_fft_torus64, a, np.int64, a.shape, a.shape[0])
+
+    def lagrange_addmul(self, res, a, b, b_shared=False):
+        res = np.ascontiguousarray(res, np.float64).reshape(-1, self.params.N)
+        d_r, d_a, d_b = self.to_device(res), self.to_device(np.asarray(a, np.float64)), self.to_device(
+            np.asarray(b, np.float64))
+        self._chk(self.lib.tfhe_amd_lagrange_addmul(self.ctx, d_r.ptr, d_a.ptr, d_b.ptr, res.shape[0], int(b_shared)))
+        out = d_r.download(np.float64, res.shape)
+        for d in (d_r, d_a, d_b):
+            d.free()
+        return out
+
+    def extern_mul(self, acc, g, index=0):
+        acc = np.ascontiguousarray(acc, self.torus).reshape(-1, 2, self.params.N)
+        d = self.to_device(acc)
+        self._chk(self.lib.tfhe_amd_extern_mul(self.ctx, d.ptr, g, index, acc.shape[0]))
+        out = d.download(self.torus, acc.shape)
+        d.free()
+        return out
+
+    def mux_rotate(self, acc, g, index, barai):
+        acc = np.ascontiguousarray(acc, self.torus).reshape(-1, 2, self.params.N)
+        d, r = self.to_device(acc), self.to_device(np.ascontiguousarray(barai, np.int32))
+        self._chk(self.lib.tfhe_amd_mux_rotate(self.ctx, d.ptr, g, index, r.ptr, acc.shape[0]))
+        out = d.download(self.torus, acc.shape)
+        d.free()
+        r.free()
+        return out
+
+    def blind_rotate(self, acc, bara):
+        acc = np.ascontiguousarray(acc, self.torus).reshape(-1, 2, self.params.N)
+        bara = np.ascontiguousarray(bara, np.int32).reshape(acc.shape[0], self.params.n)
+        d, r = self.to_device(acc), self.to_device(bara)
+        self._chk(self.lib.tfhe_amd_blind_rotate(self.ctx, d.ptr, r.ptr, acc.shape[0]))
+        out = d.download(self.torus, acc.shape)
+        d.free()
+        r.free()
+        return out
+
+    def blind_rotate_extract(self, v, rot):
+        rot = np.ascontiguousarray(rot, np.int32).reshape(-1, self.params.n + 1)
+        v = np.ascontiguousarray(v, self.torus)
+        per_sample = int(v.ndim == 2)
+        B, N = rot.shape[0], self.params.N
+        d_v, d_r = self.to_device(v), self.to_device(rot)
+        d_o = self.alloc(B * (N + 1) * v.itemsize)
+        self._chk(self.lib.tfhe_amd_blind_rotate_extract(self.ctx, d_o.ptr, d_v.ptr, per_sample, d_r.ptr, B))
+        out = d_o.download(self.torus, (B, N + 1))
+        for d in (d_v, d_r, d_o):
+            d.free()
+        return out
+
+    def bootstrap_woks(self, mu, x):
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, self.params.n + 1)
+        return self._roundtrip(lambda c, o, i, b: self.lib.tfhe_amd_bootstrap_woks(c, o, int(mu), i, b), x, np.int32,
+                               (x.shape[0], self.params.N + 1), x.shape[0])
+
+    def keyswitch(self, x):
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, self.params.N + 1)
+        return self._roundtrip(self.lib.tfhe_amd_keyswitch, x, np.int32, (x.shape[0], self.params.ks_n_out + 1),
+                               x.shape[0])
+
+    def bootstrap(self, mu, x, streamed=False):
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, self.params.n + 1)
+        fn = self.lib.tfhe_amd_bootstrap_streamed if streamed else self.lib.tfhe_amd_bootstrap
+        return self._roundtrip(lambda c, o, i, b: fn(c, o, int(mu), i, b), x, np.int32, x.shape, x.shape[0])
+
+    def bootstrap_host(self, mu, x):
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, self.params.n + 1)
+        out = np.empty_like(x)
+        self._chk(self.lib.tfhe_amd_bootstrap_host(self.ctx, _np_ptr(out), int(mu), _np_ptr(x), x.shape[0]))
+        return out
+
+    def cb_bootstrap_woks(self, mu, abar):
+        abar = np.ascontiguousarray(abar, np.int32).reshape(-1, self.params.n + 1)
+        return self._roundtrip(lambda c, o, i, b: self.lib.tfhe_amd_cb_bootstrap_woks(c, o, int(mu), i, b), abar,
+                               np.int64, (abar.shape[0], self.params.N + 1), abar.shape[0])
+
+    def modswitch(self, x):
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, self.params.n + 1)
+        return self._roundtrip(self.lib.tfhe_amd_modswitch, x, np.int32, x.shape, x.shape[0])
+
+
+# ---- harness wrappers (host side of the ABI; usable without a GPU) --------------------
+def keygen_binary(n, seed, stream, lib_path=None):
+    lib = load_library(lib_path)
+    key = np.empty(n, np.int32)
+    assert lib.tfhe_amd_keygen_binary(_np_ptr(key), n, seed, stream) == OK
+    return key
+
+
+def lwe_encrypt32(mess, stdev, key, seed, stream, lib_path=None):
+    lib = load_library(lib_path)
+    key = np.ascontiguousarray(key, np.int32)
+    ct = np.empty(key.size + 1, np.int32)
+    assert lib.tfhe_amd_lwe_encrypt32(_np_ptr(ct), int(mess), float(stdev), _np_ptr(key), key.size, seed, stream) == OK
+    return ct
+
+
+def lwe_phase32(ct, key, lib_path=None):
+    lib = load_library(lib_path)
+    ct, key = np.ascontiguousarray(ct, np.int32), np.ascontiguousarray(key, np.int32)
+    return int(lib.tfhe_amd_lwe_phase32(_np_ptr(ct), _np_ptr(key), key.size))
+
+
+def keygen_bk_torus(torus_bits, lwe_key, tlwe_key, l, Bgbit, stdev, seed, stream, lib_path=None):
+    lib = load_library(lib_path)
+    lwe_key, tlwe_key = np.ascontiguousarray(lwe_key, np.int32), np.ascontiguousarray(tlwe_key, np.int32)
+    n, N = lwe_key.size, tlwe_key.size
+    dt = np.int32 if torus_bits == 32 else np.int64
+    fn = lib.tfhe_amd_keygen_bk_torus32 if torus_bits == 32 else lib.tfhe_amd_keygen_bk_torus64
+    bk = np.empty((n, 2 * l, 2, N), dt)
+    assert fn(_np_ptr(bk), _np_ptr(lwe_key), n, _np_ptr(tlwe_key), N, l, Bgbit, float(stdev), seed, stream) == OK
+    return bk
+
+
+def keygen_ks32(in_key, out_key, t, basebit, stdev, seed, stream, lib_path=None):
+    lib = load_library(lib_path)
+    in_key, out_key = np.ascontiguousarray(in_key, np.int32), np.ascontiguousarray(out_key, np.int32)
+    ks = np.empty((in_key.size, t, 1 << basebit, out_key.size + 1), np.int32)
+    assert lib.tfhe_amd_keygen_ks32(_np_ptr(ks), _np_ptr(in_key), in_key.size, _np_ptr(out_key), out_key.size, t,
+                                    basebit, float(stdev), seed, stream) == OK
+    return ks

@@ -1,0 +1,723 @@
+// tfhe_amd.hip -- host side of the C ABI (include/tfhe_amd.h): context, twiddle tables,
+// key upload, kernel dispatch.  Built by hipcc for gfx950 (build.sh).  There is no CPU
+// path in this library: without a device, context creation fails.
+#include "tfhe_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tfhe_amd.h"
+
+using namespace tfhe;
+
+// ------------------------------------------------------------------ context
+struct tfhe_amd_gsw {
+    tfhe_amd_ctx *ctx;
+    double2 *data_d;  // [count][2l][2][PPL][64], scaled by 2/N
+    int count;
+    size_t sample_complex;  // complex values per sample = 2l*2*N/2
+};
+
+struct tfhe_amd_ctx {
+    tfhe_amd_params p;
+    int device;
+    int logn;
+    hipStream_t stream;
+    bool own_stream;
+    std::string err;
+    std::vector<double> fft_trig, ifft_trig;  // reference layout
+    double2 *tw_d;                            // [2*NC]
+    Gadget gd;
+    const tfhe_amd_gsw *bk;
+    int32_t *ks_d;
+    // growable scratch
+    void *ws_lwe;
+    size_t ws_lwe_bytes;
+    void *ws_acc;
+    size_t ws_acc_bytes;
+};
+
+namespace {
+
+int fail(tfhe_amd_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define HIPCHECK(c, expr)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((c), TFHE_AMD_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define REQUIRE(c, cond, msg) \
+    do {                      \
+        if (!(cond)) return fail((c), TFHE_AMD_ERR_PARAM, msg); \
+    } while (0)
+
+// cos/sin(2 pi i / n) with the angle folded into the first quadrant so that symmetric
+// entries are bit-identical (the reference's accurate_cos/accurate_sin,
+// CB/spqlios/spqlios-fft-impl.cpp:99-113).  Host libm; tables are pinned by SHA-256 in tests.
+double quad_cos(long i, long n) {
+    i = ((i % n) + n) % n;
+    const double w = 2. * M_PI;
+    if (i >= 3 * n / 4) return cos(w * (double)(n - i) / (double)n);
+    if (i >= n / 2) return -cos(w * (double)(i - n / 2) / (double)n);
+    if (i >= n / 4) return -cos(w * (double)(n / 2 - i) / (double)n);
+    return cos(w * (double)i / (double)n);
+}
+double quad_sin(long i, long n) {
+    i = ((i % n) + n) % n;
+    const double w = 2. * M_PI;
+    if (i >= 3 * n / 4) return -sin(w * (double)(n - i) / (double)n);
+    if (i >= n / 2) return -sin(w * (double)(i - n / 2) / (double)n);
+    if (i >= n / 4) return sin(w * (double)(n / 2 - i) / (double)n);
+    return sin(w * (double)i / (double)n);
+}
+// append `count` (cos,sin) entries for angles mult*i in the reference's [4 cos | 4 sin] packing
+void ref_block(std::vector<double> &v, int count, long mult, long n) {
+    for (int i = 0; i < count; i += 4) {
+        for (int k = 0; k < 4; k++) v.push_back(quad_cos(mult * (i + k), n));
+        for (int k = 0; k < 4; k++) v.push_back(quad_sin(mult * (i + k), n));
+    }
+}
+
+// Builds (a) the two tables exactly as new_ifft_table/new_fft_table lay them out and
+// (b) the kernels' complex table; verifies fft table == conj(ifft table) entry by entry
+// (with the quarter-turn exception of tfhe_kernels.h flip_sign_if), which the kernels rely on.
+bool build_tables(int N, std::vector<double> &fft_trig, std::vector<double> &ifft_trig, std::vector<double2> &tw) {
+    const long n = 2L * N;
+    const int NC = N / 2;
+    ifft_trig.clear();
+    fft_trig.clear();
+    ref_block(ifft_trig, NC, 1, n);
+    for (int nn = NC; nn >= 8; nn /= 2) ref_block(ifft_trig, nn / 2, n / nn, n);
+    for (int h = 4; h < NC; h *= 2) ref_block(fft_trig, h, -(n / (2 * h)), n);
+    ref_block(fft_trig, NC, -1, n);
+    tw.assign((size_t)2 * NC, make_double2(0., 0.));
+    auto rc = [](const std::vector<double> &v, size_t base, int e) { return v[base + 8 * (e >> 2) + (e & 3)]; };
+    auto rs = [](const std::vector<double> &v, size_t base, int e) { return v[base + 8 * (e >> 2) + 4 + (e & 3)]; };
+    bool conj_ok = true;
+    // twist: ifft block 0, fft last block
+    const size_t fft_twist = fft_trig.size() - (size_t)2 * NC;
+    for (int j = 0; j < NC; j++) {
+        tw[j] = make_double2(rc(ifft_trig, 0, j), rs(ifft_trig, 0, j));
+        conj_ok &= (rc(fft_trig, fft_twist, j) == tw[j].x) && (rs(fft_trig, fft_twist, j) == -tw[j].y);
+    }
+    size_t ib = (size_t)2 * NC;  // ifft stage blocks: h = NC/2 .. 4
+    for (int h = NC / 2; h >= 4; h /= 2) {
+        // fft block for half-size h starts after blocks 4, 8, .., h/2: 2*(4+8+..+h/2) = 2*(h-4)
+        const size_t fb = (size_t)2 * (h - 4);
+        const int base = 2 * NC - 2 * h;
+        for (int o = 0; o < h; o++) {
+            tw[base + o] = make_double2(rc(ifft_trig, ib, o), rs(ifft_trig, ib, o));
+            // conjugate, except cos at the quarter turn, which has the opposite sign (see flip_sign_if)
+            const double want_c = (o == h / 2) ? -tw[base + o].x : tw[base + o].x;
+            conj_ok &= (rc(fft_trig, fb, o) == want_c) && (rs(fft_trig, fb, o) == -tw[base + o].y);
+        }
+        ib += (size_t)2 * h;
+    }
+    return conj_ok;
+}
+
+int ilog2(int v) {
+    int r = 0;
+    while ((1 << r) < v) r++;
+    return r;
+}
+
+template <typename KernelT>
+int set_lds(tfhe_amd_ctx *c, KernelT kernel, size_t bytes) {
+    HIPCHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return TFHE_AMD_OK;
+}
+
+// one instantiation per (torus, N): waves per workgroup chosen so LDS fits 160 KiB
+template <typename T, int LOGN, int WAVES>
+int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
+    using Lds = BlindRotateLds<T, LOGN, WAVES>;
+    auto kernel = k_blind_rotate<T, LOGN, WAVES>;
+    static bool configured = false;  // per process; the attribute is per function
+    if (!configured) {
+        int rc = set_lds(c, kernel, Lds::total);
+        if (rc) return rc;
+        configured = true;
+    }
+    const int blocks = (a.batch + WAVES - 1) / WAVES;
+    TFHE_LAUNCH((k_blind_rotate<T, LOGN, WAVES>), dim3(blocks), dim3(WAVES * 64), Lds::total, c->stream, a);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
+    return c->logn == 10 ? launch_br_t<int32_t, 10, 8>(c, a) : launch_br_t<int32_t, 11, 4>(c, a);
+}
+int launch_br64(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
+    return c->logn == 10 ? launch_br_t<int64_t, 10, 4>(c, a) : launch_br_t<int64_t, 11, 3>(c, a);
+}
+
+template <typename TIN, int LOGN>
+int launch_ifft_t(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
+    constexpr int WAVES = 4;
+    using Lds = FftLds<LOGN, WAVES>;
+    auto kernel = k_ifft_batch<TIN, LOGN, WAVES>;
+    static bool configured = false;
+    if (!configured) {
+        int rc = set_lds(c, kernel, Lds::total);
+        if (rc) return rc;
+        configured = true;
+    }
+    TFHE_LAUNCH((k_ifft_batch<TIN, LOGN, WAVES>), dim3((batch + WAVES - 1) / WAVES), dim3(WAVES * 64), Lds::total,
+                c->stream, out_d, in_d, (const double2 *)c->tw_d, batch);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+template <typename TOUT, int LOGN>
+int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
+    constexpr int WAVES = 4;
+    using Lds = FftLds<LOGN, WAVES>;
+    auto kernel = k_fft_batch<TOUT, LOGN, WAVES>;
+    static bool configured = false;
+    if (!configured) {
+        int rc = set_lds(c, kernel, Lds::total);
+        if (rc) return rc;
+        configured = true;
+    }
+    TFHE_LAUNCH((k_fft_batch<TOUT, LOGN, WAVES>), dim3((batch + WAVES - 1) / WAVES), dim3(WAVES * 64), Lds::total,
+                c->stream, out_d, in_d, (const double2 *)c->tw_d, batch);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+
+int grow(tfhe_amd_ctx *c, void **buf, size_t *have, size_t need) {
+    if (*have >= need) return TFHE_AMD_OK;
+    if (*buf) {
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        HIPCHECK(c, hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    HIPCHECK(c, hipMalloc(buf, need));
+    *have = need;
+    return TFHE_AMD_OK;
+}
+
+size_t torus_bytes(const tfhe_amd_ctx *c) { return (size_t)c->p.torus_bits / 8; }
+
+int pack_rows(tfhe_amd_ctx *c, double2 *dst_d, const double *src_d, long long rows) {
+    const long long total = rows * (c->p.N / 2);
+    const int blocks = (int)((total + 255) / 256);
+    if (c->logn == 10)
+        TFHE_LAUNCH((k_pack_gsw<10>), dim3(blocks), dim3(256), 0, c->stream, dst_d, src_d, rows);
+    else
+        TFHE_LAUNCH((k_pack_gsw<11>), dim3(blocks), dim3(256), 0, c->stream, dst_d, src_d, rows);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+
+// common part of every blind-rotation-shaped call
+template <typename T>
+void fill_common(const tfhe_amd_ctx *c, BlindRotateArgs<T> &a, const tfhe_amd_gsw *g, int index, int steps, int batch) {
+    memset(&a, 0, sizeof(a));
+    a.bk = g->data_d + (size_t)index * g->sample_complex;
+    a.bk_step_stride = (long long)g->sample_complex;
+    a.tw = c->tw_d;
+    a.gd = c->gd;
+    a.n_steps = steps;
+    a.batch = batch;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char *tfhe_amd_version(void) { return "experimental-tfhe_amd 0.1 (gfx950)"; }
+
+int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out) {
+    if (!p || !out) return TFHE_AMD_ERR_PARAM;
+    *out = nullptr;
+    if (p->k != 1) return TFHE_AMD_ERR_PARAM;
+    if (p->N != 1024 && p->N != 2048) return TFHE_AMD_ERR_PARAM;
+    if (p->torus_bits != 32 && p->torus_bits != 64) return TFHE_AMD_ERR_PARAM;
+    if (p->l < 1 || p->l > 8 || p->Bgbit < 1 || p->l * p->Bgbit > p->torus_bits - 1) return TFHE_AMD_ERR_PARAM;
+    if (p->n < 1) return TFHE_AMD_ERR_PARAM;
+    if (p->ks_t < 0 || (p->ks_t > 0 && (p->ks_basebit < 1 || p->ks_t * p->ks_basebit > 31 || p->ks_n_out < 1)))
+        return TFHE_AMD_ERR_PARAM;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return TFHE_AMD_ERR_DEVICE;  // no GPU: fail loudly, there is no CPU fallback
+    tfhe_amd_ctx *c = new tfhe_amd_ctx();
+    c->p = *p;
+    c->device = device;
+    c->logn = ilog2(p->N);
+    c->stream = nullptr;
+    c->own_stream = false;
+    c->tw_d = nullptr;
+    c->bk = nullptr;
+    c->ks_d = nullptr;
+    c->ws_lwe = c->ws_acc = nullptr;
+    c->ws_lwe_bytes = c->ws_acc_bytes = 0;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete c;
+        return TFHE_AMD_ERR_DEVICE;
+    }
+#ifndef TFHE_EMU
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return TFHE_AMD_ERR_DEVICE;
+    }
+    c->own_stream = true;
+#endif
+    std::vector<double2> tw;
+    if (!build_tables(p->N, c->fft_trig, c->ifft_trig, tw)) {
+        delete c;
+        return TFHE_AMD_ERR_PARAM;  // libm broke the conjugate symmetry the kernels rely on
+    }
+    if (hipMalloc((void **)&c->tw_d, tw.size() * sizeof(double2)) != hipSuccess ||
+        hipMemcpy(c->tw_d, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) {
+        delete c;
+        return TFHE_AMD_ERR_DEVICE;
+    }
+    // gadget offset: Torus32 per TGswParams ctor (tgsw_functions.cpp:29-35), Torus64 per poc:349-350
+    c->gd.Bgbit = p->Bgbit;
+    c->gd.l = p->l;
+    if (p->torus_bits == 32) {
+        uint32_t s = 0;
+        for (int i = 0; i < p->l; i++) s += 1u << (32 - (i + 1) * p->Bgbit);
+        c->gd.offset = (uint32_t)(s * (1u << (p->Bgbit - 1)));
+    } else {
+        uint64_t s = 0;
+        for (int i = 0; i <= p->l; i++) s |= 1ull << (63 - i * p->Bgbit);
+        c->gd.offset = s;
+    }
+    *out = c;
+    return TFHE_AMD_OK;
+}
+
+void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->tw_d) (void)hipFree(c->tw_d);
+    if (c->ks_d) (void)hipFree(c->ks_d);
+    if (c->ws_lwe) (void)hipFree(c->ws_lwe);
+    if (c->ws_acc) (void)hipFree(c->ws_acc);
+#ifndef TFHE_EMU
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+#endif
+    delete c;
+}
+
+const char *tfhe_amd_last_error(const tfhe_amd_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int tfhe_amd_set_stream(tfhe_amd_ctx *c, void *s) {
+    if (!c) return TFHE_AMD_ERR_PARAM;
+#ifndef TFHE_EMU
+    if (s) {
+        if (c->own_stream) {
+            HIPCHECK(c, hipStreamSynchronize(c->stream));
+            HIPCHECK(c, hipStreamDestroy(c->stream));
+            c->own_stream = false;
+        }
+        c->stream = (hipStream_t)s;
+    } else if (!c->own_stream) {
+        HIPCHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+#else
+    (void)s;
+#endif
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_sync(tfhe_amd_ctx *c) {
+    if (!c) return TFHE_AMD_ERR_PARAM;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_get_tables(const tfhe_amd_ctx *c, double *fft_trig, double *ifft_trig) {
+    if (!c) return TFHE_AMD_ERR_PARAM;
+    if (fft_trig) memcpy(fft_trig, c->fft_trig.data(), c->fft_trig.size() * 8);
+    if (ifft_trig) memcpy(ifft_trig, c->ifft_trig.data(), c->ifft_trig.size() * 8);
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_malloc(tfhe_amd_ctx *c, void **dptr, size_t bytes) {
+    if (!c || !dptr) return TFHE_AMD_ERR_PARAM;
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipMalloc(dptr, bytes ? bytes : 1));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_free(tfhe_amd_ctx *c, void *dptr) {
+    if (!c) return TFHE_AMD_ERR_PARAM;
+    if (dptr) {
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        HIPCHECK(c, hipFree(dptr));
+    }
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_memcpy_h2d(tfhe_amd_ctx *c, void *dst_d, const void *src, size_t bytes) {
+    if (!c || (!dst_d && bytes) || (!src && bytes)) return TFHE_AMD_ERR_PARAM;
+    HIPCHECK(c, hipMemcpyAsync(dst_d, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_memcpy_d2h(tfhe_amd_ctx *c, void *dst, const void *src_d, size_t bytes) {
+    if (!c || (!dst && bytes) || (!src_d && bytes)) return TFHE_AMD_ERR_PARAM;
+    HIPCHECK(c, hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return TFHE_AMD_OK;
+}
+
+// ---- keys
+static int gsw_alloc(tfhe_amd_ctx *c, int count, tfhe_amd_gsw **out) {
+    tfhe_amd_gsw *g = new tfhe_amd_gsw();
+    g->ctx = c;
+    g->count = count;
+    g->sample_complex = (size_t)2 * c->p.l * 2 * (c->p.N / 2);
+    g->data_d = nullptr;
+    if (hipMalloc((void **)&g->data_d, g->sample_complex * count * sizeof(double2)) != hipSuccess) {
+        delete g;
+        return fail(c, TFHE_AMD_ERR_ALLOC, "hipMalloc(gsw)");
+    }
+    *out = g;
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_gsw_from_fft(tfhe_amd_ctx *c, const double *gsw_fft, int count, tfhe_amd_gsw **out) {
+    if (!c || !gsw_fft || !out || count < 1) return TFHE_AMD_ERR_PARAM;
+    const long long rows = (long long)count * 2 * c->p.l * 2;
+    const size_t bytes = (size_t)rows * c->p.N * sizeof(double);
+    double *tmp = nullptr;
+    HIPCHECK(c, hipMalloc((void **)&tmp, bytes));
+    int rc = TFHE_AMD_OK;
+    tfhe_amd_gsw *g = nullptr;
+    if (hipMemcpyAsync(tmp, gsw_fft, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = fail(c, TFHE_AMD_ERR_DEVICE, "upload gsw");
+    if (!rc) rc = gsw_alloc(c, count, &g);
+    if (!rc) rc = pack_rows(c, g->data_d, tmp, rows);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (rc) {
+        if (g) tfhe_amd_gsw_free(g);
+        return rc;
+    }
+    *out = g;
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_gsw_from_torus(tfhe_amd_ctx *c, const void *gsw_torus, int count, tfhe_amd_gsw **out) {
+    if (!c || !gsw_torus || !out || count < 1) return TFHE_AMD_ERR_PARAM;
+    const long long rows = (long long)count * 2 * c->p.l * 2;
+    const size_t tbytes = (size_t)rows * c->p.N * torus_bytes(c);
+    const size_t dbytes = (size_t)rows * c->p.N * sizeof(double);
+    void *tor = nullptr;
+    double *lag = nullptr;
+    HIPCHECK(c, hipMalloc(&tor, tbytes));
+    if (hipMalloc((void **)&lag, dbytes) != hipSuccess) {
+        (void)hipFree(tor);
+        return fail(c, TFHE_AMD_ERR_ALLOC, "hipMalloc(lagrange tmp)");
+    }
+    int rc = TFHE_AMD_OK;
+    tfhe_amd_gsw *g = nullptr;
+    if (hipMemcpyAsync(tor, gsw_torus, tbytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = fail(c, TFHE_AMD_ERR_DEVICE, "upload gsw");
+    // tGswToFFTConvert: every polynomial through execute_reverse_torus32/64
+    if (!rc) {
+        if (c->p.torus_bits == 32)
+            rc = tfhe_amd_ifft_int32(c, lag, (const int32_t *)tor, (int)rows);
+        else
+            rc = tfhe_amd_ifft_torus64(c, lag, (const int64_t *)tor, (int)rows);
+    }
+    if (!rc) rc = gsw_alloc(c, count, &g);
+    if (!rc) rc = pack_rows(c, g->data_d, lag, rows);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(tor);
+    (void)hipFree(lag);
+    if (rc) {
+        if (g) tfhe_amd_gsw_free(g);
+        return rc;
+    }
+    *out = g;
+    return TFHE_AMD_OK;
+}
+
+void tfhe_amd_gsw_free(tfhe_amd_gsw *g) {
+    if (!g) return;
+    if (g->ctx && g->ctx->bk == g) g->ctx->bk = nullptr;
+    if (g->data_d) {
+        (void)hipStreamSynchronize(g->ctx->stream);
+        (void)hipFree(g->data_d);
+    }
+    delete g;
+}
+
+int tfhe_amd_gsw_export_fft(tfhe_amd_ctx *c, const tfhe_amd_gsw *g, int index, double *out) {
+    if (!c || !g || !out || index < 0 || index >= g->count) return TFHE_AMD_ERR_PARAM;
+    const int N = c->p.N, NC = N / 2, PPL = NC / 64;
+    std::vector<double2> h(g->sample_complex);
+    HIPCHECK(c, hipMemcpyAsync(h.data(), g->data_d + (size_t)index * g->sample_complex,
+                               g->sample_complex * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    const double unscale = (double)N / 2.0;  // exact: power of two
+    const int rows = 2 * c->p.l * 2;
+    for (int r = 0; r < rows; r++)
+        for (int m = 0; m < PPL; m++)
+            for (int t = 0; t < 64; t++) {
+                const double2 v = h[((size_t)r * PPL + m) * 64 + t];
+                out[(size_t)r * N + PPL * t + m] = v.x * unscale;
+                out[(size_t)r * N + NC + PPL * t + m] = v.y * unscale;
+            }
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_set_bootstrap_key(tfhe_amd_ctx *c, const tfhe_amd_gsw *bk) {
+    if (!c) return TFHE_AMD_ERR_PARAM;
+    REQUIRE(c, bk && bk->ctx == c && bk->count == c->p.n, "bootstrap key must hold exactly n TGSW samples of this context");
+    c->bk = bk;
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *c, const int32_t *ks) {
+    if (!c || !ks) return TFHE_AMD_ERR_PARAM;
+    REQUIRE(c, c->p.ks_t > 0, "context has no key-switch parameters");
+    const size_t bytes = (size_t)c->p.N * c->p.ks_t * ((size_t)1 << c->p.ks_basebit) * (c->p.ks_n_out + 1) * 4;
+    if (!c->ks_d) HIPCHECK(c, hipMalloc((void **)&c->ks_d, bytes));
+    HIPCHECK(c, hipMemcpyAsync(c->ks_d, ks, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return TFHE_AMD_OK;
+}
+
+// ---- L1
+int tfhe_amd_ifft_int32(tfhe_amd_ctx *c, double *out_d, const int32_t *in_d, int batch) {
+    if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    return c->logn == 10 ? launch_ifft_t<int32_t, 10>(c, out_d, in_d, batch) : launch_ifft_t<int32_t, 11>(c, out_d, in_d, batch);
+}
+int tfhe_amd_ifft_torus64(tfhe_amd_ctx *c, double *out_d, const int64_t *in_d, int batch) {
+    if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    return c->logn == 10 ? launch_ifft_t<int64_t, 10>(c, out_d, in_d, batch) : launch_ifft_t<int64_t, 11>(c, out_d, in_d, batch);
+}
+int tfhe_amd_fft_torus32(tfhe_amd_ctx *c, int32_t *out_d, const double *in_d, int batch) {
+    if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    return c->logn == 10 ? launch_fft_t<int32_t, 10>(c, out_d, in_d, batch) : launch_fft_t<int32_t, 11>(c, out_d, in_d, batch);
+}
+int tfhe_amd_fft_torus64(tfhe_amd_ctx *c, int64_t *out_d, const double *in_d, int batch) {
+    if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    return c->logn == 10 ? launch_fft_t<int64_t, 10>(c, out_d, in_d, batch) : launch_fft_t<int64_t, 11>(c, out_d, in_d, batch);
+}
+int tfhe_amd_lagrange_addmul(tfhe_amd_ctx *c, double *res_d, const double *a_d, const double *b_d, int batch, int b_shared) {
+    if (!c || !res_d || !a_d || !b_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    const int Ns2 = c->p.N / 2;
+    const long long total = (long long)batch * Ns2;
+    TFHE_LAUNCH(k_lagrange_addmul, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, res_d, a_d, b_d, Ns2,
+                (long long)(b_shared ? 0 : c->p.N), total);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+
+// ---- L2
+static int run_steps(tfhe_amd_ctx *c, void *acc_d, const tfhe_amd_gsw *g, int index, int steps, const int32_t *rot_d,
+                     int rot_stride, int batch, uint32_t flags) {
+    if (c->p.torus_bits == 32) {
+        BlindRotateArgs<int32_t> a;
+        fill_common(c, a, g, index, steps, batch);
+        a.acc_io = (int32_t *)acc_d;
+        a.rot = rot_d;
+        a.rot_stride = rot_stride;
+        a.flags = flags;
+        return launch_br32(c, a);
+    }
+    BlindRotateArgs<int64_t> a;
+    fill_common(c, a, g, index, steps, batch);
+    a.acc_io = (int64_t *)acc_d;
+    a.rot = rot_d;
+    a.rot_stride = rot_stride;
+    a.flags = flags;
+    return launch_br64(c, a);
+}
+
+int tfhe_amd_extern_mul(tfhe_amd_ctx *c, void *acc_d, const tfhe_amd_gsw *g, int index, int batch) {
+    if (!c || !acc_d || !g || batch < 0) return TFHE_AMD_ERR_PARAM;
+    REQUIRE(c, g->ctx == c && index >= 0 && index < g->count, "bad TGSW handle/index");
+    if (batch == 0) return TFHE_AMD_OK;
+    return run_steps(c, acc_d, g, index, 1, nullptr, 0, batch, BR_NO_ROTATE);
+}
+int tfhe_amd_mux_rotate(tfhe_amd_ctx *c, void *acc_d, const tfhe_amd_gsw *g, int index, const int32_t *barai_d, int batch) {
+    if (!c || !acc_d || !g || !barai_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    REQUIRE(c, g->ctx == c && index >= 0 && index < g->count, "bad TGSW handle/index");
+    if (batch == 0) return TFHE_AMD_OK;
+    return run_steps(c, acc_d, g, index, 1, barai_d, 1, batch, 0);
+}
+
+// ---- L3
+int tfhe_amd_blind_rotate(tfhe_amd_ctx *c, void *acc_d, const int32_t *bara_d, int batch) {
+    if (!c || !acc_d || !bara_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
+    if (batch == 0) return TFHE_AMD_OK;
+    return run_steps(c, acc_d, c->bk, 0, c->p.n, bara_d, c->p.n, batch, 0);
+}
+
+int tfhe_amd_blind_rotate_extract(tfhe_amd_ctx *c, void *lwe_out_d, const void *v_d, int v_per_sample,
+                                  const int32_t *rot_d, int batch) {
+    if (!c || !lwe_out_d || !v_d || !rot_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
+    if (batch == 0) return TFHE_AMD_OK;
+    const uint32_t flags = BR_INIT_TESTVEC | BR_EXTRACT;
+    if (c->p.torus_bits == 32) {
+        BlindRotateArgs<int32_t> a;
+        fill_common(c, a, c->bk, 0, c->p.n, batch);
+        a.rot = rot_d;
+        a.rot_stride = c->p.n + 1;
+        a.tv = (const int32_t *)v_d;
+        a.tv_stride = v_per_sample ? c->p.N : 0;
+        a.lwe_out = (int32_t *)lwe_out_d;
+        a.flags = flags;
+        return launch_br32(c, a);
+    }
+    BlindRotateArgs<int64_t> a;
+    fill_common(c, a, c->bk, 0, c->p.n, batch);
+    a.rot = rot_d;
+    a.rot_stride = c->p.n + 1;
+    a.tv = (const int64_t *)v_d;
+    a.tv_stride = v_per_sample ? c->p.N : 0;
+    a.lwe_out = (int64_t *)lwe_out_d;
+    a.flags = flags;
+    return launch_br64(c, a);
+}
+
+int tfhe_amd_bootstrap_woks(tfhe_amd_ctx *c, int32_t *lwe_out_d, int32_t mu, const int32_t *x_d, int batch) {
+    if (!c || !lwe_out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    REQUIRE(c, c->p.torus_bits == 32, "tfhe_bootstrap_woKS_FFT is a Torus32 operation");
+    if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
+    if (batch == 0) return TFHE_AMD_OK;
+    BlindRotateArgs<int32_t> a;
+    fill_common(c, a, c->bk, 0, c->p.n, batch);
+    a.rot = x_d;
+    a.rot_stride = c->p.n + 1;
+    a.tv_const = mu;
+    a.lwe_out = lwe_out_d;
+    a.flags = BR_INIT_TESTVEC | BR_EXTRACT | BR_MODSWITCH | BR_TV_CONST;
+    return launch_br32(c, a);
+}
+
+int tfhe_amd_keyswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
+    if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (!c->ks_d) return fail(c, TFHE_AMD_ERR_STATE, "no key-switch key");
+    if (batch == 0) return TFHE_AMD_OK;
+    TFHE_LAUNCH(k_keyswitch32, dim3(batch), dim3(256), 0, c->stream, out_d, in_d, (const int32_t *)c->ks_d, c->p.N,
+                c->p.ks_n_out, c->p.ks_t, c->p.ks_basebit, batch);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_bootstrap(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, const int32_t *x_d, int batch) {
+    if (!c || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    int rc = grow(c, &c->ws_lwe, &c->ws_lwe_bytes, (size_t)batch * (c->p.N + 1) * 4);
+    if (rc) return rc;
+    rc = tfhe_amd_bootstrap_woks(c, (int32_t *)c->ws_lwe, mu, x_d, batch);
+    if (rc) return rc;
+    return tfhe_amd_keyswitch(c, out_d, (const int32_t *)c->ws_lwe, batch);
+}
+
+int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, const int32_t *x_d, int batch) {
+    if (!c || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    REQUIRE(c, c->p.torus_bits == 32, "Torus32 operation");
+    if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
+    if (batch == 0) return TFHE_AMD_OK;
+    const int n = c->p.n, N = c->p.N;
+    int rc = grow(c, &c->ws_lwe, &c->ws_lwe_bytes, (size_t)batch * (N + 1) * 4);
+    if (rc) return rc;
+    rc = grow(c, &c->ws_acc, &c->ws_acc_bytes, (size_t)batch * 2 * N * 4);
+    if (rc) return rc;
+    BlindRotateArgs<int32_t> a;
+    // 1. acc = (0, X^{-barb} * mu)           (0 CMux steps, store the accumulator)
+    fill_common(c, a, c->bk, 0, 0, batch);
+    a.rot = x_d + n;  // entry [n_steps = 0] of each row must be b
+    a.rot_stride = n + 1;
+    a.tv_const = mu;
+    a.acc_io = (int32_t *)c->ws_acc;
+    a.flags = BR_INIT_TESTVEC | BR_MODSWITCH | BR_TV_CONST;
+    rc = launch_br32(c, a);
+    // 2. one launch per CMux step, accumulators round-trip through HBM
+    for (int i = 0; i < n && !rc; i++) {
+        fill_common(c, a, c->bk, i, 1, batch);
+        a.rot = x_d + i;
+        a.rot_stride = n + 1;
+        a.acc_io = (int32_t *)c->ws_acc;
+        a.flags = BR_MODSWITCH;
+        rc = launch_br32(c, a);
+    }
+    if (rc) return rc;
+    // 3. sample extraction (0 steps)
+    fill_common(c, a, c->bk, 0, 0, batch);
+    a.rot = x_d;
+    a.rot_stride = n + 1;
+    a.acc_io = (int32_t *)c->ws_acc;
+    a.lwe_out = (int32_t *)c->ws_lwe;
+    a.flags = BR_EXTRACT;
+    rc = launch_br32(c, a);
+    if (rc) return rc;
+    return tfhe_amd_keyswitch(c, out_d, (const int32_t *)c->ws_lwe, batch);
+}
+
+int tfhe_amd_bootstrap_host(tfhe_amd_ctx *c, int32_t *out, int32_t mu, const int32_t *x, int batch) {
+    if (!c || !out || !x || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    const size_t bytes = (size_t)batch * (c->p.n + 1) * 4;
+    void *in_d = nullptr, *out_d = nullptr;
+    HIPCHECK(c, hipMalloc(&in_d, bytes));
+    if (hipMalloc(&out_d, bytes) != hipSuccess) {
+        (void)hipFree(in_d);
+        return fail(c, TFHE_AMD_ERR_ALLOC, "hipMalloc");
+    }
+    int rc = tfhe_amd_memcpy_h2d(c, in_d, x, bytes);
+    if (!rc) rc = tfhe_amd_bootstrap(c, (int32_t *)out_d, mu, (const int32_t *)in_d, batch);
+    if (!rc) rc = tfhe_amd_memcpy_d2h(c, out, out_d, bytes);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(in_d);
+    (void)hipFree(out_d);
+    return rc;
+}
+
+int tfhe_amd_cb_bootstrap_woks(tfhe_amd_ctx *c, int64_t *lwe_out_d, int64_t mu, const int32_t *abar_d, int batch) {
+    if (!c || !lwe_out_d || !abar_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    REQUIRE(c, c->p.torus_bits == 64, "circuitBootstrapWoKS works on Torus64");
+    if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
+    if (batch == 0) return TFHE_AMD_OK;
+    BlindRotateArgs<int64_t> a;
+    fill_common(c, a, c->bk, 0, c->p.n, batch);
+    a.rot = abar_d;
+    a.rot_stride = c->p.n + 1;
+    a.tv_const = mu / 2;
+    a.out_b_add = mu / 2;
+    a.lwe_out = lwe_out_d;
+    a.flags = BR_INIT_TESTVEC | BR_EXTRACT | BR_TV_HALF;
+    return launch_br64(c, a);
+}
+
+int tfhe_amd_modswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *x_d, int batch) {
+    if (!c || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    const long long total = (long long)batch * (c->p.n + 1);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (c->logn == 10)
+        TFHE_LAUNCH((k_modswitch<10>), dim3(blocks), dim3(256), 0, c->stream, out_d, x_d, total);
+    else
+        TFHE_LAUNCH((k_modswitch<11>), dim3(blocks), dim3(256), 0, c->stream, out_d, x_d, total);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,695 @@
+// tfhe_kernels.h -- CDNA4 (gfx950) kernels of the TFHE bootstrapping hot path.
+//
+// One 64-lane wavefront owns one ciphertext for the whole blind rotation:
+//   * the TLWE accumulator (k+1 = 2 polynomials) lives in the wave's slice of LDS,
+//   * every polynomial transform is a wave-level anticyclic FFT over Z[X]/(X^N+1):
+//     N/2 complex points, N/128 per lane, radix-2 butterflies grouped in three
+//     register passes with two LDS transposes in between (no workgroup barrier:
+//     a wave's DS instructions execute in order),
+//   * the Fourier-domain accumulator of the external product never leaves registers,
+//   * bootstrapping-key rows are read straight from HBM/L2 with one coalesced 16-byte
+//     load per lane per complex value, in a layout fixed at key-upload time.
+//
+// Arithmetic follows the reference's FMA assembly operation by operation (SURVEY.md
+// App. A; CB/spqlios/spqlios-{i,}fft-fma.s, lagrangehalfc_impl_fma.s), so Torus32 /
+// Torus64 results are bit-identical to the CPU path.  Compile with -ffp-contract=off:
+// every fused multiply-add below is explicit.
+//
+// Reference functions covered (CB/ = circuit-bootstrapping/src/):
+//   ifft_wave / fft_wave            spqlios-ifft-fma.s:9-275 / spqlios-fft-fma.s:9-285
+//   load/convert, round/store       fft_processor_spqlios.cpp:27-170 (execute_*)
+//   mac_row                         lagrangehalfc_impl_fma.s:78-135
+//   decomposition                   tgsw_functions.cpp:224-337 ; poc_CircuitBootstrapping.cpp:492-515
+//   (X^a-1) rotation                numeric_functions.cpp:304-323
+//   cmux_step                       lwe_functions.cpp:328-333 + tgsw_functions.cpp:424-449
+//   k_blind_rotate                  lwe_functions.cpp:337-430 (+ poc:530-659 test vector form)
+#pragma once
+#include "devport.h"
+
+namespace tfhe {
+
+// ------------------------------------------------------------------ geometry
+template <int LOGN>
+struct Geom {
+    static constexpr int N = 1 << LOGN;       // ring degree
+    static constexpr int NC = N / 2;          // complex points
+    static constexpr int LB = LOGN - 1;       // log2(NC)
+    static constexpr int PPL = NC / 64;       // complex points per lane: 8 (N=1024), 16 (N=2048)
+    static constexpr int R = (PPL == 8) ? 3 : 4;
+    static constexpr int CB = LB - 2 * R;     // index bits left for the last pass: 3 / 2
+    static constexpr int XCH = NC + 64;       // doubles in the (padded) transpose buffer
+    static constexpr int TW = 2 * NC;         // complex twiddles (2*NC-4 used)
+    static_assert(PPL == 8 || PPL == 16, "N must be 1024 or 2048");
+    static_assert(LB - R == 6, "one wave = 64 lanes");
+    // twiddle table: [0,NC) = omega^j (twist); stage with half-size h at tw_base(h)+off,
+    // value e^{2 pi i off / (2h)}  (= the reference's ifft table; its fft table is the conjugate)
+    TFHE_HOST_DEVICE static constexpr int tw_base(int h) { return 2 * NC - 2 * h; }
+    // lane/register -> point index j for the three register passes
+    TFHE_HOST_DEVICE static int jA(int t, int m) { return t + 64 * m; }
+    TFHE_HOST_DEVICE static int jB(int t, int m) {
+        return ((t >> CB) << 6) + (m << CB) + (t & ((1 << CB) - 1));
+    }
+    TFHE_HOST_DEVICE static int jC(int t, int m) { return PPL * t + m; }
+    // padded LDS index of point j for transpose 1 (A<->B) and transpose 2 (B<->C);
+    // both directions of both transposes are bank-conflict free (LDS)
+    TFHE_HOST_DEVICE static int idx1(int j) { return j + ((j >> 6) << CB); }
+    TFHE_HOST_DEVICE static int idx2(int j) { return j + (j >> R); }
+};
+
+// -------------------------------------------------------------- butterflies
+// ifft stage (spqlios-ifft-fma.s:113-157): (a,b) -> (a+b, (a-b)*w), w=(c,s)
+TFHE_DEVICE void dif_bfly(double &ar, double &ai, double &br, double &bi, double c, double s) {
+    const double sr = ar + br, si = ai + bi;
+    const double dr = ar - br, di = ai - bi;
+    ar = sr;
+    ai = si;
+    br = __builtin_fma(-di, s, dr * c);
+    bi = __builtin_fma(di, c, dr * s);
+}
+// fft stage (spqlios-fft-fma.s:189-234) with the fft table (c,-s) written through (c,s):
+// tr = fma(-i1,-s, r1*c) = fma(i1,s,r1*c); ti = fma(i1,c, r1*(-s)) = fma(i1,c,-(r1*s)).
+TFHE_DEVICE void dit_bfly(double &ar, double &ai, double &br, double &bi, double c, double s) {
+    const double tr = __builtin_fma(bi, s, br * c);
+    const double ti = __builtin_fma(bi, c, -(br * s));
+    const double r0 = ar, i0 = ai;
+    br = r0 - tr;
+    bi = i0 - ti;
+    ar = r0 + tr;
+    ai = i0 + ti;
+}
+
+// The reference's fft table is the conjugate of its ifft table EXCEPT at the quarter turn
+// (off == h/2): accurate_cos folds +n/4 to -cos(pi/2) = -6.1e-17 and -n/4 to +cos(pi/2)
+// (spqlios-fft-impl.cpp:99-105), so there cos_fft = -cos_ifft.  One table serves both
+// directions; the fft butterflies flip the sign of c on exactly those entries.
+TFHE_DEVICE double flip_sign_if(double c, bool cond) { return cond ? -c : c; }
+
+template <int LOGN>
+struct WaveFFT {
+    using G = Geom<LOGN>;
+    static constexpr int PPL = G::PPL;
+
+    // one wave-wide transpose through LDS: write with map W, read with map Rd (index fns)
+    template <class WIdx, class RIdx>
+    TFHE_DEVICE static void transpose(double (&x)[PPL], double *xch, WIdx widx, RIdx ridx) {
+#pragma unroll
+        for (int m = 0; m < PPL; m++) xch[widx(m)] = x[m];
+        TFHE_WAVE_FENCE();
+#pragma unroll
+        for (int m = 0; m < PPL; m++) x[m] = xch[ridx(m)];
+        TFHE_WAVE_FENCE();
+    }
+
+    // coefficient -> Lagrange.  In: lane t register m = point jA(t,m) (re = coef j, im = coef j+N/2).
+    // Out: register m = position jC(t,m) of the reference's output order.
+    TFHE_DEVICE static void ifft(double (&xr)[PPL], double (&xi)[PPL], const double2 *tw, double *xch, int t) {
+        // twist by omega^j (spqlios-ifft-fma.s:63-78)
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            const double2 w = tw[G::jA(t, m)];
+            const double r = xr[m], i = xi[m];
+            xr[m] = __builtin_fma(-i, w.y, r * w.x);
+            xi[m] = __builtin_fma(i, w.x, r * w.y);
+        }
+        // pass A: strides 64*s, s = PPL/2 .. 1
+#pragma unroll
+        for (int s = PPL / 2; s >= 1; s >>= 1) {
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                if (m & s) continue;
+                const double2 w = tw[G::tw_base(64 * s) + t + 64 * (m & (s - 1))];
+                dif_bfly(xr[m], xi[m], xr[m + s], xi[m + s], w.x, w.y);
+            }
+        }
+        auto wA = [&](int m) { return G::idx1(G::jA(t, m)); };
+        auto rB = [&](int m) { return G::idx1(G::jB(t, m)); };
+        transpose(xr, xch, wA, rB);
+        transpose(xi, xch, wA, rB);
+        // pass B: strides s<<CB
+        const int c = t & ((1 << G::CB) - 1);
+#pragma unroll
+        for (int s = PPL / 2; s >= 1; s >>= 1) {
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                if (m & s) continue;
+                const double2 w = tw[G::tw_base(s << G::CB) + ((m & (s - 1)) << G::CB) + c];
+                dif_bfly(xr[m], xi[m], xr[m + s], xi[m + s], w.x, w.y);
+            }
+        }
+        auto wB = [&](int m) { return G::idx2(G::jB(t, m)); };
+        auto rC = [&](int m) { return G::idx2(G::jC(t, m)); };
+        transpose(xr, xch, wB, rC);
+        transpose(xi, xch, wB, rC);
+        // pass C: (N=1024 only) stride 4 general stage, then size-4 and size-2 steps
+        if (G::CB == 3) {
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                if (m & 4) continue;
+                const double2 w = tw[G::tw_base(4) + (m & 3)];
+                dif_bfly(xr[m], xi[m], xr[m + 4], xi[m + 4], w.x, w.y);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < PPL; b += 4) {  // spqlios-ifft-fma.s:194-213
+            const double r0 = xr[b], r1 = xr[b + 1], r2 = xr[b + 2], r3 = xr[b + 3];
+            const double i0 = xi[b], i1 = xi[b + 1], i2 = xi[b + 2], i3 = xi[b + 3];
+            xr[b] = r0 + r2;
+            xr[b + 1] = r1 + r3;
+            xr[b + 2] = r0 - r2;
+            xr[b + 3] = i3 - i1;
+            xi[b] = i0 + i2;
+            xi[b + 1] = i1 + i3;
+            xi[b + 2] = i0 - i2;
+            xi[b + 3] = r1 - r3;
+        }
+#pragma unroll
+        for (int b = 0; b < PPL; b += 2) {  // :247-263
+            const double r0 = xr[b], r1 = xr[b + 1], i0 = xi[b], i1 = xi[b + 1];
+            xr[b] = r0 + r1;
+            xr[b + 1] = r0 - r1;
+            xi[b] = i0 + i1;
+            xi[b + 1] = i0 - i1;
+        }
+    }
+
+    // Lagrange -> coefficient (caller has applied the 2/N scale).  In: register m = position
+    // jC(t,m).  Out: register m = point jA(t,m) (re = coef j, im = coef j+N/2).
+    TFHE_DEVICE static void fft(double (&xr)[PPL], double (&xi)[PPL], const double2 *tw, double *xch, int t) {
+#pragma unroll
+        for (int b = 0; b < PPL; b += 2) {  // spqlios-fft-fma.s:79-95
+            const double r0 = xr[b], r1 = xr[b + 1], i0 = xi[b], i1 = xi[b + 1];
+            xr[b] = r0 + r1;
+            xr[b + 1] = r0 - r1;
+            xi[b] = i0 + i1;
+            xi[b + 1] = i0 - i1;
+        }
+#pragma unroll
+        for (int b = 0; b < PPL; b += 4) {  // :134-152
+            const double r0 = xr[b], r1 = xr[b + 1], r2 = xr[b + 2], r3 = xr[b + 3];
+            const double i0 = xi[b], i1 = xi[b + 1], i2 = xi[b + 2], i3 = xi[b + 3];
+            xr[b] = r0 + r2;
+            xr[b + 1] = r1 + i3;
+            xr[b + 2] = r0 - r2;
+            xr[b + 3] = r1 - i3;
+            xi[b] = i0 + i2;
+            xi[b + 1] = i1 - r3;
+            xi[b + 2] = i0 - i2;
+            xi[b + 3] = i1 + r3;
+        }
+        if (G::CB == 3) {
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                if (m & 4) continue;
+                const double2 w = tw[G::tw_base(4) + (m & 3)];
+                dit_bfly(xr[m], xi[m], xr[m + 4], xi[m + 4], (m & 3) == 2 ? -w.x : w.x, w.y);
+            }
+        }
+        auto wC = [&](int m) { return G::idx2(G::jC(t, m)); };
+        auto rB = [&](int m) { return G::idx2(G::jB(t, m)); };
+        transpose(xr, xch, wC, rB);
+        transpose(xi, xch, wC, rB);
+        const int c = t & ((1 << G::CB) - 1);
+#pragma unroll
+        for (int s = 1; s <= PPL / 2; s <<= 1) {
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                if (m & s) continue;
+                const double2 w = tw[G::tw_base(s << G::CB) + ((m & (s - 1)) << G::CB) + c];
+                // quarter turn: off == (s<<CB)/2
+                const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
+                const bool lq = (s == 1) ? (c == (1 << (G::CB - 1))) : (c == 0);
+                dit_bfly(xr[m], xi[m], xr[m + s], xi[m + s], mq ? flip_sign_if(w.x, lq) : w.x, w.y);
+            }
+        }
+        auto wB = [&](int m) { return G::idx1(G::jB(t, m)); };
+        auto rA = [&](int m) { return G::idx1(G::jA(t, m)); };
+        transpose(xr, xch, wB, rA);
+        transpose(xi, xch, wB, rA);
+#pragma unroll
+        for (int s = 1; s <= PPL / 2; s <<= 1) {
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                if (m & s) continue;
+                const double2 w = tw[G::tw_base(64 * s) + t + 64 * (m & (s - 1))];
+                // quarter turn: off == 32*s
+                const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
+                const bool lq = (s == 1) ? (t == 32) : (t == 0);
+                dit_bfly(xr[m], xi[m], xr[m + s], xi[m + s], mq ? flip_sign_if(w.x, lq) : w.x, w.y);
+            }
+        }
+        // final twist by conj(omega^j), four rounded products (spqlios-fft-fma.s:255-274):
+        // re' = re*c - im*(-s) = re*c + im*s ; im' = re*(-s) + im*c = im*c - re*s
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            const double2 w = tw[G::jA(t, m)];
+            const double r = xr[m], i = xi[m];
+            const double rc = r * w.x, rs = r * w.y, ic = i * w.x, is = i * w.y;
+            xr[m] = rc + is;
+            xi[m] = ic - rs;
+        }
+    }
+};
+
+// ------------------------------------------------------------- torus helpers
+template <typename T>
+struct Torus;
+template <>
+struct Torus<int32_t> {
+    using U = uint32_t;
+    static constexpr int BITS = 32;
+    // int32_t(int64_t(x)), fft_processor_spqlios.cpp:102 (truncate toward zero, wrap)
+    TFHE_DEVICE static int32_t from_double(double x) { return (int32_t)(int64_t)x; }
+    TFHE_DEVICE static double to_double(int32_t v) { return (double)v; }
+};
+template <>
+struct Torus<int64_t> {
+    using U = uint64_t;
+    static constexpr int BITS = 64;
+    // fft_processor_spqlios.cpp:131-142: mantissa shifted by (exponent-1075), truncation,
+    // modulo 2^64; shifts of 64 or more (|x| < 2^-11: undefined in the reference) give 0.
+    TFHE_DEVICE static int64_t from_double(double x) {
+        const uint64_t bits = (uint64_t)__builtin_bit_cast(int64_t, x);
+        const uint64_t mant = (bits & 0x000FFFFFFFFFFFFFull) | 0x0010000000000000ull;
+        const int trans = (int)((bits >> 52) & 0x7FF) - 1075;
+        uint64_t v;
+        if (trans > 0)
+            v = trans >= 64 ? 0 : (mant << trans);
+        else
+            v = (-trans) >= 64 ? 0 : (mant >> (-trans));
+        return (int64_t)((bits >> 63) ? (0 - v) : v);
+    }
+    TFHE_DEVICE static double to_double(int64_t v) { return (double)v; }  // round to nearest even
+};
+
+// gadget decomposition parameters, computed on the host (tgsw_functions.cpp:24-36 for
+// Torus32: no rounding bit; poc:349-350 for Torus64: with rounding bit)
+struct Gadget {
+    uint64_t offset;
+    int32_t Bgbit;
+    int32_t l;
+};
+
+// one coefficient of (X^a - 1) * p, a in [1, 2N)   (numeric_functions.cpp:304-323)
+template <typename T, int LOGN>
+TFHE_DEVICE typename Torus<T>::U rot_minus_one(const T *p, int i, int a) {
+    using U = typename Torus<T>::U;
+    constexpr int N = 1 << LOGN;
+    const int idx = (i - a) & (2 * N - 1);
+    const U src = (U)p[idx & (N - 1)];
+    const U rot = (idx & N) ? (U)(0 - src) : src;
+    return rot - (U)p[i];
+}
+// one coefficient of X^a * p, a in [0, 2N)   (numeric_functions.cpp:327-347)
+template <typename T, int LOGN>
+TFHE_DEVICE T rot_only(const T *p, int i, int a) {
+    using U = typename Torus<T>::U;
+    constexpr int N = 1 << LOGN;
+    const int idx = (i - a) & (2 * N - 1);
+    const U src = (U)p[idx & (N - 1)];
+    return (T)((idx & N) ? (U)(0 - src) : src);
+}
+
+// --------------------------------------------------------------- CMux step
+// Shared (LDS) state of one wave.
+template <typename T, int LOGN>
+struct WaveLds {
+    T *acc;              // [2][N] accumulator
+    double *xch;         // [Geom::XCH] transpose buffer
+    const double2 *tw;   // [Geom::TW] twiddles (shared by the workgroup)
+};
+
+// Fourier-domain multiply-accumulate of one decomposed limb with one key row
+// (lagrangehalfc_impl_fma.s:96-107), bk already in registers.
+template <int PPL>
+TFHE_DEVICE void mac_row(double (&fr)[2][PPL], double (&fi)[2][PPL], const double (&xr)[PPL],
+                         const double (&xi)[PPL], const double2 (&bk)[2][PPL]) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            const double ar = xr[m], ai = xi[m], br = bk[q][m].x, bi = bk[q][m].y;
+            const double tneg = __builtin_fma(ai, bi, -fr[q][m]);
+            fr[q][m] = __builtin_fma(ar, br, -tneg);
+            const double u = __builtin_fma(ar, bi, fi[q][m]);
+            fi[q][m] = __builtin_fma(ai, br, u);
+        }
+    }
+}
+
+// acc <- bk_row (x) ((X^a - 1) * acc) + acc      (a != 0; ROTATE=false: acc <- bk_row (x) acc)
+// bkrow: device layout [2l][2][PPL][64] complex, pre-scaled by 2/N at upload.
+template <typename T, int LOGN, bool ROTATE>
+TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int a,
+                           const Gadget &gd, int t) {
+    using G = Geom<LOGN>;
+    using U = typename Torus<T>::U;
+    constexpr int PPL = G::PPL, N = G::N, NC = G::NC;
+    const U offset = (U)gd.offset;
+    const U mask = ((U)1 << gd.Bgbit) - 1;
+    const int32_t halfBg = 1 << (gd.Bgbit - 1);
+
+    double fr[2][PPL], fi[2][PPL];  // Fourier accumulator (tLweFFTClear)
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int m = 0; m < PPL; m++) fr[q][m] = fi[q][m] = 0.0;
+
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {
+        const T *p = w.acc + q * N;
+        U lo[PPL], hi[PPL];  // coefficients j and j+N/2 of the (rotated) polynomial, offset added
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            const int j = G::jA(t, m);
+            if (ROTATE) {
+                lo[m] = rot_minus_one<T, LOGN>(p, j, a) + offset;
+                hi[m] = rot_minus_one<T, LOGN>(p, j + NC, a) + offset;
+            } else {
+                lo[m] = (U)p[j] + offset;
+                hi[m] = (U)p[j + NC] + offset;
+            }
+        }
+#pragma unroll 1
+        for (int d = 0; d < gd.l; d++) {
+            const int row = q * gd.l + d;  // p = bloc*l + i  (tgsw_functions.cpp:435-443)
+            double2 bk[2][PPL];
+#pragma unroll
+            for (int qq = 0; qq < 2; qq++)
+#pragma unroll
+                for (int m = 0; m < PPL; m++) bk[qq][m] = bkrow[((row * 2 + qq) * PPL + m) * 64 + t];
+            const int decal = Torus<T>::BITS - (d + 1) * gd.Bgbit;
+            double xr[PPL], xi[PPL];
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                xr[m] = (double)((int32_t)((lo[m] >> decal) & mask) - halfBg);
+                xi[m] = (double)((int32_t)((hi[m] >> decal) & mask) - halfBg);
+            }
+            WaveFFT<LOGN>::ifft(xr, xi, w.tw, w.xch, t);
+            mac_row<PPL>(fr, fi, xr, xi, bk);
+        }
+    }
+    // back to coefficients, round, accumulate into acc (tLweFromFFTConvert + tLweAddTo)
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {
+        double xr[PPL], xi[PPL];
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            xr[m] = fr[q][m];
+            xi[m] = fi[q][m];
+        }
+        WaveFFT<LOGN>::fft(xr, xi, w.tw, w.xch, t);
+        T *p = w.acc + q * N;
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            const int j = G::jA(t, m);
+            const U r0 = (U)Torus<T>::from_double(xr[m]);
+            const U r1 = (U)Torus<T>::from_double(xi[m]);
+            if (ROTATE) {
+                p[j] = (T)((U)p[j] + r0);
+                p[j + NC] = (T)((U)p[j + NC] + r1);
+            } else {
+                p[j] = (T)r0;
+                p[j + NC] = (T)r1;
+            }
+        }
+    }
+    TFHE_WAVE_FENCE();
+}
+
+// ----------------------------------------------------- blind-rotation kernel
+enum : uint32_t {
+    BR_INIT_TESTVEC = 1u << 0,  // acc = (0, X^{2N-barb} * v)    else: load acc from acc_io
+    BR_EXTRACT = 1u << 1,       // write sample-extracted LWE (index 0)   else: store acc to acc_io
+    BR_MODSWITCH = 1u << 2,     // `rot` holds Torus32 LWE samples; rotations = modSwitchFromTorus32(.,2N)
+    BR_TV_CONST = 1u << 3,      // test vector = tv_const everywhere (tfhe_bootstrap_woKS_FFT)
+    BR_TV_HALF = 1u << 4,       // test vector = -tv_const for j<N/2, +tv_const above (poc:551-553)
+    BR_NO_ROTATE = 1u << 5,     // plain external product steps (tGswFFTExternMulToTLwe): no X^a, no +acc
+};
+
+template <typename T>
+struct BlindRotateArgs {
+    const double2 *bk;      // [n_steps][2l][2][PPL][64], pre-scaled
+    const double2 *tw;      // [2*NC] twiddles
+    const int32_t *rot;     // [batch][rot_stride]: rotations (or LWE a_i); entry n_steps = barb / b
+    T *acc_io;              // [batch][2][N] (in and/or out)
+    const T *tv;            // test vector(s) [N] (tv_stride 0) or [batch][N]
+    T *lwe_out;             // [batch][N+1]
+    long long tv_stride;
+    long long bk_step_stride;  // complex elements between consecutive steps (0: same row every step)
+    T tv_const;
+    T out_b_add;            // added to b of the extracted sample (poc:648: + mu/2)
+    Gadget gd;
+    int32_t n_steps;
+    int32_t rot_stride;
+    int32_t batch;
+    uint32_t flags;
+};
+
+// modSwitchFromTorus32(phase, 2N), numeric_functions.cpp:54-60, for Msize = 2N a power of two
+template <int LOGN>
+TFHE_DEVICE int modswitch_2N(int32_t phase) {
+    const int sh = 63 - LOGN;  // interv = 2^(63-LOGN)
+    const uint64_t half = 1ull << (sh - 1);
+    return (int)((((uint64_t)(uint32_t)phase << 32) + half) >> sh);
+}
+
+template <typename T, int LOGN, int WAVES>
+struct BlindRotateLds {
+    using G = Geom<LOGN>;
+    static constexpr size_t tw_bytes = sizeof(double2) * G::TW;
+    static constexpr size_t acc_bytes = sizeof(T) * 2 * G::N;
+    static constexpr size_t xch_bytes = sizeof(double) * G::XCH;
+    static constexpr size_t wave_bytes = acc_bytes + xch_bytes;
+    static constexpr size_t total = tw_bytes + WAVES * wave_bytes;
+};
+
+#ifdef TFHE_EMU
+#define TFHE_DYN_LDS(name) unsigned char *name = emu::dyn_smem()
+#else
+#define TFHE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
+template <typename T, int LOGN, int WAVES>
+TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T> A) {
+    using G = Geom<LOGN>;
+    using U = typename Torus<T>::U;
+    using Lds = BlindRotateLds<T, LOGN, WAVES>;
+    constexpr int N = G::N, PPL = G::PPL;
+    TFHE_DYN_LDS(smem);
+    double2 *tw = reinterpret_cast<double2 *>(smem);
+    for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = A.tw[i];
+    __syncthreads();
+
+    const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
+    const int t = threadIdx.x & 63;
+    const int ct = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
+    if (ct >= A.batch) return;
+
+    WaveLds<T, LOGN> w;
+    unsigned char *mine = smem + Lds::tw_bytes + (size_t)wave * Lds::wave_bytes;
+    w.acc = reinterpret_cast<T *>(mine);
+    w.xch = reinterpret_cast<double *>(mine + Lds::acc_bytes);
+    w.tw = tw;
+
+    const int32_t *rot = A.rot + (size_t)ct * A.rot_stride;
+    // ---- accumulator initialisation
+    if (A.flags & BR_INIT_TESTVEC) {
+        int barb = rot[A.n_steps];
+        if (A.flags & BR_MODSWITCH) barb = modswitch_2N<LOGN>(barb);
+        const int a0 = (2 * N - barb) & (2 * N - 1);  // lwe_functions.cpp:385-386
+        const T *tv = A.tv + (size_t)ct * A.tv_stride;
+#pragma unroll
+        for (int m = 0; m < 2 * PPL; m++) {
+            const int j = t + 64 * m;
+            // coefficient j of X^{a0} * v
+            const int idx = (j - a0) & (2 * N - 1);
+            const int src = idx & (N - 1);
+            U v;
+            if (A.flags & BR_TV_CONST)
+                v = (U)A.tv_const;
+            else if (A.flags & BR_TV_HALF)
+                v = (src < N / 2) ? (U)(0 - (U)A.tv_const) : (U)A.tv_const;
+            else
+                v = (U)tv[src];
+            w.acc[j] = 0;
+            w.acc[N + j] = (T)((idx & N) ? (U)(0 - v) : v);
+        }
+    } else {
+        const T *src = A.acc_io + (size_t)ct * 2 * N;
+#pragma unroll
+        for (int m = 0; m < 4 * PPL; m++) w.acc[t + 64 * m] = src[t + 64 * m];
+    }
+    TFHE_WAVE_FENCE();
+
+    // ---- CMux loop (lwe_functions.cpp:337-361)
+#pragma unroll 1
+    for (int i = 0; i < A.n_steps; i++) {
+        const double2 *bkrow = A.bk + (size_t)i * A.bk_step_stride;
+        if (A.flags & BR_NO_ROTATE) {
+            cmux_step<T, LOGN, false>(w, bkrow, 0, A.gd, t);
+        } else {
+            int a = rot[i];
+            if (A.flags & BR_MODSWITCH) a = modswitch_2N<LOGN>(a);
+            a = TFHE_UNIFORM(a);
+            if (a == 0) continue;  // :348-350
+            cmux_step<T, LOGN, true>(w, bkrow, a, A.gd, t);
+        }
+    }
+
+    // ---- output
+    if (A.flags & BR_EXTRACT) {  // tLweExtractLweSampleIndex, index 0 (tlwe_functions.cpp:351-363)
+        T *out = A.lwe_out + (size_t)ct * (N + 1);
+#pragma unroll
+        for (int m = 0; m < 2 * PPL; m++) {
+            const int j = t + 64 * m;
+            out[j] = (j == 0) ? w.acc[0] : (T)(0 - (U)w.acc[N - j]);
+        }
+        if (t == 0) out[N] = (T)((U)w.acc[N] + (U)A.out_b_add);
+    } else {
+        T *dst = A.acc_io + (size_t)ct * 2 * N;
+#pragma unroll
+        for (int m = 0; m < 4 * PPL; m++) dst[t + 64 * m] = w.acc[t + 64 * m];
+    }
+}
+
+// ------------------------------------------- standalone batched transforms
+// FFT plugin boundary (CB/spqlios/lagrangehalfc_impl.h:8-31), one wave per polynomial.
+template <int LOGN, int WAVES>
+struct FftLds {
+    using G = Geom<LOGN>;
+    static constexpr size_t tw_bytes = sizeof(double2) * G::TW;
+    static constexpr size_t wave_bytes = sizeof(double) * G::XCH;
+    static constexpr size_t total = tw_bytes + WAVES * wave_bytes;
+};
+
+// execute_reverse_int / _torus32 / _torus64: torus or int coefficients -> LagrangeHalfC
+template <typename TIN, int LOGN, int WAVES>
+TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
+    k_ifft_batch(double *__restrict__ out, const TIN *__restrict__ in, const double2 *__restrict__ twg, int batch) {
+    using G = Geom<LOGN>;
+    constexpr int N = G::N, NC = G::NC, PPL = G::PPL;
+    TFHE_DYN_LDS(smem);
+    double2 *tw = reinterpret_cast<double2 *>(smem);
+    for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = twg[i];
+    __syncthreads();
+    const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
+    const int t = threadIdx.x & 63;
+    const int b = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
+    if (b >= batch) return;
+    double *xch = reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH;
+    const TIN *p = in + (size_t)b * N;
+    double xr[PPL], xi[PPL];
+#pragma unroll
+    for (int m = 0; m < PPL; m++) {
+        xr[m] = (double)p[G::jA(t, m)];
+        xi[m] = (double)p[G::jA(t, m) + NC];
+    }
+    WaveFFT<LOGN>::ifft(xr, xi, tw, xch, t);
+    double *o = out + (size_t)b * N;
+#pragma unroll
+    for (int m = 0; m < PPL; m++) {
+        o[G::jC(t, m)] = xr[m];
+        o[G::jC(t, m) + NC] = xi[m];
+    }
+}
+
+// execute_direct_torus32 / _torus64: LagrangeHalfC -> torus coefficients (scale 2/N first)
+template <typename TOUT, int LOGN, int WAVES>
+TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
+    k_fft_batch(TOUT *__restrict__ out, const double *__restrict__ in, const double2 *__restrict__ twg, int batch) {
+    using G = Geom<LOGN>;
+    constexpr int N = G::N, NC = G::NC, PPL = G::PPL;
+    TFHE_DYN_LDS(smem);
+    double2 *tw = reinterpret_cast<double2 *>(smem);
+    for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = twg[i];
+    __syncthreads();
+    const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
+    const int t = threadIdx.x & 63;
+    const int b = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
+    if (b >= batch) return;
+    double *xch = reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH;
+    const double *p = in + (size_t)b * N;
+    const double scale = 2.0 / (double)N;  // fft_processor_spqlios.cpp:78
+    double xr[PPL], xi[PPL];
+#pragma unroll
+    for (int m = 0; m < PPL; m++) {
+        xr[m] = p[G::jC(t, m)] * scale;
+        xi[m] = p[G::jC(t, m) + NC] * scale;
+    }
+    WaveFFT<LOGN>::fft(xr, xi, tw, xch, t);
+    TOUT *o = out + (size_t)b * N;
+#pragma unroll
+    for (int m = 0; m < PPL; m++) {
+        o[G::jA(t, m)] = Torus<TOUT>::from_double(xr[m]);
+        o[G::jA(t, m) + NC] = Torus<TOUT>::from_double(xi[m]);
+    }
+}
+
+// LagrangeHalfCPolynomialAddMulASM over a batch: res[b] += a[b] * bb[b or 0]
+TFHE_GLOBAL void k_lagrange_addmul(double *__restrict__ res, const double *__restrict__ a,
+                                   const double *__restrict__ bb, int Ns2, long long b_stride, long long total) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const long long poly = gid / Ns2;
+    const int i = (int)(gid - poly * Ns2);
+    const double *pa = a + poly * 2 * Ns2, *pb = bb + poly * b_stride;
+    double *pr = res + poly * 2 * Ns2;
+    const double ar = pa[i], ai = pa[Ns2 + i], br = pb[i], bi = pb[Ns2 + i];
+    const double tneg = __builtin_fma(ai, bi, -pr[i]);
+    pr[i] = __builtin_fma(ar, br, -tneg);
+    const double u = __builtin_fma(ar, bi, pr[Ns2 + i]);
+    pr[Ns2 + i] = __builtin_fma(ai, br, u);
+}
+
+// Key upload: LagrangeHalfC polynomials (reference order) -> kernel layout, scaled by 2/N.
+// src: [rows][N] doubles (re[0..NC) | im[0..NC));  dst: [rows][PPL][64] complex with
+// dst[row][m][t] = (re, im)[jC(t,m)] * 2/N.
+template <int LOGN>
+TFHE_GLOBAL void k_pack_gsw(double2 *__restrict__ dst, const double *__restrict__ src, long long rows) {
+    using G = Geom<LOGN>;
+    constexpr int N = G::N, NC = G::NC, PPL = G::PPL;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows * NC) return;
+    const long long row = gid / NC;
+    const int e = (int)(gid - row * NC);
+    const int m = e >> 6, t = e & 63;
+    const double scale = 2.0 / (double)N;
+    const double *p = src + row * N;
+    const int pos = PPL * t + m;
+    dst[gid] = make_double2(p[pos] * scale, p[pos + NC] * scale);
+}
+
+// preModSwitch (poc:472-484) / modSwitchFromTorus32(., 2N) over flat arrays
+template <int LOGN>
+TFHE_GLOBAL void k_modswitch(int32_t *__restrict__ out, const int32_t *__restrict__ in, long long total) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < total) out[gid] = modswitch_2N<LOGN>(in[gid]);
+}
+
+// ----------------------------------------------------------- LWE key switch
+// lweKeySwitch (lwe_functions.cpp:136-171) / preKeySwitch (poc:437-465), one workgroup per
+// sample, threads over the n_out+1 output coefficients.  ks: [n_in][t][base][n_out+1].
+TFHE_GLOBAL void k_keyswitch32(int32_t *__restrict__ out, const int32_t *__restrict__ in,
+                               const int32_t *__restrict__ ks, int n_in, int n_out, int t, int basebit,
+                               int batch) {
+    const int b = blockIdx.x;
+    if (b >= batch) return;
+    const int base = 1 << basebit;
+    const uint32_t mask = (uint32_t)base - 1;
+    const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+    const int row = n_out + 1;
+    const int32_t *x = in + (size_t)b * (n_in + 1);
+    for (int h = threadIdx.x; h < row; h += blockDim.x) {
+        uint32_t acc = (h == n_out) ? (uint32_t)x[n_in] : 0u;
+        for (int i = 0; i < n_in; i++) {
+            const uint32_t aibar = (uint32_t)x[i] + prec_offset;
+            for (int j = 0; j < t; j++) {
+                const uint32_t aij = (aibar >> (32 - (j + 1) * basebit)) & mask;
+                if (aij != 0) acc -= (uint32_t)ks[(((size_t)i * t + j) * base + aij) * row + h];
+            }
+        }
+        out[(size_t)b * row + h] = (int32_t)acc;
+    }
+}
+
+}  // namespace tfhe

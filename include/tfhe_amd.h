@@ -1,0 +1,170 @@
+/*
+ * tfhe_amd.h -- C ABI of the MI355X-native TFHE bootstrapping engine.
+ *
+ * This is the drop-in boundary for the hot path of tfhe/experimental-tfhe: every entry
+ * point below names the reference interface it replaces (CB/ = the reference's
+ * circuit-bootstrapping/src/).  The reference processes ONE sample per call on the host;
+ * here every operation takes a BATCH of independent samples resident in GPU memory and
+ * runs asynchronously on the context's HIP stream.  Batch-1 shims with the reference's
+ * exact names and struct types are in include/tfhe_amd_compat.hpp.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, int status (0 = TFHE_AMD_OK); no HIP or torch types.
+ *   - `*_d` pointers are device pointers (hipMalloc, tfhe_amd_malloc or any framework's
+ *     allocator on the context's device); everything else is host memory.
+ *   - Torus32 = int32_t, Torus64 = int64_t (CB/poc_types.h:13-14), wrap-around arithmetic.
+ *   - LWE sample of dimension n: n+1 torus values, a[0..n-1] then b (CB/poc_types.h:137-158).
+ *   - TLWE sample (k=1): 2N torus values, polynomial a then polynomial b (poc_types.h:164-197).
+ *   - LagrangeHalfC polynomial: N doubles, re[0..N/2) then im[0..N/2) in the order
+ *     produced by the reference's ifft (CB/spqlios/lagrangehalfc_impl_fma.s:91-93).
+ *   - TGSW sample in Lagrange form: [(k+1)l][k+1][N] doubles = `allsamples` rows
+ *     p = bloc*l + i, each with polynomials a[0..k] (poc_types.h:239-251).
+ *   - a context is bound to one device and one stream and is not thread-safe; use one
+ *     context per host thread / per GPU.  Distinct contexts are independent.
+ *   - the library never falls back to the CPU: without a usable gfx950 device
+ *     tfhe_amd_ctx_create fails with TFHE_AMD_ERR_DEVICE.
+ */
+#ifndef TFHE_AMD_H
+#define TFHE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    TFHE_AMD_OK = 0,
+    TFHE_AMD_ERR_PARAM = 1,   /* unsupported or inconsistent parameters / null pointer */
+    TFHE_AMD_ERR_DEVICE = 2,  /* HIP error (see tfhe_amd_last_error)                  */
+    TFHE_AMD_ERR_STATE = 3,   /* a required key has not been loaded                   */
+    TFHE_AMD_ERR_ALLOC = 4
+};
+
+/* Parameters of one bootstrapping level.  Reference: LweParams/TLweParams/TGswParams
+ * (CB/lwe_functions.cpp:17, CB/tgsw_functions.cpp:15-38) and the PoC's Globals
+ * (CB/poc_types.h:267-283).  Supported: N in {1024, 2048}, k = 1, l in [1,8],
+ * l*Bgbit <= torus_bits - 1, torus_bits in {32, 64}. */
+typedef struct tfhe_amd_params {
+    int32_t torus_bits; /* 32: Torus32 accumulator (gate bootstrap); 64: Torus64 (circuit bootstrap lvl2) */
+    int32_t n;          /* LWE dimension = number of CMux steps of a blind rotation */
+    int32_t N;          /* ring degree */
+    int32_t k;          /* must be 1 (the reference hard-codes it: CB/poc_types.h:10) */
+    int32_t l;          /* gadget length */
+    int32_t Bgbit;      /* log2 of the gadget base */
+    int32_t ks_t;       /* key-switch length t (0: no key switch on this context) */
+    int32_t ks_basebit; /* key-switch base bits */
+    int32_t ks_n_out;   /* output dimension of the key switch (gate bootstrap: = n) */
+} tfhe_amd_params;
+
+typedef struct tfhe_amd_ctx tfhe_amd_ctx;
+typedef struct tfhe_amd_gsw tfhe_amd_gsw; /* device-resident TGSW samples, kernel layout */
+
+/* ---- context ------------------------------------------------------------------------ */
+int tfhe_amd_ctx_create(const tfhe_amd_params *params, int device, tfhe_amd_ctx **out);
+void tfhe_amd_ctx_destroy(tfhe_amd_ctx *ctx);
+const char *tfhe_amd_last_error(const tfhe_amd_ctx *ctx);
+const char *tfhe_amd_version(void);
+/* use an existing hipStream_t (passed as void*); NULL = the context's own stream */
+int tfhe_amd_set_stream(tfhe_amd_ctx *ctx, void *hip_stream);
+int tfhe_amd_sync(tfhe_amd_ctx *ctx);
+/* twiddle tables as the reference lays them out (new_fft_table / new_ifft_table,
+ * CB/spqlios/spqlios-fft-impl.cpp:158-193,400-437): 2N-8 doubles each; for SHA pinning. */
+int tfhe_amd_get_tables(const tfhe_amd_ctx *ctx, double *fft_trig, double *ifft_trig);
+
+/* device memory helpers so a host language needs no HIP binding of its own */
+int tfhe_amd_malloc(tfhe_amd_ctx *ctx, void **dptr, size_t bytes);
+int tfhe_amd_free(tfhe_amd_ctx *ctx, void *dptr);
+int tfhe_amd_memcpy_h2d(tfhe_amd_ctx *ctx, void *dst_d, const void *src, size_t bytes);
+int tfhe_amd_memcpy_d2h(tfhe_amd_ctx *ctx, void *dst, const void *src_d, size_t bytes);
+
+/* ---- keys --------------------------------------------------------------------------- */
+/* TGSW samples already in Lagrange form, host layout [count][(k+1)l][k+1][N] doubles
+ * (what init_LweBootstrappingKeyFFT / tGswToFFTConvert produce: CB/lwe_functions.cpp:287-316,
+ * CB/tgsw_functions.cpp:389-394; PoC: poc_CircuitBootstrapping.cpp:395-402). */
+int tfhe_amd_gsw_from_fft(tfhe_amd_ctx *ctx, const double *gsw_fft, int count, tfhe_amd_gsw **out);
+/* TGSW samples in coefficient form, host layout [count][(k+1)l][k+1][N] torus values
+ * (int32_t or int64_t per params.torus_bits); converted on the GPU = tGswToFFTConvert. */
+int tfhe_amd_gsw_from_torus(tfhe_amd_ctx *ctx, const void *gsw_torus, int count, tfhe_amd_gsw **out);
+void tfhe_amd_gsw_free(tfhe_amd_gsw *gsw);
+/* read back sample `index` in the reference's Lagrange layout [(k+1)l][k+1][N] (unscaled) */
+int tfhe_amd_gsw_export_fft(tfhe_amd_ctx *ctx, const tfhe_amd_gsw *gsw, int index, double *out);
+/* bootstrapping key = TGSW array of exactly n samples (LweBootstrappingKeyFFT::bkFFT,
+ * CB/lwe_functions.cpp:272-281); the context keeps a reference, the caller keeps ownership */
+int tfhe_amd_set_bootstrap_key(tfhe_amd_ctx *ctx, const tfhe_amd_gsw *bk);
+/* key-switch key, host layout [N][ks_t][1<<ks_basebit][ks_n_out+1] int32
+ * (LweKeySwitchKey::ks, CB/lwe_functions.cpp:96-110; PoC preKS poc:375) */
+int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *ctx, const int32_t *ks);
+
+/* ---- L1: the FFT plugin (class FFT_Processor_Spqlios, CB/spqlios/lagrangehalfc_impl.h:8-36) */
+/* execute_reverse_int / execute_reverse_torus32: [batch][N] int32 -> [batch][N] doubles */
+int tfhe_amd_ifft_int32(tfhe_amd_ctx *ctx, double *out_d, const int32_t *in_d, int batch);
+/* execute_reverse_torus64 */
+int tfhe_amd_ifft_torus64(tfhe_amd_ctx *ctx, double *out_d, const int64_t *in_d, int batch);
+/* execute_direct_torus32: scale by 2/N, fft, int32_t(int64_t(x)) */
+int tfhe_amd_fft_torus32(tfhe_amd_ctx *ctx, int32_t *out_d, const double *in_d, int batch);
+/* execute_direct_torus64 */
+int tfhe_amd_fft_torus64(tfhe_amd_ctx *ctx, int64_t *out_d, const double *in_d, int batch);
+/* LagrangeHalfCPolynomialAddMulASM: res[i] += a[i]*b[i] (b_shared != 0: b[0] for every i) */
+int tfhe_amd_lagrange_addmul(tfhe_amd_ctx *ctx, double *res_d, const double *a_d, const double *b_d,
+                             int batch, int b_shared);
+
+/* ---- L2: ring / TGSW ---------------------------------------------------------------- */
+/* tGswFFTExternMulToTLwe (CB/tgsw_functions.cpp:424-449; PoC inline poc:609-620):
+ * acc[i] <- gsw[index] (x) acc[i], acc_d: [batch][2][N] torus */
+int tfhe_amd_extern_mul(tfhe_amd_ctx *ctx, void *acc_d, const tfhe_amd_gsw *gsw, int index, int batch);
+/* tfhe_MuxRotate_FFT (CB/lwe_functions.cpp:328-333), in place:
+ * acc[i] <- gsw[index] (x) ((X^barai[i] - 1) acc[i]) + acc[i]; barai in [0,2N), 0 = no-op */
+int tfhe_amd_mux_rotate(tfhe_amd_ctx *ctx, void *acc_d, const tfhe_amd_gsw *gsw, int index,
+                        const int32_t *barai_d, int batch);
+
+/* ---- L3: bootstrapping -------------------------------------------------------------- */
+/* tfhe_blindRotate_FFT (CB/lwe_functions.cpp:337-361): acc_d [batch][2][N] in place,
+ * bara_d [batch][n] rotations in [0,2N) */
+int tfhe_amd_blind_rotate(tfhe_amd_ctx *ctx, void *acc_d, const int32_t *bara_d, int batch);
+/* tfhe_blindRotateAndExtract_FFT (CB/lwe_functions.cpp:366-395).  v_d: test vector(s), [N]
+ * when v_per_sample == 0 else [batch][N]; rot_d: [batch][n+1] = bara[0..n-1] then barb;
+ * lwe_out_d: [batch][N+1] */
+int tfhe_amd_blind_rotate_extract(tfhe_amd_ctx *ctx, void *lwe_out_d, const void *v_d, int v_per_sample,
+                                  const int32_t *rot_d, int batch);
+/* tfhe_bootstrap_woKS_FFT (CB/lwe_functions.cpp:399-430), Torus32 contexts: x_d [batch][n+1]
+ * LWE samples, lwe_out_d [batch][N+1] */
+int tfhe_amd_bootstrap_woks(tfhe_amd_ctx *ctx, int32_t *lwe_out_d, int32_t mu, const int32_t *x_d, int batch);
+/* lweKeySwitch (CB/lwe_functions.cpp:163-171) / preKeySwitch (poc:437-465):
+ * in_d [batch][N+1] -> out_d [batch][ks_n_out+1] */
+int tfhe_amd_keyswitch(tfhe_amd_ctx *ctx, int32_t *out_d, const int32_t *in_d, int batch);
+/* tfhe_bootstrap_FFT (CB/lwe_functions.cpp:434-446): x_d [batch][n+1] -> out_d [batch][n+1] */
+int tfhe_amd_bootstrap(tfhe_amd_ctx *ctx, int32_t *out_d, int32_t mu, const int32_t *x_d, int batch);
+/* the "one external-product kernel per CMux" schedule of the same bootstrap (BASELINE
+ * config 2): n launches of tfhe_amd_mux_rotate on an HBM-resident accumulator batch.
+ * Identical results; exists so the streamed schedule can be measured. */
+int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *ctx, int32_t *out_d, int32_t mu, const int32_t *x_d, int batch);
+/* host-pointer convenience form of tfhe_amd_bootstrap (copies in, runs, copies out, syncs) */
+int tfhe_amd_bootstrap_host(tfhe_amd_ctx *ctx, int32_t *out, int32_t mu, const int32_t *x, int batch);
+
+/* circuit-bootstrap blind rotation, circuitBootstrapWoKS (poc:530-659) with the library's
+ * rotation semantics (see DESIGN.md "PoC defects"): Torus64 contexts.  abar_d [batch][n+1]
+ * (preModSwitch output, poc:472-484), lwe_out_d [batch][N+1] int64. */
+int tfhe_amd_cb_bootstrap_woks(tfhe_amd_ctx *ctx, int64_t *lwe_out_d, int64_t mu, const int32_t *abar_d, int batch);
+/* preModSwitch (poc:472-484): x_d [batch][n+1] Torus32 -> out_d [batch][n+1] in [0, 2N) */
+int tfhe_amd_modswitch(tfhe_amd_ctx *ctx, int32_t *out_d, const int32_t *x_d, int batch);
+
+/* ---- harness: synthetic keys and samples (the reference's keygen/encrypt/phase,
+ *      poc:88-134,191-227,342-423; PRNG spec in DESIGN.md) -- host side ------------------ */
+int tfhe_amd_keygen_binary(int32_t *key, int n, uint64_t seed, uint64_t stream);
+int tfhe_amd_lwe_encrypt32(int32_t *ct, int32_t mess, double stdev, const int32_t *key, int n,
+                           uint64_t seed, uint64_t stream);
+int32_t tfhe_amd_lwe_phase32(const int32_t *ct, const int32_t *key, int n);
+/* bootstrapping key in coefficient form [n][(k+1)l][k+1][N] (feed to tfhe_amd_gsw_from_torus) */
+int tfhe_amd_keygen_bk_torus32(int32_t *bk, const int32_t *lwe_key, int n, const int32_t *tlwe_key, int N,
+                               int l, int Bgbit, double stdev, uint64_t seed, uint64_t stream);
+int tfhe_amd_keygen_bk_torus64(int64_t *bk, const int32_t *lwe_key, int n, const int32_t *tlwe_key, int N,
+                               int l, int Bgbit, double stdev, uint64_t seed, uint64_t stream);
+int tfhe_amd_keygen_ks32(int32_t *ks, const int32_t *in_key, int n_in, const int32_t *out_key, int n_out,
+                         int t, int basebit, double stdev, uint64_t seed, uint64_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFHE_AMD_H */

@@ -1,0 +1,148 @@
+// emu_runtime.cpp -- TEST-ONLY fiber scheduler behind tests/emu/emu_runtime.h.
+#include "emu_runtime.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+namespace emu {
+
+thread_local Dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+
+namespace {
+constexpr size_t kStack = 512 * 1024;
+
+struct Rendezvous {
+    int expected = 0, count = 0;
+    unsigned gen = 0;
+};
+struct Fiber {
+    ucontext_t ctx;
+    void *stack = nullptr;
+    bool done = false;
+    unsigned tid = 0;
+};
+struct Block {
+    std::vector<Fiber> fibers;
+    Rendezvous all;
+    std::vector<Rendezvous> waves;
+    ucontext_t sched;
+    const std::function<void()> *body = nullptr;
+    unsigned char *smem = nullptr;
+    int current = -1;
+};
+thread_local Block *t_blk = nullptr;
+
+void yield() { swapcontext(&t_blk->fibers[t_blk->current].ctx, &t_blk->sched); }
+
+void arrive(Rendezvous &r) {
+    const unsigned g = r.gen;
+    if (++r.count >= r.expected) {
+        r.count = 0;
+        r.gen++;
+        return;
+    }
+    while (r.gen == g) yield();
+}
+void retire(Rendezvous &r) {  // a work-item that returned no longer takes part
+    r.expected--;
+    if (r.count > 0 && r.count >= r.expected) {
+        r.count = 0;
+        r.gen++;
+    }
+}
+void trampoline() {
+    Block *b = t_blk;
+    Fiber &f = b->fibers[b->current];
+    (*b->body)();
+    f.done = true;
+    retire(b->all);
+    retire(b->waves[f.tid / 64]);
+    swapcontext(&f.ctx, &b->sched);
+}
+
+void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigned bx, size_t smem_bytes) {
+    Block b;
+    t_blk = &b;
+    b.body = &body;
+    const unsigned nt = block.x;
+    b.fibers.resize(nt);
+    b.all.expected = (int)nt;
+    b.waves.resize((nt + 63) / 64);
+    for (unsigned w = 0; w < b.waves.size(); w++) b.waves[w].expected = (int)std::min(64u, nt - 64 * w);
+    // 64 KiB of slack behind the requested LDS so an out-of-bounds index is caught by ASan
+    // (or at least does not trample a neighbour) rather than silently aliasing.
+    b.smem = (unsigned char *)aligned_alloc(64, ((smem_bytes + 63) / 64) * 64 + 64);
+    t_blockIdx = Dim3(bx);
+    t_blockDim = block;
+    t_gridDim = grid;
+    for (unsigned t = 0; t < nt; t++) {
+        Fiber &f = b.fibers[t];
+        f.tid = t;
+        f.stack = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (f.stack == MAP_FAILED) { perror("mmap"); abort(); }
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, trampoline, 0);
+    }
+    unsigned alive = nt;
+    while (alive) {
+        alive = 0;
+        for (unsigned t = 0; t < nt; t++) {
+            Fiber &f = b.fibers[t];
+            if (f.done) continue;
+            b.current = (int)t;
+            t_threadIdx = Dim3(t);
+            swapcontext(&b.sched, &f.ctx);
+            if (!f.done) alive++;
+        }
+    }
+    for (auto &f : b.fibers) munmap(f.stack, kStack);
+    free(b.smem);
+    t_blk = nullptr;
+}
+}  // namespace
+
+void syncthreads() { arrive(t_blk->all); }
+void wave_fence() { arrive(t_blk->waves[t_threadIdx.x / 64]); }
+unsigned char *dyn_smem() { return t_blk->smem; }
+
+void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes) {
+    const unsigned nb = grid.x;
+    unsigned nthreads = std::min<unsigned>(nb, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("TFHE_EMU_THREADS")) nthreads = std::max(1, atoi(e));
+    std::atomic<unsigned> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const unsigned bx = next.fetch_add(1);
+            if (bx >= nb) break;
+            run_block(body, grid, block, bx, smem_bytes);
+        }
+    };
+    if (nthreads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned i = 0; i < nthreads; i++) pool.emplace_back(worker);
+        for (auto &t : pool) t.join();
+    }
+}
+
+}  // namespace emu
+
+hipError_t hipMalloc(void **p, size_t bytes) {
+    *p = aligned_alloc(256, ((bytes + 255) / 256) * 256 + 256);
+    return *p ? hipSuccess : hipErrorInvalidValue;
+}
+hipError_t hipFree(void *p) {
+    free(p);
+    return hipSuccess;
+}

@@ -1,0 +1,71 @@
+// emu_runtime.h -- TEST-ONLY emulation of the slice of HIP the kernels and the host
+// library use, so the very same sources can be compiled by g++ and checked against the
+// oracle (and run under sanitizers) where no GPU exists.  Nothing under
+// experimental-tfhe_amd/ ever loads a library built from this; see tests/emu/README.md.
+//
+// Model: a workgroup is a set of cooperative fibers (ucontext) on one OS thread, one
+// fiber per work-item, scheduled round-robin.  __syncthreads() and the wave-level LDS
+// fence are rendezvous points; between two rendezvous a work-item runs alone, which is
+// a legal interleaving of the lock-step hardware.  Workgroups of one launch are spread
+// over a few OS threads.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <functional>
+
+namespace emu {
+struct Dim3 {
+    unsigned x, y, z;
+    Dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+extern thread_local Dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes);
+void syncthreads();
+void wave_fence();
+unsigned char *dyn_smem();
+}  // namespace emu
+
+using dim3 = emu::Dim3;
+#define threadIdx (emu::t_threadIdx)
+#define blockIdx (emu::t_blockIdx)
+#define blockDim (emu::t_blockDim)
+#define gridDim (emu::t_gridDim)
+#define __syncthreads() emu::syncthreads()
+#define __launch_bounds__(...)
+
+#define TFHE_DEVICE inline
+#define TFHE_GLOBAL
+#define TFHE_HOST_DEVICE inline
+#define TFHE_WAVE_FENCE() emu::wave_fence()
+#define TFHE_UNIFORM(x) (x)
+#define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    emu::launch([=]() { kernel(__VA_ARGS__); }, grid, block, smem)
+
+struct double2 {
+    double x, y;
+};
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+
+// ---- host runtime subset -------------------------------------------------------------
+typedef int hipError_t;
+typedef void *hipStream_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *d) { *d = 1; return hipSuccess; }
+hipError_t hipMalloc(void **p, size_t bytes);
+hipError_t hipFree(void *p);
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+template <class F>
+static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
