@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- gate bootstraps/s on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of tfhe_bootstrap_FFT (blind rotation + extraction + key switch) over a
+batch of 4096 synthetic LWE samples ALREADY RESIDENT IN HBM (BASELINE config 2: n=630,
+N=1024, k=1, l=2; Bgbit=10, key switch 8x2 bits).  N > 1: every rank runs the same per-GPU
+batch on its own GPU with replicated keys (weak scaling, no data-path collective);
+value = all ranks' bootstraps / max-over-ranks time.
+
+The JSON line also carries
+  roofline      dominant kernel (k_blind_rotate): algorithmic bytes of the streamed external
+                product (16,388 B per CMux per sample + 65,536 B key row per CMux per
+                launch) / HIP-event kernel time, against 8 TB/s HBM; plus the fp64-VALU view
+                (173,056 flop per CMux vs 78.6 TF), since that kernel sits at the ridge point
+  cpu_baseline  the same bootstrap composed from the REFERENCE's own FFT/MAC object code
+                (oracle/_ref/ref_driver bench32), one process per host core, bounded to ~10 s;
+                falls back to the C oracle ("port") where the reference binary is absent.
+Only that cpu_baseline leg touches oracle/.
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU = 4096
+SEED = 0x5446484500000001
+HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
+FP64_PEAK = 78.6e12      # flop/s vector fp64 (256 CU x 128 flop/clk x 2.4 GHz)
+BYTES_PER_CMUX = 16388   # acc read+write 16,384 + rotation 4
+BYTES_PER_ROW = 65536    # bootstrapping-key row, once per CMux per launch
+FLOP_PER_CMUX = 173056
+
+
+def cpu_baseline(cfg, seconds=10.0):
+    """bounded CPU sample on this host: returns the cpu_baseline object"""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    cores = os.cpu_count() or 1
+    if os.path.exists(ref) and os.access(ref, os.X_OK) and cfg.N == 1024:
+        args = [ref, "bench32", "/dev/null", "/dev/null", str(cfg.n), str(cfg.l), str(cfg.Bgbit), str(cfg.ks_t),
+                str(cfg.ks_basebit), str(int(seconds))]
+        procs = [subprocess.Popen(args, stdout=subprocess.PIPE, text=True) for _ in range(cores)]
+        total = 0.0
+        for p in procs:
+            out = p.communicate()[0].split()
+            total += float(out[0]) / float(out[1])
+        return {"value": total, "unit": "bootstraps/s", "cores": cores, "kind": "reference",
+                "sample": f"{cores} processes x {int(seconds)} s of tfhe_bootstrap_FFT composed from the reference's "
+                          "spqlios FMA assembly (execute_reverse_int x4, AddMul x8, execute_direct_torus32 x2 per "
+                          "CMux) + key switch, same parameters, synthetic keys/samples"}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py as O
+    lk, tk = O.keygen_binary(cfg.n, SEED, 1), O.keygen_binary(cfg.N, SEED, 2)
+    bk = O.bk_create32(cfg.N, lk, tk, cfg.l, cfg.Bgbit, cfg.bk_stdev, SEED, 1000)
+    ks = O.ks_create32(tk, lk, cfg.ks_t, cfg.ks_basebit, cfg.ks_stdev, SEED, 100000)
+    rs = np.random.RandomState(1)
+    t0, cnt = time.time(), 0
+    while time.time() - t0 < seconds:
+        x = rs.randint(-2 ** 31, 2 ** 31, size=cfg.n + 1).astype(np.int32)
+        O.bootstrap32(cfg.N, bk, ks, 1 << 29, x, cfg.l, cfg.Bgbit, cfg.ks_t, cfg.ks_basebit)
+        cnt += 1
+    return {"value": cnt / (time.time() - t0), "unit": "bootstraps/s", "cores": 1, "kind": "port",
+            "sample": f"{cnt} bootstraps, scalar C oracle, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="bootstraps per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    T = importlib.import_module("experimental-tfhe_amd")
+    shard = importlib.import_module("experimental-tfhe_amd.shard")
+    if not os.path.exists(T.DEFAULT_LIB):
+        importlib.import_module("experimental-tfhe_amd.build").build()
+    cfg = shard.GateConfig()
+    job = shard.GateJob(cfg, SEED, device=local)  # identical key replicas on every rank
+    eng, lib = job.eng, job.eng.lib
+    stream = torch.cuda.Stream(device=dev)
+    eng.set_stream(stream.cuda_stream)
+
+    B = a.batch
+    x_host = shard.synthetic_samples(cfg, B, seed=1234 + rank)
+    # a few real encryptions at the front: decrypt-checked after the timed region
+    msgs = [(1 << 29) if (i & 1) else -(1 << 29) for i in range(16)]
+    x_host[:16] = job.encrypt(msgs)
+    with torch.cuda.stream(stream):
+        x_d = torch.from_numpy(x_host).to(dev)
+        u_d = torch.empty((B, cfg.N + 1), dtype=torch.int32, device=dev)
+        out_d = torch.empty((B, cfg.n + 1), dtype=torch.int32, device=dev)
+    mu = 1 << 29
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev[k][0].record(stream)
+        eng._chk(lib.tfhe_amd_bootstrap_woks(eng.ctx, u_d.data_ptr(), mu, x_d.data_ptr(), B))
+        if k is not None:
+            ev[k][1].record(stream)
+        eng._chk(lib.tfhe_amd_keyswitch(eng.ctx, out_d.data_ptr(), u_d.data_ptr(), B))
+        if k is not None:
+            ev[k][2].record(stream)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(elapsed, dev)
+
+    # outside the timed region: the real encryptions must decrypt to their sign
+    out = out_d[:16].cpu().numpy()
+    ok = all((job.phase(out[i]) > 0) == (msgs[i] > 0) for i in range(16))
+    br_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(a.steps)]))
+    ks_ms = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(a.steps)]))
+
+    if rank == 0:
+        total = B * world * a.steps
+        algo_bytes = B * cfg.n * BYTES_PER_CMUX + cfg.n * BYTES_PER_ROW
+        achieved = algo_bytes / (br_ms * 1e-3)
+        flops = B * cfg.n * FLOP_PER_CMUX / (br_ms * 1e-3)
+        line = {
+            "metric": "gate bootstraps/sec (N=1024, 128-bit params)",
+            "value": total / elapsed,
+            "unit": "bootstraps/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 (anticyclic FFT) over int32 torus",
+            "data": "synthetic",
+            "config": {"workload": f"batch {B} gate bootstraps per GPU per step, {cfg.describe()}, persistent "
+                                   "blind-rotation kernel + key-switch kernel, inputs resident in HBM",
+                       "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, keys replicated"},
+            "roofline": {"bound": "hbm", "kernel": "k_blind_rotate<int32,N=1024>", "achieved": achieved / 1e9,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel_ms": br_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "fp64_valu": {"achieved_tflops": flops / 1e12, "peak_tflops": FP64_PEAK / 1e12,
+                                       "frac": flops / FP64_PEAK}},
+            "kernels_ms": {"blind_rotate_extract": br_ms, "keyswitch": ks_ms},
+            "decrypt_check": bool(ok),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    job.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("decrypt check failed")
+
+
+if __name__ == "__main__":
+    main()

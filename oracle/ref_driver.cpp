@@ -22,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -333,6 +335,122 @@ int main(int argc, char **argv) {
         LweSample64 res(N);
         circuitBootstrapWoKS(&res, mu, abar.data(), env);
         spill(outp, res.a, (size_t)(N + 1) * 8);
+        return 0;
+    }
+    if (op == "boot32" || op == "bench32") {
+        // Gate bootstrap (tfhe_bootstrap_FFT, CB/lwe_functions.cpp:434-446) COMPOSED FROM THE
+        // REFERENCE'S OWN FFT/MAC OBJECT CODE: fftp1024.execute_reverse_int, the AddMul assembly and
+        // fftp1024.execute_direct_torus32 do the arithmetic; the integer glue around them
+        // (decomposition tgsw_functions.cpp:224-337, rotation numeric_functions.cpp:304-347,
+        // extraction tlwe_functions.cpp:351-363, mod switch numeric_functions.cpp:54-60, key switch
+        // lwe_functions.cpp:136-171) is written here because those reference files do not compile.
+        //   boot32  args: n l Bgbit ks_t ks_bb count ; in: [mu i32][pad i32][bkfft][ks][x] ; out: count*(n+1) i32
+        //   bench32 args: n l Bgbit ks_t ks_bb seconds ; synthetic keys/samples; prints "<count> <seconds>"
+        const int N = 1024, n = (int)arg(0), l = (int)arg(1), Bgbit = (int)arg(2), t = (int)arg(3), bb = (int)arg(4);
+        const int kpl = 2 * l, base = 1 << bb;
+        const size_t bk_len = (size_t)n * kpl * 2 * N, ks_len = (size_t)N * t * base * (n + 1);
+        std::vector<double> bk(bk_len);
+        std::vector<int32_t> ks(ks_len), xs;
+        int32_t mu = 1 << 29;
+        size_t count = 0;
+        double budget = 0;
+        if (op == "boot32") {
+            auto in = slurp(inp);
+            const uint8_t *p = in.data();
+            memcpy(&mu, p, 4);
+            p += 8;
+            memcpy(bk.data(), p, bk_len * 8);
+            p += bk_len * 8;
+            memcpy(ks.data(), p, ks_len * 4);
+            p += ks_len * 4;
+            count = (size_t)arg(5);
+            xs.resize(count * (n + 1));
+            memcpy(xs.data(), p, xs.size() * 4);
+        } else {
+            budget = (double)arg(5);
+            SplitMix rng(42);
+            std::vector<int32_t> tor(N);
+            for (size_t r = 0; r < bk_len / N; r++) {
+                for (int j = 0; j < N; j++) tor[j] = rng.next32();
+                fftp1024.execute_reverse_torus32(bk.data() + r * N, tor.data());
+            }
+            for (auto &v : ks) v = rng.next32();
+            count = 1u << 20;  // upper bound; the time budget stops the loop
+            xs.resize((size_t)64 * (n + 1));
+            for (auto &v : xs) v = rng.next32();
+        }
+        uint32_t offset = 0;
+        for (int i = 0; i < l; i++) offset += 1u << (32 - (i + 1) * Bgbit);
+        offset *= 1u << (Bgbit - 1);
+        const uint32_t mask = (1u << Bgbit) - 1;
+        const int32_t halfBg = 1 << (Bgbit - 1);
+        std::vector<int32_t> acc(2 * N), tmp(2 * N), deca((size_t)kpl * N), u(N + 1), out(count * (n + 1));
+        std::vector<double> decaF((size_t)kpl * N), tmpa(2 * N);
+        auto modsw = [&](int32_t ph) { return (int)((((uint64_t)(uint32_t)ph << 32) + (1ull << 52)) >> 53); };
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        size_t done = 0;
+        for (size_t c = 0; c < count; c++) {
+            const int32_t *x = xs.data() + (op == "boot32" ? c : (c % 64)) * (n + 1);
+            const int barb = modsw(x[n]);
+            // acc = (0, X^{2N-barb} * mu)
+            for (int j = 0; j < N; j++) {
+                acc[j] = 0;
+                const int idx = (j - (2 * N - barb)) & (2 * N - 1);
+                acc[N + j] = (idx & N) ? -mu : mu;
+            }
+            for (int i = 0; i < n; i++) {
+                const int a = modsw(x[i]);
+                if (a == 0) continue;
+                for (int q = 0; q < 2; q++)
+                    for (int j = 0; j < N; j++) {
+                        const int idx = (j - a) & (2 * N - 1);
+                        const uint32_t s = (uint32_t)acc[q * N + (idx & (N - 1))];
+                        tmp[q * N + j] = (int32_t)(((idx & N) ? (0u - s) : s) - (uint32_t)acc[q * N + j]);
+                    }
+                for (int q = 0; q < 2; q++)
+                    for (int d = 0; d < l; d++) {
+                        const int decal = 32 - (d + 1) * Bgbit;
+                        int32_t *o = deca.data() + (size_t)(q * l + d) * N;
+                        for (int j = 0; j < N; j++)
+                            o[j] = (int32_t)((((uint32_t)tmp[q * N + j] + offset) >> decal) & mask) - halfBg;
+                    }
+                for (int p = 0; p < kpl; p++) fftp1024.execute_reverse_int(decaF.data() + (size_t)p * N, deca.data() + (size_t)p * N);
+                std::fill(tmpa.begin(), tmpa.end(), 0.0);
+                const double *row = bk.data() + (size_t)i * kpl * 2 * N;
+                for (int p = 0; p < kpl; p++)
+                    for (int q = 0; q < 2; q++)
+                        LagrangeHalfCPolynomialAddMulASM(tmpa.data() + q * N, decaF.data() + (size_t)p * N,
+                                                         (double *)row + ((size_t)p * 2 + q) * N, N / 2);
+                for (int q = 0; q < 2; q++) fftp1024.execute_direct_torus32(tmp.data() + q * N, tmpa.data() + q * N);
+                for (int j = 0; j < 2 * N; j++) acc[j] = (int32_t)((uint32_t)acc[j] + (uint32_t)tmp[j]);
+            }
+            u[0] = acc[0];
+            for (int j = 1; j < N; j++) u[j] = (int32_t)(0u - (uint32_t)acc[N - j]);
+            u[N] = acc[N];
+            int32_t *r = out.data() + (op == "boot32" ? c : 0) * (n + 1);
+            for (int h = 0; h < n; h++) r[h] = 0;
+            r[n] = u[N];
+            const uint32_t prec = 1u << (32 - (1 + bb * t));
+            for (int i = 0; i < N; i++) {
+                const uint32_t aibar = (uint32_t)u[i] + prec;
+                for (int j = 0; j < t; j++) {
+                    const uint32_t aij = (aibar >> (32 - (j + 1) * bb)) & (uint32_t)(base - 1);
+                    if (!aij) continue;
+                    const int32_t *kr = ks.data() + (((size_t)i * t + j) * base + aij) * (n + 1);
+                    for (int h = 0; h <= n; h++) r[h] = (int32_t)((uint32_t)r[h] - (uint32_t)kr[h]);
+                }
+            }
+            done++;
+            if (op == "bench32") {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) >= budget) break;
+            }
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double secs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+        if (op == "boot32") spill(outp, out.data(), out.size() * 4);
+        printf("%zu %.6f\n", done, secs);
         return 0;
     }
     fprintf(stderr, "unknown op %s\n", op.c_str());

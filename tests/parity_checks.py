@@ -1,0 +1,190 @@
+"""Parity checks shared by the GPU tests (real library, -m gpu) and the CPU-side kernel
+emulation tests (tests/emu build of the same sources).  Every check drives the C ABI
+(include/tfhe_amd.h) through the ctypes binding and compares with the oracle bit for bit:
+integer torus outputs with array_equal, Lagrange-domain doubles on their raw 64-bit
+patterns (+0.0 / -0.0 are the one tolerated difference: a sign of zero never reaches a
+torus value)."""
+import importlib
+
+import numpy as np
+
+import oracle_py as O
+
+T = importlib.import_module("experimental-tfhe_amd")
+
+SEED = 0x5446484500000001
+
+
+def same_doubles(a, b):
+    a, b = np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64)
+    if a.shape != b.shape:
+        return False
+    ua, ub = a.view(np.uint64).copy(), b.view(np.uint64).copy()
+    z = np.uint64(0x8000000000000000)
+    ua[ua == z] = 0  # -0.0 -> +0.0
+    ub[ub == z] = 0
+    return bool(np.array_equal(ua, ub))
+
+
+class GateSetup:
+    """keys + engine for one Torus32 parameter set; keys come from the ORACLE's generator and
+    are cross-checked against the library's own generator (same PRNG specification)."""
+
+    def __init__(self, lib_path, N, n, l, Bgbit, ks_t, ks_bb, bk_stdev=2.0 ** -25, ks_stdev=2.0 ** -15, seed=SEED):
+        self.N, self.n, self.l, self.Bgbit, self.ks_t, self.ks_bb = N, n, l, Bgbit, ks_t, ks_bb
+        self.lib_path, self.seed = lib_path, seed
+        self.lwe_key = O.keygen_binary(n, seed, 1)
+        self.tkey = O.keygen_binary(N, seed, 2)
+        self.bk = O.bk_create32(N, self.lwe_key, self.tkey, l, Bgbit, bk_stdev, seed, 1000)
+        self.ks = O.ks_create32(self.tkey, self.lwe_key, ks_t, ks_bb, ks_stdev, seed, 100000)
+        self.bk_stdev, self.ks_stdev = bk_stdev, ks_stdev
+        self.eng = T.Engine(torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=ks_t, ks_basebit=ks_bb, lib_path=lib_path)
+        self.gsw = self.eng.gsw_from_fft(self.bk)
+        self.eng.set_bootstrap_key(self.gsw)
+        self.eng.load_keyswitch_key(self.ks)
+
+    def close(self):
+        self.eng.close()
+
+    def encrypt(self, messages, stdev=2.0 ** -15, stream0=5000):
+        return np.stack([O.lwe_encrypt32(int(m), stdev, self.lwe_key, O.rng(self.seed, stream0 + i))
+                         for i, m in enumerate(messages)])
+
+
+# ---------------------------------------------------------------- L1 plugin
+def check_fft_plugin(lib_path, N, count=4, seed=11):
+    rs = np.random.RandomState(seed)
+    e = T.Engine(torus_bits=32, n=1, N=N, l=2, Bgbit=10, ks_t=0, lib_path=lib_path)
+    try:
+        f, r = e.tables()
+        fo, ro = O.table_arrays(N)
+        assert np.array_equal(f.view(np.uint64), fo.view(np.uint64)), "fft twiddle table"
+        assert np.array_equal(r.view(np.uint64), ro.view(np.uint64)), "ifft twiddle table"
+        a32 = rs.randint(-2 ** 31, 2 ** 31, size=(count, N)).astype(np.int32)
+        dig = rs.randint(-512, 512, size=(count, N)).astype(np.int32)
+        a64 = rs.randint(-2 ** 63, 2 ** 63 - 1, size=(count, N), dtype=np.int64)
+        edge = np.zeros((4, N), np.int32)  # empty / extreme inputs
+        edge[1] = 2 ** 31 - 1
+        edge[2] = -2 ** 31
+        edge[3, 0] = 1
+        for x in (a32, dig, edge):
+            assert same_doubles(e.ifft_int32(x), O.execute_reverse_int(N, x)), "execute_reverse_int"
+        assert same_doubles(e.ifft_torus64(a64), O.execute_reverse_torus64(N, a64)), "execute_reverse_torus64"
+        lag32 = O.lagrange_addmul(N, np.zeros((count, N)), O.execute_reverse_int(N, dig), O.execute_reverse_int(N, a32))
+        assert np.array_equal(e.fft_torus32(lag32), O.execute_direct_torus32(N, lag32)), "execute_direct_torus32"
+        lag64 = O.lagrange_addmul(N, np.zeros((count, N)), O.execute_reverse_int(N, dig),
+                                  O.execute_reverse_torus64(N, a64))
+        assert np.array_equal(e.fft_torus64(lag64), O.execute_direct_torus64(N, lag64)), "execute_direct_torus64"
+        assert np.array_equal(e.fft_torus32(np.zeros((1, N))), np.zeros((1, N), np.int32))
+        assert np.array_equal(e.fft_torus64(np.zeros((1, N))), np.zeros((1, N), np.int64))
+        got = e.lagrange_addmul(lag32, O.execute_reverse_int(N, dig), O.execute_reverse_int(N, a32))
+        want = O.lagrange_addmul(N, lag32, O.execute_reverse_int(N, dig), O.execute_reverse_int(N, a32))
+        assert same_doubles(got, want), "LagrangeHalfCPolynomialAddMul"
+        got = e.lagrange_addmul(lag32, O.execute_reverse_int(N, dig), O.execute_reverse_int(N, a32[0]), b_shared=True)
+        want = O.lagrange_addmul(N, lag32, O.execute_reverse_int(N, dig),
+                                 np.repeat(O.execute_reverse_int(N, a32[:1]), count, axis=0))
+        assert same_doubles(got, want), "AddMul with shared b"
+        # round trip fft(ifft(a)) (spqlios-bench.cpp:76-77 identity with 2/N folded in): the
+        # truncating conversion may lose one unit, and must lose it exactly where the oracle does
+        rt = e.fft_torus32(e.ifft_int32(a32))
+        assert np.array_equal(rt, O.execute_direct_torus32(N, O.execute_reverse_int(N, a32))), "round trip"
+        assert np.abs(rt.astype(np.int64) - a32).max() <= 1
+    finally:
+        e.close()
+
+
+# ------------------------------------------------------------ Torus32 path
+def check_gate_path(lib_path, N, n, l, Bgbit, ks_t, ks_bb, B, seed=21, check_export=True):
+    rs = np.random.RandomState(seed)
+    s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb)
+    e = s.eng
+    try:
+        # harness parity: the library's key generator == the oracle's (same PRNG spec)
+        assert np.array_equal(T.keygen_binary(n, s.seed, 1, lib_path=lib_path), s.lwe_key)
+        bkt = T.keygen_bk_torus(32, s.lwe_key, s.tkey, l, Bgbit, s.bk_stdev, s.seed, 1000, lib_path=lib_path)
+        assert np.array_equal(T.keygen_ks32(s.tkey, s.lwe_key, ks_t, ks_bb, s.ks_stdev, s.seed, 100000,
+                                            lib_path=lib_path), s.ks)
+        if check_export:
+            # tGswToFFTConvert on the GPU == oracle's execute_reverse_torus32 of every polynomial
+            g2 = e.gsw_from_torus(bkt)
+            for idx in (0, n - 1):
+                assert same_doubles(e.gsw_export_fft(g2, idx), s.bk[idx]), "bk conversion"
+                assert same_doubles(e.gsw_export_fft(s.gsw, idx), s.bk[idx]), "bk upload/export"
+        acc = rs.randint(-2 ** 31, 2 ** 31, size=(B, 2, N)).astype(np.int32)
+        # tGswFFTExternMulToTLwe
+        want = np.stack([O.extprod32(N, acc[b], s.bk[n // 2], l, Bgbit) for b in range(B)]).reshape(B, 2, N)
+        assert np.array_equal(e.extern_mul(acc, s.gsw, n // 2), want), "external product"
+        # tfhe_MuxRotate_FFT (rotation 0 = identity)
+        ba = rs.randint(1, 2 * N, size=B).astype(np.int32)
+        ba[0] = 0
+        want = np.stack([O.mux_rotate32(N, acc[b], s.bk[1 % n], ba[b], l, Bgbit) if ba[b] else acc[b]
+                         for b in range(B)]).reshape(B, 2, N)
+        assert np.array_equal(e.mux_rotate(acc, s.gsw, 1 % n, ba), want), "CMux"
+        # tfhe_blindRotate_FFT, including skipped (zero) rotations and both halves of [0,2N)
+        bara = rs.randint(0, 2 * N, size=(B, n)).astype(np.int32)
+        bara[0, 0] = 0
+        bara[B - 1, n - 1] = 0
+        bara[0, 1 % n] = N
+        bara[0, 2 % n] = 2 * N - 1
+        want = np.stack([O.blind_rotate32(N, acc[b], s.bk, bara[b], l, Bgbit) for b in range(B)]).reshape(B, 2, N)
+        assert np.array_equal(e.blind_rotate(acc, bara), want), "blind rotation"
+        # tfhe_blindRotateAndExtract_FFT, shared and per-sample test vectors, barb = 0 edge
+        rot = rs.randint(0, 2 * N, size=(B, n + 1)).astype(np.int32)
+        rot[0, n] = 0
+        v = rs.randint(-2 ** 31, 2 ** 31, size=N).astype(np.int32)
+        want = np.stack([O.blind_rotate_extract32(N, v, s.bk, rot[b, n], rot[b, :n], l, Bgbit) for b in range(B)])
+        assert np.array_equal(e.blind_rotate_extract(v, rot), want), "blind rotate + extract"
+        vs = rs.randint(-2 ** 31, 2 ** 31, size=(B, N)).astype(np.int32)
+        want = np.stack([O.blind_rotate_extract32(N, vs[b], s.bk, rot[b, n], rot[b, :n], l, Bgbit) for b in range(B)])
+        assert np.array_equal(e.blind_rotate_extract(vs, rot), want), "per-sample test vectors"
+        # tfhe_bootstrap_woKS_FFT / lweKeySwitch / tfhe_bootstrap_FFT on real ciphertexts
+        mu = 1 << 29
+        msgs = [mu if b % 2 else -mu for b in range(B)]
+        x = s.encrypt(msgs)
+        assert np.array_equal(T.lwe_encrypt32(msgs[0], 2.0 ** -15, s.lwe_key, s.seed, 5000, lib_path=lib_path), x[0])
+        assert np.array_equal(e.modswitch(x), O.modswitch32(x, 2 * N)), "modSwitchFromTorus32"
+        woks = np.stack([O.bootstrap_woks32(N, s.bk, mu, x[b], l, Bgbit) for b in range(B)])
+        assert np.array_equal(e.bootstrap_woks(mu, x), woks), "bootstrap without key switch"
+        ksw = np.stack([O.keyswitch32(s.ks, woks[b], N, n, ks_t, ks_bb) for b in range(B)])
+        assert np.array_equal(e.keyswitch(woks), ksw), "key switch"
+        full = np.stack([O.bootstrap32(N, s.bk, s.ks, mu, x[b], l, Bgbit, ks_t, ks_bb) for b in range(B)])
+        assert np.array_equal(full, ksw)
+        assert np.array_equal(e.bootstrap(mu, x), full), "bootstrap"
+        assert np.array_equal(e.bootstrap(mu, x, streamed=True), full), "bootstrap, one launch per CMux"
+        assert np.array_equal(e.bootstrap_host(mu, x), full), "bootstrap, host pointers"
+        # uniformly random 'ciphertexts' (throughput workload): still bit-identical
+        xr = rs.randint(-2 ** 31, 2 ** 31, size=(B, n + 1)).astype(np.int32)
+        want = np.stack([O.bootstrap32(N, s.bk, s.ks, mu, xr[b], l, Bgbit, ks_t, ks_bb) for b in range(B)])
+        assert np.array_equal(e.bootstrap(mu, xr), want), "bootstrap on random samples"
+        # empty batch is a no-op
+        assert e.bootstrap(mu, np.zeros((0, n + 1), np.int32)).shape == (0, n + 1)
+        return s, x, msgs, full
+    finally:
+        s.close()
+
+
+# ------------------------------------------------------------ Torus64 path
+def check_torus64_path(lib_path, N, n, l, Bgbit, B, seed=31):
+    rs = np.random.RandomState(seed)
+    key0 = O.keygen_binary(n, SEED, 11)
+    tkey = O.keygen_binary(N, SEED, 12)
+    bk = O.bk_create64(N, key0, tkey, l, Bgbit, 2.0 ** -44, SEED, 2000)
+    e = T.Engine(torus_bits=64, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=0, lib_path=lib_path)
+    try:
+        bkt = T.keygen_bk_torus(64, key0, tkey, l, Bgbit, 2.0 ** -44, SEED, 2000, lib_path=lib_path)
+        g = e.gsw_from_torus(bkt)
+        assert same_doubles(e.gsw_export_fft(g, n - 1), bk[n - 1]), "Torus64 bk conversion"
+        e.set_bootstrap_key(g)
+        acc = rs.randint(-2 ** 63, 2 ** 63 - 1, size=(B, 2, N), dtype=np.int64)
+        want = np.stack([O.extprod64(N, acc[b], bk[0], l, Bgbit) for b in range(B)]).reshape(B, 2, N)
+        assert np.array_equal(e.extern_mul(acc, g, 0), want), "Torus64 external product"
+        bara = rs.randint(0, 2 * N, size=(B, n)).astype(np.int32)
+        bara[0, 0] = 0
+        want = np.stack([O.blind_rotate64(N, acc[b], bk, bara[b], l, Bgbit) for b in range(B)]).reshape(B, 2, N)
+        assert np.array_equal(e.blind_rotate(acc, bara), want), "Torus64 blind rotation"
+        abar = rs.randint(0, 2 * N, size=(B, n + 1)).astype(np.int32)
+        mu = 1 << 56
+        want = np.stack([O.cb_bootstrap_woks64(N, mu, abar[b], bk, l, Bgbit) for b in range(B)])
+        assert np.array_equal(e.cb_bootstrap_woks(mu, abar), want), "circuitBootstrapWoKS"
+    finally:
+        e.close()

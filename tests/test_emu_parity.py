@@ -1,0 +1,30 @@
+"""Kernel logic vs the oracle on the CPU emulation build (tests/emu).  Same checks as the GPU
+parity tests, at sizes the fiber emulator finishes in seconds.  These do NOT count as GPU
+parity; they exist to catch kernel bugs before a GPU call and to run the kernels under
+sanitizers."""
+import pytest
+
+import parity_checks as P
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_fft_plugin_emu(emu_lib, N):
+    P.check_fft_plugin(emu_lib, N, count=3)
+
+
+def test_gate_path_emu_n1024(emu_lib):
+    P.check_gate_path(emu_lib, N=1024, n=6, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=3)
+
+
+def test_gate_path_emu_other_gadgets(emu_lib):
+    P.check_gate_path(emu_lib, N=1024, n=3, l=3, Bgbit=7, ks_t=16, ks_bb=1, B=2, seed=5)
+    P.check_gate_path(emu_lib, N=1024, n=2, l=1, Bgbit=12, ks_t=5, ks_bb=3, B=9, seed=6)  # ragged: 9 = 8 + 1 waves
+
+
+def test_gate_path_emu_n2048(emu_lib):
+    P.check_gate_path(emu_lib, N=2048, n=3, l=2, Bgbit=9, ks_t=4, ks_bb=3, B=5)
+
+
+@pytest.mark.parametrize("N,l,Bgbit,B", [(2048, 4, 9, 4), (1024, 3, 10, 5)])
+def test_torus64_path_emu(emu_lib, N, l, Bgbit, B):
+    P.check_torus64_path(emu_lib, N=N, n=3, l=l, Bgbit=Bgbit, B=B)
