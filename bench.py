@@ -84,11 +84,23 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     a = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    T = importlib.import_module("experimental-tfhe_amd")
+    shard = importlib.import_module("experimental-tfhe_amd.shard")
+    cfg = shard.GateConfig()
+    # Everything that spawns a child process happens HERE, before this process initialises the
+    # GPU (a fork/exec from a GPU-initialised process is not allowed on the GPU pool):
+    # the library build if missing, and the CPU baseline (rank 0, single-GPU runs only).
+    if not os.path.exists(T.DEFAULT_LIB):
+        importlib.import_module("experimental-tfhe_amd.build").build()
+    cpu_line = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu_line = cpu_baseline(cfg, a.cpu_seconds)
+
+    import torch
+    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -99,11 +111,6 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    T = importlib.import_module("experimental-tfhe_amd")
-    shard = importlib.import_module("experimental-tfhe_amd.shard")
-    if not os.path.exists(T.DEFAULT_LIB):
-        importlib.import_module("experimental-tfhe_amd.build").build()
-    cfg = shard.GateConfig()
     job = shard.GateJob(cfg, SEED, device=local)  # identical key replicas on every rank
     eng, lib = job.eng, job.eng.lib
     stream = torch.cuda.Stream(device=dev)
@@ -182,8 +189,8 @@ def main():
             "kernels_ms": {"blind_rotate_extract": br_ms, "keyswitch": ks_ms},
             "decrypt_check": bool(ok),
         }
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
     job.close()
     if world > 1:

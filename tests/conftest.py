@@ -13,6 +13,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # build + load the oracle before any test can touch a GPU: afterwards this process must not
+    # fork/exec (a child exec from a GPU-initialised process can take the GPU box down)
+    import oracle_py
+    oracle_py.lib()
+
+
 @pytest.fixture(scope="session")
 def emu_lib():
     """CPU emulation build of the kernel sources (tests/emu); test infrastructure only."""

@@ -76,9 +76,10 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
     b.all.expected = (int)nt;
     b.waves.resize((nt + 63) / 64);
     for (unsigned w = 0; w < b.waves.size(); w++) b.waves[w].expected = (int)std::min(64u, nt - 64 * w);
-    // 64 KiB of slack behind the requested LDS so an out-of-bounds index is caught by ASan
-    // (or at least does not trample a neighbour) rather than silently aliasing.
-    b.smem = (unsigned char *)aligned_alloc(64, ((smem_bytes + 63) / 64) * 64 + 64);
+    // exact size (rounded to the 16-byte LDS granule) so ASan sees any out-of-bounds LDS index
+    unsigned char *smem_raw = (unsigned char *)malloc(((smem_bytes + 15) / 16) * 16 + 16);
+    b.smem = smem_raw;
+    b.smem += 16 - ((uintptr_t)b.smem & 15);  // 16-byte aligned like the hardware carve-out
     t_blockIdx = Dim3(bx);
     t_blockDim = block;
     t_gridDim = grid;
@@ -106,7 +107,7 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
         }
     }
     for (auto &f : b.fibers) munmap(f.stack, kStack);
-    free(b.smem);
+    free(smem_raw);
     t_blk = nullptr;
 }
 }  // namespace
@@ -139,7 +140,8 @@ void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t sme
 }  // namespace emu
 
 hipError_t hipMalloc(void **p, size_t bytes) {
-    *p = aligned_alloc(256, ((bytes + 255) / 256) * 256 + 256);
+    // exact size: ASan then flags any out-of-bounds device-pointer access made by a kernel
+    *p = malloc(bytes ? bytes : 1);
     return *p ? hipSuccess : hipErrorInvalidValue;
 }
 hipError_t hipFree(void *p) {

@@ -1,0 +1,50 @@
+"""Staged GPU sanity run (manual tool, not a pytest module): each stage prints before it
+starts, so a hang or fault can be attributed.  Usage: python tests/gpu_stage_check.py [max_stage]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import oracle_py as O  # noqa: E402
+
+O.lib()
+T = importlib.import_module("experimental-tfhe_amd")
+import parity_checks as P  # noqa: E402
+
+max_stage = int(sys.argv[1]) if len(sys.argv) > 1 else 99
+
+
+def say(*a):
+    print(time.strftime("%H:%M:%S"), *a, flush=True)
+
+
+say("stage 1: context + N=1024 ifft of 4 polynomials")
+e = T.Engine(torus_bits=32, n=1, N=1024, l=2, Bgbit=10, ks_t=0)
+rs = np.random.RandomState(0)
+a = rs.randint(-2 ** 31, 2 ** 31, size=(4, 1024)).astype(np.int32)
+got = e.ifft_int32(a)
+say("   ifft bit-exact:", P.same_doubles(got, O.execute_reverse_int(1024, a)))
+e.close()
+if max_stage >= 2:
+    say("stage 2: FFT plugin checks, N=1024 and 2048")
+    P.check_fft_plugin(T.DEFAULT_LIB, 1024, count=5)
+    P.check_fft_plugin(T.DEFAULT_LIB, 2048, count=5)
+    say("   ok")
+if max_stage >= 3:
+    say("stage 3: gate path, n=4, B=3")
+    P.check_gate_path(T.DEFAULT_LIB, N=1024, n=4, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=3)
+    say("   ok")
+if max_stage >= 4:
+    say("stage 4: gate path, n=630, B=4")
+    P.check_gate_path(T.DEFAULT_LIB, N=1024, n=630, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=4, check_export=False)
+    say("   ok")
+if max_stage >= 5:
+    say("stage 5: Torus64 N=2048 l=4, n=5, B=4")
+    P.check_torus64_path(T.DEFAULT_LIB, N=2048, n=5, l=4, Bgbit=9, B=4)
+    say("   ok")
+say("done")
