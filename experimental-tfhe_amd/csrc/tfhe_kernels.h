@@ -89,7 +89,7 @@ struct WaveFFT {
     using G = Geom<LOGN>;
     static constexpr int PPL = G::PPL;
 
-    // one wave-wide transpose through LDS: write with map W, read with map Rd (index fns)
+    // one wave-wide transpose through LDS: write with map widx, read with map ridx
     template <class WIdx, class RIdx>
     TFHE_DEVICE static void transpose(double (&x)[PPL], double *xch, WIdx widx, RIdx ridx) {
 #pragma unroll
@@ -100,16 +100,21 @@ struct WaveFFT {
         TFHE_WAVE_FENCE();
     }
 
-    // coefficient -> Lagrange.  In: lane t register m = point jA(t,m) (re = coef j, im = coef j+N/2).
+    // coefficient -> Lagrange for NP polynomials at once (every twiddle is read from LDS once
+    // and used by all NP).  In: lane t register m = point jA(t,m) (re = coef j, im = coef j+N/2).
     // Out: register m = position jC(t,m) of the reference's output order.
-    TFHE_DEVICE static void ifft(double (&xr)[PPL], double (&xi)[PPL], const double2 *tw, double *xch, int t) {
+    template <int NP>
+    TFHE_DEVICE static void ifft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const double2 *tw, double *xch, int t) {
         // twist by omega^j (spqlios-ifft-fma.s:63-78)
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
             const double2 w = tw[G::jA(t, m)];
-            const double r = xr[m], i = xi[m];
-            xr[m] = __builtin_fma(-i, w.y, r * w.x);
-            xi[m] = __builtin_fma(i, w.x, r * w.y);
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const double r = xr[p][m], i = xi[p][m];
+                xr[p][m] = __builtin_fma(-i, w.y, r * w.x);
+                xi[p][m] = __builtin_fma(i, w.x, r * w.y);
+            }
         }
         // pass A: strides 64*s, s = PPL/2 .. 1
 #pragma unroll
@@ -118,13 +123,17 @@ struct WaveFFT {
             for (int m = 0; m < PPL; m++) {
                 if (m & s) continue;
                 const double2 w = tw[G::tw_base(64 * s) + t + 64 * (m & (s - 1))];
-                dif_bfly(xr[m], xi[m], xr[m + s], xi[m + s], w.x, w.y);
+#pragma unroll
+                for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], w.x, w.y);
             }
         }
         auto wA = [&](int m) { return G::idx1(G::jA(t, m)); };
         auto rB = [&](int m) { return G::idx1(G::jB(t, m)); };
-        transpose(xr, xch, wA, rB);
-        transpose(xi, xch, wA, rB);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            transpose(xr[p], xch, wA, rB);
+            transpose(xi[p], xch, wA, rB);
+        }
         // pass B: strides s<<CB
         const int c = t & ((1 << G::CB) - 1);
 #pragma unroll
@@ -133,81 +142,98 @@ struct WaveFFT {
             for (int m = 0; m < PPL; m++) {
                 if (m & s) continue;
                 const double2 w = tw[G::tw_base(s << G::CB) + ((m & (s - 1)) << G::CB) + c];
-                dif_bfly(xr[m], xi[m], xr[m + s], xi[m + s], w.x, w.y);
+#pragma unroll
+                for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], w.x, w.y);
             }
         }
         auto wB = [&](int m) { return G::idx2(G::jB(t, m)); };
         auto rC = [&](int m) { return G::idx2(G::jC(t, m)); };
-        transpose(xr, xch, wB, rC);
-        transpose(xi, xch, wB, rC);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            transpose(xr[p], xch, wB, rC);
+            transpose(xi[p], xch, wB, rC);
+        }
         // pass C: (N=1024 only) stride 4 general stage, then size-4 and size-2 steps
         if (G::CB == 3) {
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 if (m & 4) continue;
                 const double2 w = tw[G::tw_base(4) + (m & 3)];
-                dif_bfly(xr[m], xi[m], xr[m + 4], xi[m + 4], w.x, w.y);
+#pragma unroll
+                for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + 4], xi[p][m + 4], w.x, w.y);
             }
         }
 #pragma unroll
-        for (int b = 0; b < PPL; b += 4) {  // spqlios-ifft-fma.s:194-213
-            const double r0 = xr[b], r1 = xr[b + 1], r2 = xr[b + 2], r3 = xr[b + 3];
-            const double i0 = xi[b], i1 = xi[b + 1], i2 = xi[b + 2], i3 = xi[b + 3];
-            xr[b] = r0 + r2;
-            xr[b + 1] = r1 + r3;
-            xr[b + 2] = r0 - r2;
-            xr[b + 3] = i3 - i1;
-            xi[b] = i0 + i2;
-            xi[b + 1] = i1 + i3;
-            xi[b + 2] = i0 - i2;
-            xi[b + 3] = r1 - r3;
-        }
+        for (int p = 0; p < NP; p++) {
 #pragma unroll
-        for (int b = 0; b < PPL; b += 2) {  // :247-263
-            const double r0 = xr[b], r1 = xr[b + 1], i0 = xi[b], i1 = xi[b + 1];
-            xr[b] = r0 + r1;
-            xr[b + 1] = r0 - r1;
-            xi[b] = i0 + i1;
-            xi[b + 1] = i0 - i1;
+            for (int b = 0; b < PPL; b += 4) {  // spqlios-ifft-fma.s:194-213
+                const double r0 = xr[p][b], r1 = xr[p][b + 1], r2 = xr[p][b + 2], r3 = xr[p][b + 3];
+                const double i0 = xi[p][b], i1 = xi[p][b + 1], i2 = xi[p][b + 2], i3 = xi[p][b + 3];
+                xr[p][b] = r0 + r2;
+                xr[p][b + 1] = r1 + r3;
+                xr[p][b + 2] = r0 - r2;
+                xr[p][b + 3] = i3 - i1;
+                xi[p][b] = i0 + i2;
+                xi[p][b + 1] = i1 + i3;
+                xi[p][b + 2] = i0 - i2;
+                xi[p][b + 3] = r1 - r3;
+            }
+#pragma unroll
+            for (int b = 0; b < PPL; b += 2) {  // :247-263
+                const double r0 = xr[p][b], r1 = xr[p][b + 1], i0 = xi[p][b], i1 = xi[p][b + 1];
+                xr[p][b] = r0 + r1;
+                xr[p][b + 1] = r0 - r1;
+                xi[p][b] = i0 + i1;
+                xi[p][b + 1] = i0 - i1;
+            }
         }
     }
 
-    // Lagrange -> coefficient (caller has applied the 2/N scale).  In: register m = position
-    // jC(t,m).  Out: register m = point jA(t,m) (re = coef j, im = coef j+N/2).
-    TFHE_DEVICE static void fft(double (&xr)[PPL], double (&xi)[PPL], const double2 *tw, double *xch, int t) {
+    // Lagrange -> coefficient for NP polynomials (caller has applied the 2/N scale).
+    // In: register m = position jC(t,m).  Out: register m = point jA(t,m).
+    template <int NP>
+    TFHE_DEVICE static void fft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const double2 *tw, double *xch, int t) {
 #pragma unroll
-        for (int b = 0; b < PPL; b += 2) {  // spqlios-fft-fma.s:79-95
-            const double r0 = xr[b], r1 = xr[b + 1], i0 = xi[b], i1 = xi[b + 1];
-            xr[b] = r0 + r1;
-            xr[b + 1] = r0 - r1;
-            xi[b] = i0 + i1;
-            xi[b + 1] = i0 - i1;
-        }
+        for (int p = 0; p < NP; p++) {
 #pragma unroll
-        for (int b = 0; b < PPL; b += 4) {  // :134-152
-            const double r0 = xr[b], r1 = xr[b + 1], r2 = xr[b + 2], r3 = xr[b + 3];
-            const double i0 = xi[b], i1 = xi[b + 1], i2 = xi[b + 2], i3 = xi[b + 3];
-            xr[b] = r0 + r2;
-            xr[b + 1] = r1 + i3;
-            xr[b + 2] = r0 - r2;
-            xr[b + 3] = r1 - i3;
-            xi[b] = i0 + i2;
-            xi[b + 1] = i1 - r3;
-            xi[b + 2] = i0 - i2;
-            xi[b + 3] = i1 + r3;
+            for (int b = 0; b < PPL; b += 2) {  // spqlios-fft-fma.s:79-95
+                const double r0 = xr[p][b], r1 = xr[p][b + 1], i0 = xi[p][b], i1 = xi[p][b + 1];
+                xr[p][b] = r0 + r1;
+                xr[p][b + 1] = r0 - r1;
+                xi[p][b] = i0 + i1;
+                xi[p][b + 1] = i0 - i1;
+            }
+#pragma unroll
+            for (int b = 0; b < PPL; b += 4) {  // :134-152
+                const double r0 = xr[p][b], r1 = xr[p][b + 1], r2 = xr[p][b + 2], r3 = xr[p][b + 3];
+                const double i0 = xi[p][b], i1 = xi[p][b + 1], i2 = xi[p][b + 2], i3 = xi[p][b + 3];
+                xr[p][b] = r0 + r2;
+                xr[p][b + 1] = r1 + i3;
+                xr[p][b + 2] = r0 - r2;
+                xr[p][b + 3] = r1 - i3;
+                xi[p][b] = i0 + i2;
+                xi[p][b + 1] = i1 - r3;
+                xi[p][b + 2] = i0 - i2;
+                xi[p][b + 3] = i1 + r3;
+            }
         }
         if (G::CB == 3) {
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 if (m & 4) continue;
                 const double2 w = tw[G::tw_base(4) + (m & 3)];
-                dit_bfly(xr[m], xi[m], xr[m + 4], xi[m + 4], (m & 3) == 2 ? -w.x : w.x, w.y);
+                const double wc = (m & 3) == 2 ? -w.x : w.x;  // quarter turn
+#pragma unroll
+                for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + 4], xi[p][m + 4], wc, w.y);
             }
         }
         auto wC = [&](int m) { return G::idx2(G::jC(t, m)); };
         auto rB = [&](int m) { return G::idx2(G::jB(t, m)); };
-        transpose(xr, xch, wC, rB);
-        transpose(xi, xch, wC, rB);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            transpose(xr[p], xch, wC, rB);
+            transpose(xi[p], xch, wC, rB);
+        }
         const int c = t & ((1 << G::CB) - 1);
 #pragma unroll
         for (int s = 1; s <= PPL / 2; s <<= 1) {
@@ -218,13 +244,18 @@ struct WaveFFT {
                 // quarter turn: off == (s<<CB)/2
                 const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
                 const bool lq = (s == 1) ? (c == (1 << (G::CB - 1))) : (c == 0);
-                dit_bfly(xr[m], xi[m], xr[m + s], xi[m + s], mq ? flip_sign_if(w.x, lq) : w.x, w.y);
+                const double wc = mq ? flip_sign_if(w.x, lq) : w.x;
+#pragma unroll
+                for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], wc, w.y);
             }
         }
         auto wB = [&](int m) { return G::idx1(G::jB(t, m)); };
         auto rA = [&](int m) { return G::idx1(G::jA(t, m)); };
-        transpose(xr, xch, wB, rA);
-        transpose(xi, xch, wB, rA);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            transpose(xr[p], xch, wB, rA);
+            transpose(xi[p], xch, wB, rA);
+        }
 #pragma unroll
         for (int s = 1; s <= PPL / 2; s <<= 1) {
 #pragma unroll
@@ -234,7 +265,9 @@ struct WaveFFT {
                 // quarter turn: off == 32*s
                 const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
                 const bool lq = (s == 1) ? (t == 32) : (t == 0);
-                dit_bfly(xr[m], xi[m], xr[m + s], xi[m + s], mq ? flip_sign_if(w.x, lq) : w.x, w.y);
+                const double wc = mq ? flip_sign_if(w.x, lq) : w.x;
+#pragma unroll
+                for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], wc, w.y);
             }
         }
         // final twist by conj(omega^j), four rounded products (spqlios-fft-fma.s:255-274):
@@ -242,10 +275,13 @@ struct WaveFFT {
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
             const double2 w = tw[G::jA(t, m)];
-            const double r = xr[m], i = xi[m];
-            const double rc = r * w.x, rs = r * w.y, ic = i * w.x, is = i * w.y;
-            xr[m] = rc + is;
-            xi[m] = ic - rs;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const double r = xr[p][m], i = xi[p][m];
+                const double rc = r * w.x, rs = r * w.y, ic = i * w.x, is = i * w.y;
+                xr[p][m] = rc + is;
+                xi[p][m] = ic - rs;
+            }
         }
     }
 };
@@ -336,10 +372,15 @@ TFHE_DEVICE void mac_row(double (&fr)[2][PPL], double (&fi)[2][PPL], const doubl
     }
 }
 
-// acc <- bk_row (x) ((X^a - 1) * acc) + acc      (a != 0; ROTATE=false: acc <- bk_row (x) acc)
-// bkrow: device layout [2l][2][PPL][64] complex, pre-scaled by 2/N at upload.
-template <typename T, int LOGN, bool ROTATE>
-TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int a,
+// One CMux step on the wave's accumulator:
+//   rotate:  acc <- bk_row (x) ((X^a - 1) * acc) + acc   (tfhe_MuxRotate_FFT, a != 0)
+//   !rotate: acc <- bk_row (x) acc                       (tGswFFTExternMulToTLwe)
+// `rotate` is wave-uniform.  bkrow: device layout [2l][2][PPL][64] complex, pre-scaled by 2/N.
+// The 2l inverse transforms run one at a time (their key row is prefetched into registers
+// under the transform); the two forward transforms run together, in place on the Fourier
+// accumulator, sharing every twiddle read.
+template <typename T, int LOGN>
+TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
                            const Gadget &gd, int t) {
     using G = Geom<LOGN>;
     using U = typename Torus<T>::U;
@@ -358,13 +399,17 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
     for (int q = 0; q < 2; q++) {
         const T *p = w.acc + q * N;
         U lo[PPL], hi[PPL];  // coefficients j and j+N/2 of the (rotated) polynomial, offset added
+        if (rotate) {
 #pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            const int j = G::jA(t, m);
-            if (ROTATE) {
+            for (int m = 0; m < PPL; m++) {
+                const int j = G::jA(t, m);
                 lo[m] = rot_minus_one<T, LOGN>(p, j, a) + offset;
                 hi[m] = rot_minus_one<T, LOGN>(p, j + NC, a) + offset;
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                const int j = G::jA(t, m);
                 lo[m] = (U)p[j] + offset;
                 hi[m] = (U)p[j + NC] + offset;
             }
@@ -378,33 +423,28 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
 #pragma unroll
                 for (int m = 0; m < PPL; m++) bk[qq][m] = bkrow[((row * 2 + qq) * PPL + m) * 64 + t];
             const int decal = Torus<T>::BITS - (d + 1) * gd.Bgbit;
-            double xr[PPL], xi[PPL];
+            double xr[1][PPL], xi[1][PPL];
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
-                xr[m] = (double)((int32_t)((lo[m] >> decal) & mask) - halfBg);
-                xi[m] = (double)((int32_t)((hi[m] >> decal) & mask) - halfBg);
+                xr[0][m] = (double)((int32_t)((lo[m] >> decal) & mask) - halfBg);
+                xi[0][m] = (double)((int32_t)((hi[m] >> decal) & mask) - halfBg);
             }
-            WaveFFT<LOGN>::ifft(xr, xi, w.tw, w.xch, t);
-            mac_row<PPL>(fr, fi, xr, xi, bk);
+            WaveFFT<LOGN>::template ifft<1>(xr, xi, w.tw, w.xch, t);
+            mac_row<PPL>(fr, fi, xr[0], xi[0], bk);
         }
     }
-    // back to coefficients, round, accumulate into acc (tLweFromFFTConvert + tLweAddTo)
-#pragma unroll 1
-    for (int q = 0; q < 2; q++) {
-        double xr[PPL], xi[PPL];
+    // back to coefficients (both polynomials together), round, accumulate into acc
+    // (tLweFromFFTConvert + tLweAddTo)
+    WaveFFT<LOGN>::template fft<2>(fr, fi, w.tw, w.xch, t);
 #pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            xr[m] = fr[q][m];
-            xi[m] = fi[q][m];
-        }
-        WaveFFT<LOGN>::fft(xr, xi, w.tw, w.xch, t);
+    for (int q = 0; q < 2; q++) {
         T *p = w.acc + q * N;
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
             const int j = G::jA(t, m);
-            const U r0 = (U)Torus<T>::from_double(xr[m]);
-            const U r1 = (U)Torus<T>::from_double(xi[m]);
-            if (ROTATE) {
+            const U r0 = (U)Torus<T>::from_double(fr[q][m]);
+            const U r1 = (U)Torus<T>::from_double(fi[q][m]);
+            if (rotate) {
                 p[j] = (T)((U)p[j] + r0);
                 p[j + NC] = (T)((U)p[j + NC] + r1);
             } else {
@@ -525,15 +565,15 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
 #pragma unroll 1
     for (int i = 0; i < A.n_steps; i++) {
         const double2 *bkrow = A.bk + (size_t)i * A.bk_step_stride;
-        if (A.flags & BR_NO_ROTATE) {
-            cmux_step<T, LOGN, false>(w, bkrow, 0, A.gd, t);
-        } else {
-            int a = rot[i];
+        int a = 0;
+        const bool rotate = !(A.flags & BR_NO_ROTATE);
+        if (rotate) {
+            a = rot[i];
             if (A.flags & BR_MODSWITCH) a = modswitch_2N<LOGN>(a);
             a = TFHE_UNIFORM(a);
             if (a == 0) continue;  // :348-350
-            cmux_step<T, LOGN, true>(w, bkrow, a, A.gd, t);
         }
+        cmux_step<T, LOGN>(w, bkrow, a, rotate, A.gd, t);
     }
 
     // ---- output
@@ -578,18 +618,18 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     if (b >= batch) return;
     double *xch = reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH;
     const TIN *p = in + (size_t)b * N;
-    double xr[PPL], xi[PPL];
+    double xr[1][PPL], xi[1][PPL];
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
-        xr[m] = (double)p[G::jA(t, m)];
-        xi[m] = (double)p[G::jA(t, m) + NC];
+        xr[0][m] = (double)p[G::jA(t, m)];
+        xi[0][m] = (double)p[G::jA(t, m) + NC];
     }
-    WaveFFT<LOGN>::ifft(xr, xi, tw, xch, t);
+    WaveFFT<LOGN>::template ifft<1>(xr, xi, tw, xch, t);
     double *o = out + (size_t)b * N;
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
-        o[G::jC(t, m)] = xr[m];
-        o[G::jC(t, m) + NC] = xi[m];
+        o[G::jC(t, m)] = xr[0][m];
+        o[G::jC(t, m) + NC] = xi[0][m];
     }
 }
 
@@ -610,18 +650,18 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     double *xch = reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH;
     const double *p = in + (size_t)b * N;
     const double scale = 2.0 / (double)N;  // fft_processor_spqlios.cpp:78
-    double xr[PPL], xi[PPL];
+    double xr[1][PPL], xi[1][PPL];
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
-        xr[m] = p[G::jC(t, m)] * scale;
-        xi[m] = p[G::jC(t, m) + NC] * scale;
+        xr[0][m] = p[G::jC(t, m)] * scale;
+        xi[0][m] = p[G::jC(t, m) + NC] * scale;
     }
-    WaveFFT<LOGN>::fft(xr, xi, tw, xch, t);
+    WaveFFT<LOGN>::template fft<1>(xr, xi, tw, xch, t);
     TOUT *o = out + (size_t)b * N;
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
-        o[G::jA(t, m)] = Torus<TOUT>::from_double(xr[m]);
-        o[G::jA(t, m) + NC] = Torus<TOUT>::from_double(xi[m]);
+        o[G::jA(t, m)] = Torus<TOUT>::from_double(xr[0][m]);
+        o[G::jA(t, m) + NC] = Torus<TOUT>::from_double(xi[0][m]);
     }
 }
 

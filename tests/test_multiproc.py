@@ -6,14 +6,12 @@ import os
 import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _worker(rank, world, port, emu_lib, q):
+    import torch.distributed as dist
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -37,6 +35,7 @@ def _worker(rank, world, port, emu_lib, q):
 
 
 def test_two_rank_sharding(emu_lib):
+    import torch.multiprocessing as mp  # imported lazily: collecting -m gpu tests must stay light
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
