@@ -27,8 +27,13 @@
     } while (0)
 
 #define TFHE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// value of `v` held by lane `lane` (wave-uniform lane index) -> scalar register
+#define TFHE_READLANE(v, lane) __builtin_amdgcn_readlane((v), (lane))
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
+// same launch; the name tells the tests/emu build the kernel never synchronises work-items
+#define TFHE_LAUNCH_FLAT(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #endif
 
 #include <stdint.h>

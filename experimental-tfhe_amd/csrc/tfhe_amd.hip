@@ -34,12 +34,14 @@ struct tfhe_amd_ctx {
     double2 *tw_d;                            // [2*NC]
     Gadget gd;
     const tfhe_amd_gsw *bk;
-    int32_t *ks_d;
+    int32_t *ks_d;   // reference layout [N][t][base][n_out+1]
+    int32_t *ksd_d;  // tiled-kernel layout [N][t][base-1][rowp] (null: shape not covered, use the gather kernel)
     // growable scratch
     void *ws_lwe;
     size_t ws_lwe_bytes;
     void *ws_acc;
     size_t ws_acc_bytes;
+    bool ks_force_gather;  // test hook: use the per-sample gather kernel even when the tiled one applies
 };
 
 namespace {
@@ -212,11 +214,43 @@ int pack_rows(tfhe_amd_ctx *c, double2 *dst_d, const double *src_d, long long ro
     const long long total = rows * (c->p.N / 2);
     const int blocks = (int)((total + 255) / 256);
     if (c->logn == 10)
-        TFHE_LAUNCH((k_pack_gsw<10>), dim3(blocks), dim3(256), 0, c->stream, dst_d, src_d, rows);
+        TFHE_LAUNCH_FLAT((k_pack_gsw<10>), dim3(blocks), dim3(256), c->stream, dst_d, src_d, rows);
     else
-        TFHE_LAUNCH((k_pack_gsw<11>), dim3(blocks), dim3(256), 0, c->stream, dst_d, src_d, rows);
+        TFHE_LAUNCH_FLAT((k_pack_gsw<11>), dim3(blocks), dim3(256), c->stream, dst_d, src_d, rows);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
+}
+
+// ---- batch-tiled key switch dispatch (k_keyswitch_tiled): shapes with an instantiation
+constexpr int KS_SPLIT = 8;
+int ks_nch(int n_out) { return (n_out + 1 + 127) / 128; }
+bool ks_tiled_supported(int n_out, int basebit) {
+    const int nch = ks_nch(n_out);
+    return (nch == 1 || nch == 4 || nch == 5) && basebit >= 1 && basebit <= 3;
+}
+template <int TB, int NCH, int BB>
+int launch_ks_tiled_t(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
+    using Lds = KsTiledLds<TB, NCH, BB, KS_SPLIT>;
+    const int tiles = (batch + TB - 1) / TB;
+    TFHE_LAUNCH((k_keyswitch_tiled<TB, NCH, BB, KS_SPLIT>), dim3(tiles), dim3(KS_SPLIT * 64), Lds::total, c->stream,
+                out_d, in_d, (const int32_t *)c->ksd_d, c->p.N, c->p.ks_n_out, c->p.ks_t, batch);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+template <int NCH>
+int launch_ks_tiled_n(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
+    switch (c->p.ks_basebit) {
+        case 1: return launch_ks_tiled_t<16, NCH, 1>(c, out_d, in_d, batch);
+        case 2: return launch_ks_tiled_t<16, NCH, 2>(c, out_d, in_d, batch);
+        default: return launch_ks_tiled_t<8, NCH, 3>(c, out_d, in_d, batch);
+    }
+}
+int launch_ks_tiled(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
+    switch (ks_nch(c->p.ks_n_out)) {
+        case 1: return launch_ks_tiled_n<1>(c, out_d, in_d, batch);
+        case 4: return launch_ks_tiled_n<4>(c, out_d, in_d, batch);
+        default: return launch_ks_tiled_n<5>(c, out_d, in_d, batch);
+    }
 }
 
 // common part of every blind-rotation-shaped call
@@ -260,6 +294,8 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->tw_d = nullptr;
     c->bk = nullptr;
     c->ks_d = nullptr;
+    c->ksd_d = nullptr;
+    c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") != nullptr;
     c->ws_lwe = c->ws_acc = nullptr;
     c->ws_lwe_bytes = c->ws_acc_bytes = 0;
     if (hipSetDevice(device) != hipSuccess) {
@@ -305,6 +341,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->tw_d) (void)hipFree(c->tw_d);
     if (c->ks_d) (void)hipFree(c->ks_d);
+    if (c->ksd_d) (void)hipFree(c->ksd_d);
     if (c->ws_lwe) (void)hipFree(c->ws_lwe);
     if (c->ws_acc) (void)hipFree(c->ws_acc);
 #ifndef TFHE_EMU
@@ -490,6 +527,16 @@ int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *c, const int32_t *ks) {
     const size_t bytes = (size_t)c->p.N * c->p.ks_t * ((size_t)1 << c->p.ks_basebit) * (c->p.ks_n_out + 1) * 4;
     if (!c->ks_d) HIPCHECK(c, hipMalloc((void **)&c->ks_d, bytes));
     HIPCHECK(c, hipMemcpyAsync(c->ks_d, ks, bytes, hipMemcpyHostToDevice, c->stream));
+    if (ks_tiled_supported(c->p.ks_n_out, c->p.ks_basebit)) {
+        // re-layout for the batch-tiled kernel: drop the digit-0 rows, pad rows to 128-int chunks
+        const int base = 1 << c->p.ks_basebit, rowp = ks_nch(c->p.ks_n_out) * 128;
+        const long long rows_out = (long long)c->p.N * c->p.ks_t * (base - 1);
+        if (!c->ksd_d) HIPCHECK(c, hipMalloc((void **)&c->ksd_d, (size_t)rows_out * rowp * 4));
+        const long long total = rows_out * rowp;
+        TFHE_LAUNCH_FLAT(k_pack_ks, dim3((unsigned)((total + 255) / 256)), dim3(256), c->stream, c->ksd_d,
+                    (const int32_t *)c->ks_d, rows_out, base, c->p.ks_n_out + 1, rowp);
+        HIPCHECK(c, hipGetLastError());
+    }
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     return TFHE_AMD_OK;
 }
@@ -520,7 +567,7 @@ int tfhe_amd_lagrange_addmul(tfhe_amd_ctx *c, double *res_d, const double *a_d, 
     if (batch == 0) return TFHE_AMD_OK;
     const int Ns2 = c->p.N / 2;
     const long long total = (long long)batch * Ns2;
-    TFHE_LAUNCH(k_lagrange_addmul, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, res_d, a_d, b_d, Ns2,
+    TFHE_LAUNCH_FLAT(k_lagrange_addmul, dim3((unsigned)((total + 255) / 256)), dim3(256), c->stream, res_d, a_d, b_d, Ns2,
                 (long long)(b_shared ? 0 : c->p.N), total);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
@@ -615,7 +662,8 @@ int tfhe_amd_keyswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
     if (!c->ks_d) return fail(c, TFHE_AMD_ERR_STATE, "no key-switch key");
     if (batch == 0) return TFHE_AMD_OK;
-    TFHE_LAUNCH(k_keyswitch32, dim3(batch), dim3(256), 0, c->stream, out_d, in_d, (const int32_t *)c->ks_d, c->p.N,
+    if (c->ksd_d && !c->ks_force_gather) return launch_ks_tiled(c, out_d, in_d, batch);
+    TFHE_LAUNCH_FLAT(k_keyswitch32, dim3(batch), dim3(256), c->stream, out_d, in_d, (const int32_t *)c->ks_d, c->p.N,
                 c->p.ks_n_out, c->p.ks_t, c->p.ks_basebit, batch);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
@@ -713,9 +761,9 @@ int tfhe_amd_modswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *x_d, int 
     const long long total = (long long)batch * (c->p.n + 1);
     const unsigned blocks = (unsigned)((total + 255) / 256);
     if (c->logn == 10)
-        TFHE_LAUNCH((k_modswitch<10>), dim3(blocks), dim3(256), 0, c->stream, out_d, x_d, total);
+        TFHE_LAUNCH_FLAT((k_modswitch<10>), dim3(blocks), dim3(256), c->stream, out_d, x_d, total);
     else
-        TFHE_LAUNCH((k_modswitch<11>), dim3(blocks), dim3(256), 0, c->stream, out_d, x_d, total);
+        TFHE_LAUNCH_FLAT((k_modswitch<11>), dim3(blocks), dim3(256), c->stream, out_d, x_d, total);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }

@@ -732,4 +732,119 @@ TFHE_GLOBAL void k_keyswitch32(int32_t *__restrict__ out, const int32_t *__restr
     }
 }
 
+// Batch-tiled key switch.  The gather above reads one 2.5 KB key row per non-zero digit per
+// sample (15.5 MB per gate bootstrap).  Here a workgroup owns a tile of TB samples and walks
+// the (i, j) digit positions once for all of them: the base-1 candidate rows of a position
+// are loaded once (coalesced 8-byte loads, rows padded to NCH*128 ints at upload), and each
+// sample of the tile subtracts the row its (wave-uniform, scalar) digit selects.  Key bytes
+// per sample drop by TB*(base-1)/base (12x for TB=16, base 4); the SPLIT waves of the
+// workgroup take disjoint i-ranges and are summed through LDS at the end.
+//   ksd: device layout [n_in][t][base-1][NCH*128] (digit 0 rows dropped, rows zero-padded)
+template <int TB, int NCH, int BB, int SPLIT>
+struct KsTiledLds {
+    static constexpr int ROWP = NCH * 128;
+    static constexpr size_t total = sizeof(int32_t) * (size_t)TB * ROWP;
+};
+
+template <int TB, int NCH, int BB, int SPLIT>
+TFHE_GLOBAL void __launch_bounds__(SPLIT * 64)
+    k_keyswitch_tiled(int32_t *__restrict__ out, const int32_t *__restrict__ in, const int32_t *__restrict__ ksd,
+                      int n_in, int n_out, int t, int batch) {
+    constexpr int ROWP = NCH * 128, NR = (1 << BB) - 1;
+    constexpr uint32_t mask = (1u << BB) - 1;
+    TFHE_DYN_LDS(smem);
+    uint32_t *red = reinterpret_cast<uint32_t *>(smem);  // [TB][ROWP] partial sums
+    const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int tile0 = blockIdx.x * TB;
+    const uint32_t prec_offset = 1u << (32 - (1 + BB * t));
+    // the b-term (lweNoiselessTrivial(result, sample->b)) seeds the reduction buffer
+    for (int e = threadIdx.x; e < TB * ROWP; e += SPLIT * 64) {
+        const int b = e / ROWP, h = e - b * ROWP;
+        uint32_t v = 0;
+        if (h == n_out && tile0 + b < batch) v = (uint32_t)in[(size_t)(tile0 + b) * (n_in + 1) + n_in];
+        red[e] = v;
+    }
+    uint32_t acc[TB][NCH][2];
+#pragma unroll
+    for (int b = 0; b < TB; b++)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) acc[b][c][0] = acc[b][c][1] = 0u;
+
+    // my slice of the input dimension, in chunks of 64 (one a-value per lane per sample)
+    const int per_wave = ((n_in + SPLIT * 64 - 1) / (SPLIT * 64)) * 64;
+    const int i_begin = wave * per_wave;
+    const int i_end = (i_begin + per_wave < n_in) ? i_begin + per_wave : n_in;
+#pragma unroll 1
+    for (int i0 = i_begin; i0 < i_end; i0 += 64) {
+        int avec[TB];  // lane L: a[i0+L] + prec_offset of sample b (0 => all digits 0)
+#pragma unroll
+        for (int b = 0; b < TB; b++) {
+            const bool ok = (tile0 + b < batch) && (i0 + lane < n_in);
+            avec[b] = ok ? (int)((uint32_t)in[(size_t)(tile0 + b) * (n_in + 1) + i0 + lane] + prec_offset) : 0;
+        }
+        const int cnt = (i_end - i0 < 64) ? (i_end - i0) : 64;
+#pragma unroll 1
+        for (int ii = 0; ii < cnt; ii++) {
+            uint32_t ab[TB];
+#pragma unroll
+            for (int b = 0; b < TB; b++) ab[b] = (uint32_t)TFHE_READLANE(avec[b], ii);
+#pragma unroll 1
+            for (int j = 0; j < t; j++) {
+                const int sh = 32 - (j + 1) * BB;
+                const int32_t *rows = ksd + ((size_t)(i0 + ii) * t + j) * NR * ROWP;
+                uint32_t r[NR][NCH][2];
+#pragma unroll
+                for (int d = 0; d < NR; d++)
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) {
+                        const int32_t *src = rows + d * ROWP + c * 128 + 2 * lane;
+                        r[d][c][0] = (uint32_t)src[0];
+                        r[d][c][1] = (uint32_t)src[1];
+                    }
+#pragma unroll
+                for (int b = 0; b < TB; b++) {
+                    const uint32_t dig = (ab[b] >> sh) & mask;  // wave-uniform
+#pragma unroll
+                    for (int d = 0; d < NR; d++) {
+                        if (dig == (uint32_t)(d + 1)) {
+#pragma unroll
+                            for (int c = 0; c < NCH; c++) {
+                                acc[b][c][0] -= r[d][c][0];
+                                acc[b][c][1] -= r[d][c][1];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();  // red[] seeded
+#pragma unroll
+    for (int b = 0; b < TB; b++)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            atomicAdd(&red[b * ROWP + c * 128 + 2 * lane], acc[b][c][0]);
+            atomicAdd(&red[b * ROWP + c * 128 + 2 * lane + 1], acc[b][c][1]);
+        }
+    __syncthreads();
+    const int row = n_out + 1;
+    for (int e = threadIdx.x; e < TB * row; e += SPLIT * 64) {
+        const int b = e / row, h = e - b * row;
+        if (tile0 + b < batch) out[(size_t)(tile0 + b) * row + h] = (int32_t)red[b * ROWP + h];
+    }
+}
+
+// host/upload helper: [n_in][t][base][n_out+1] -> [n_in][t][base-1][rowp] (zero padded)
+TFHE_GLOBAL void k_pack_ks(int32_t *__restrict__ dst, const int32_t *__restrict__ src, long long rows_out, int base,
+                           int row, int rowp) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows_out * rowp) return;
+    const long long ro = gid / rowp;
+    const int h = (int)(gid - ro * rowp);
+    const long long ij = ro / (base - 1);
+    const int d = (int)(ro - ij * (base - 1)) + 1;
+    dst[gid] = (h < row) ? src[(ij * base + d) * row + h] : 0;
+}
+
 }  // namespace tfhe

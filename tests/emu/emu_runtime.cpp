@@ -29,6 +29,7 @@ struct Fiber {
     unsigned tid = 0;
 };
 struct Block {
+    std::vector<int> lane_xchg;  // per work-item slot for readlane
     std::vector<Fiber> fibers;
     Rendezvous all;
     std::vector<Rendezvous> waves;
@@ -73,6 +74,7 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
     b.body = &body;
     const unsigned nt = block.x;
     b.fibers.resize(nt);
+    b.lane_xchg.resize(nt);
     b.all.expected = (int)nt;
     b.waves.resize((nt + 63) / 64);
     for (unsigned w = 0; w < b.waves.size(); w++) b.waves[w].expected = (int)std::min(64u, nt - 64 * w);
@@ -115,6 +117,14 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
 void syncthreads() { arrive(t_blk->all); }
 void wave_fence() { arrive(t_blk->waves[t_threadIdx.x / 64]); }
 unsigned char *dyn_smem() { return t_blk->smem; }
+int readlane(int v, int lane) {
+    const unsigned tid = t_threadIdx.x;
+    t_blk->lane_xchg[tid] = v;
+    wave_fence();
+    const int r = t_blk->lane_xchg[(tid & ~63u) + (unsigned)lane];
+    wave_fence();
+    return r;
+}
 
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes) {
     const unsigned nb = grid.x;
@@ -126,6 +136,35 @@ void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t sme
             const unsigned bx = next.fetch_add(1);
             if (bx >= nb) break;
             run_block(body, grid, block, bx, smem_bytes);
+        }
+    };
+    if (nthreads <= 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned i = 0; i < nthreads; i++) pool.emplace_back(worker);
+        for (auto &t : pool) t.join();
+    }
+}
+
+void launch_flat(const std::function<void()> &body, Dim3 grid, Dim3 block) {
+    const unsigned nb = grid.x;
+    unsigned nthreads = std::min<unsigned>(std::max(1u, nb / 64), std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("TFHE_EMU_THREADS")) nthreads = std::max(1, atoi(e));
+    std::atomic<unsigned> next{0};
+    auto worker = [&]() {
+        t_blockDim = block;
+        t_gridDim = grid;
+        for (;;) {
+            const unsigned b0 = next.fetch_add(64);
+            if (b0 >= nb) break;
+            for (unsigned bx = b0; bx < std::min(nb, b0 + 64); bx++) {
+                t_blockIdx = Dim3(bx);
+                for (unsigned t = 0; t < block.x; t++) {
+                    t_threadIdx = Dim3(t);
+                    body();
+                }
+            }
         }
     };
     if (nthreads <= 1) {

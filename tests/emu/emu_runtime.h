@@ -22,9 +22,12 @@ struct Dim3 {
 };
 extern thread_local Dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes);
+// kernels that never synchronise (no barrier, no LDS hand-off): work-items run as a plain loop
+void launch_flat(const std::function<void()> &body, Dim3 grid, Dim3 block);
 void syncthreads();
 void wave_fence();
 unsigned char *dyn_smem();
+int readlane(int v, int lane);
 }  // namespace emu
 
 using dim3 = emu::Dim3;
@@ -40,8 +43,18 @@ using dim3 = emu::Dim3;
 #define TFHE_HOST_DEVICE inline
 #define TFHE_WAVE_FENCE() emu::wave_fence()
 #define TFHE_UNIFORM(x) (x)
+#define TFHE_READLANE(v, lane) emu::readlane((v), (lane))
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu::launch([=]() { kernel(__VA_ARGS__); }, grid, block, smem)
+#define TFHE_LAUNCH_FLAT(kernel, grid, block, stream, ...) \
+    emu::launch_flat([=]() { kernel(__VA_ARGS__); }, grid, block)
+
+// a workgroup runs on one OS thread (fibers), so a plain read-modify-write is atomic enough
+static inline unsigned atomicAdd(unsigned *p, unsigned v) {
+    const unsigned o = *p;
+    *p = o + v;
+    return o;
+}
 
 struct double2 {
     double x, y;

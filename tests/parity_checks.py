@@ -188,3 +188,27 @@ def check_torus64_path(lib_path, N, n, l, Bgbit, B, seed=31):
         assert np.array_equal(e.cb_bootstrap_woks(mu, abar), want), "circuitBootstrapWoKS"
     finally:
         e.close()
+
+
+# --------------------------------------------------------------- key switch only
+def check_keyswitch_shapes(lib_path, N, n_out, ks_t, ks_bb, B, seed=51):
+    """lweKeySwitch / preKeySwitch on a synthetic (uniformly random) key: exercises the batch-tiled
+    kernel's row padding / tiling for the real output sizes, and the gather kernel beside it."""
+    import os
+    rs = np.random.RandomState(seed)
+    ks = rs.randint(-2 ** 31, 2 ** 31, size=(N, ks_t, 1 << ks_bb, n_out + 1)).astype(np.int32)
+    x = rs.randint(-2 ** 31, 2 ** 31, size=(B, N + 1)).astype(np.int32)
+    x[0, :4] = [0, -1, 1 << 31 - ks_t * ks_bb, -(1 << 31 - ks_t * ks_bb)]  # rounding-boundary digits
+    want = np.stack([O.keyswitch32(ks, x[b], N, n_out, ks_t, ks_bb) for b in range(B)])
+    for force_gather in (False, True):
+        if force_gather:
+            os.environ["TFHE_AMD_KS_GATHER"] = "1"
+        try:
+            e = T.Engine(torus_bits=32, n=n_out, N=N, l=2, Bgbit=10, ks_t=ks_t, ks_basebit=ks_bb, lib_path=lib_path)
+            try:
+                e.load_keyswitch_key(ks)
+                assert np.array_equal(e.keyswitch(x), want), f"key switch (gather={force_gather})"
+            finally:
+                e.close()
+        finally:
+            os.environ.pop("TFHE_AMD_KS_GATHER", None)

@@ -25,6 +25,12 @@ def test_gate_path_emu_n2048(emu_lib):
     P.check_gate_path(emu_lib, N=2048, n=3, l=2, Bgbit=9, ks_t=4, ks_bb=3, B=5)
 
 
+@pytest.mark.parametrize("n_out,t,bb,B", [(630, 8, 2, 17), (500, 6, 2, 3), (630, 16, 1, 2)])
+def test_keyswitch_real_shapes_emu(emu_lib, n_out, t, bb, B):
+    """gate key switch 8x2 and 16x1 (n=630) and the PoC's preKeySwitch 6x2 (n0=500): tiled + gather kernels"""
+    P.check_keyswitch_shapes(emu_lib, 1024, n_out, t, bb, B)
+
+
 @pytest.mark.parametrize("N,l,Bgbit,B", [(2048, 4, 9, 4), (1024, 3, 10, 5)])
 def test_torus64_path_emu(emu_lib, N, l, Bgbit, B):
     P.check_torus64_path(emu_lib, N=N, n=3, l=l, Bgbit=Bgbit, B=B)

@@ -71,6 +71,13 @@ def test_keyswitch_second_config(gpu_lib):
     P.check_gate_path(gpu_lib, N=1024, n=12, l=2, Bgbit=10, ks_t=16, ks_bb=1, B=5, seed=8, check_export=False)
 
 
+@pytest.mark.parametrize("n_out,t,bb,B", [(630, 8, 2, 67), (500, 6, 2, 33), (630, 16, 1, 16), (700, 4, 3, 5)])
+def test_keyswitch_real_shapes(gpu_lib, n_out, t, bb, B):
+    """lweKeySwitch at the gate sizes, preKeySwitch at the PoC sizes (both through the batch-tiled
+    and the gather kernel) and one shape only the gather kernel covers"""
+    P.check_keyswitch_shapes(gpu_lib, 1024, n_out, t, bb, B)
+
+
 @pytest.mark.parametrize("N,n,l,Bgbit,B", [(2048, 6, 4, 9, 7), (1024, 5, 3, 10, 9)])
 def test_torus64_path(gpu_lib, N, n, l, Bgbit, B):
     P.check_torus64_path(gpu_lib, N=N, n=n, l=l, Bgbit=Bgbit, B=B)
