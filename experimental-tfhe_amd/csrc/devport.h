@@ -27,6 +27,9 @@
     } while (0)
 
 #define TFHE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// placed at the top of a wave-uniform `if` body: keeps it a real scalar branch (hipcc otherwise
+// if-converts short bodies into per-lane selects, which costs VALU work on the skipped paths)
+#define TFHE_KEEP_BRANCH() asm volatile("" ::: "memory")
 // value of `v` held by lane `lane` (wave-uniform lane index) -> scalar register
 #define TFHE_READLANE(v, lane) __builtin_amdgcn_readlane((v), (lane))
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \

@@ -239,10 +239,12 @@ int launch_ks_tiled_t(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int 
 }
 template <int NCH>
 int launch_ks_tiled_n(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
+    // samples per tile: as many as keep accumulators + candidate rows in 256 VGPRs without spilling
+    constexpr int TB12 = 16, TB3 = 8;
     switch (c->p.ks_basebit) {
-        case 1: return launch_ks_tiled_t<16, NCH, 1>(c, out_d, in_d, batch);
-        case 2: return launch_ks_tiled_t<16, NCH, 2>(c, out_d, in_d, batch);
-        default: return launch_ks_tiled_t<8, NCH, 3>(c, out_d, in_d, batch);
+        case 1: return launch_ks_tiled_t<TB12, NCH, 1>(c, out_d, in_d, batch);
+        case 2: return launch_ks_tiled_t<TB12, NCH, 2>(c, out_d, in_d, batch);
+        default: return launch_ks_tiled_t<TB3, NCH, 3>(c, out_d, in_d, batch);
     }
 }
 int launch_ks_tiled(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {

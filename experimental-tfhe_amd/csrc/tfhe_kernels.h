@@ -804,10 +804,12 @@ TFHE_GLOBAL void __launch_bounds__(SPLIT * 64)
                     }
 #pragma unroll
                 for (int b = 0; b < TB; b++) {
-                    const uint32_t dig = (ab[b] >> sh) & mask;  // wave-uniform
+                    const uint32_t dig = (ab[b] >> sh) & mask;  // wave-uniform (scalar registers)
+                    if (dig == 0) continue;
 #pragma unroll
                     for (int d = 0; d < NR; d++) {
                         if (dig == (uint32_t)(d + 1)) {
+                            TFHE_KEEP_BRANCH();
 #pragma unroll
                             for (int c = 0; c < NCH; c++) {
                                 acc[b][c][0] -= r[d][c][0];

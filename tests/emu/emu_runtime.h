@@ -43,6 +43,7 @@ using dim3 = emu::Dim3;
 #define TFHE_HOST_DEVICE inline
 #define TFHE_WAVE_FENCE() emu::wave_fence()
 #define TFHE_UNIFORM(x) (x)
+#define TFHE_KEEP_BRANCH() ((void)0)
 #define TFHE_READLANE(v, lane) emu::readlane((v), (lane))
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu::launch([=]() { kernel(__VA_ARGS__); }, grid, block, smem)
