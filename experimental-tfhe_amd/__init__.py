@@ -31,6 +31,10 @@ ABI_SYMBOLS = [
     "tfhe_amd_blind_rotate", "tfhe_amd_blind_rotate_extract", "tfhe_amd_bootstrap_woks",
     "tfhe_amd_keyswitch", "tfhe_amd_bootstrap", "tfhe_amd_bootstrap_streamed", "tfhe_amd_bootstrap_host",
     "tfhe_amd_cb_bootstrap_woks", "tfhe_amd_modswitch",
+    "tfhe_amd_cb_create", "tfhe_amd_cb_destroy", "tfhe_amd_cb_last_error", "tfhe_amd_cb_set_stream",
+    "tfhe_amd_cb_sync", "tfhe_amd_cb_ctx_lvl10", "tfhe_amd_cb_ctx_lvl2", "tfhe_amd_cb_load_preks",
+    "tfhe_amd_cb_load_bk_torus", "tfhe_amd_cb_load_bk_fft", "tfhe_amd_cb_load_privks_plane",
+    "tfhe_amd_privks", "tfhe_amd_circuit_bootstrap",
     "tfhe_amd_keygen_binary", "tfhe_amd_lwe_encrypt32", "tfhe_amd_lwe_phase32",
     "tfhe_amd_keygen_bk_torus32", "tfhe_amd_keygen_bk_torus64", "tfhe_amd_keygen_ks32",
 ]
@@ -41,6 +45,11 @@ class Params(C.Structure):
     _fields_ = [("torus_bits", C.c_int32), ("n", C.c_int32), ("N", C.c_int32), ("k", C.c_int32),
                 ("l", C.c_int32), ("Bgbit", C.c_int32), ("ks_t", C.c_int32), ("ks_basebit", C.c_int32),
                 ("ks_n_out", C.c_int32)]
+
+
+class CbParams(C.Structure):
+    """mirror of tfhe_amd_cb_params (include/tfhe_amd.h)"""
+    _fields_ = [(k, C.c_int32) for k in ("n0", "N1", "N2", "l1", "Bgbit1", "l2", "Bgbit2", "t10", "bb10", "t21", "bb21")]
 
 
 class TfheAmdError(RuntimeError):
@@ -97,6 +106,23 @@ def load_library(path=None):
     lib.tfhe_amd_bootstrap_host.argtypes = [vp, i32p, C.c_int32, i32p, C.c_int]
     lib.tfhe_amd_cb_bootstrap_woks.argtypes = [vp, i64p, C.c_int64, i32p, C.c_int]
     lib.tfhe_amd_modswitch.argtypes = [vp, i32p, i32p, C.c_int]
+    lib.tfhe_amd_cb_create.argtypes = [C.POINTER(CbParams), C.c_int, C.POINTER(vp)]
+    lib.tfhe_amd_cb_destroy.argtypes = [vp]
+    lib.tfhe_amd_cb_destroy.restype = None
+    lib.tfhe_amd_cb_last_error.argtypes = [vp]
+    lib.tfhe_amd_cb_last_error.restype = C.c_char_p
+    lib.tfhe_amd_cb_set_stream.argtypes = [vp, vp]
+    lib.tfhe_amd_cb_sync.argtypes = [vp]
+    lib.tfhe_amd_cb_ctx_lvl10.argtypes = [vp]
+    lib.tfhe_amd_cb_ctx_lvl10.restype = vp
+    lib.tfhe_amd_cb_ctx_lvl2.argtypes = [vp]
+    lib.tfhe_amd_cb_ctx_lvl2.restype = vp
+    lib.tfhe_amd_cb_load_preks.argtypes = [vp, i32p]
+    lib.tfhe_amd_cb_load_bk_torus.argtypes = [vp, i64p]
+    lib.tfhe_amd_cb_load_bk_fft.argtypes = [vp, f64p]
+    lib.tfhe_amd_cb_load_privks_plane.argtypes = [vp, C.c_int, i32p]
+    lib.tfhe_amd_privks.argtypes = [vp, i32p, C.c_int, i64p, C.c_int]
+    lib.tfhe_amd_circuit_bootstrap.argtypes = [vp, i32p, i32p, C.c_int]
     lib.tfhe_amd_keygen_binary.argtypes = [i32p, C.c_int, C.c_uint64, C.c_uint64]
     lib.tfhe_amd_lwe_encrypt32.argtypes = [i32p, C.c_int32, C.c_double, i32p, C.c_int, C.c_uint64, C.c_uint64]
     lib.tfhe_amd_lwe_phase32.argtypes = [i32p, i32p, C.c_int]
@@ -334,6 +360,84 @@ class Engine:
     def modswitch(self, x):
         x = np.ascontiguousarray(x, np.int32).reshape(-1, self.params.n + 1)
         return self._roundtrip(self.lib.tfhe_amd_modswitch, x, np.int32, x.shape, x.shape[0])
+
+
+class CircuitBootstrap:
+    """tfhe_amd_cb: the three-level circuit bootstrap of the PoC (tfhe_CircuitBootstrapFFT)."""
+
+    def __init__(self, n0=500, N1=1024, N2=2048, l1=2, Bgbit1=8, l2=4, Bgbit2=9, t10=6, bb10=2, t21=10, bb21=3,
+                 device=0, lib_path=None):
+        self.lib = load_library(lib_path)
+        self.p = CbParams(n0, N1, N2, l1, Bgbit1, l2, Bgbit2, t10, bb10, t21, bb21)
+        self.cb = C.c_void_p()
+        rc = self.lib.tfhe_amd_cb_create(C.byref(self.p), device, C.byref(self.cb))
+        if rc != OK:
+            raise TfheAmdError(f"tfhe_amd_cb_create failed with status {rc}")
+        self.ctx = C.c_void_p(self.lib.tfhe_amd_cb_ctx_lvl2(self.cb))  # memory helpers go through lvl2
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise TfheAmdError(f"status {rc}: {self.lib.tfhe_amd_cb_last_error(self.cb).decode()}")
+
+    def close(self):
+        if self.cb:
+            self.lib.tfhe_amd_cb_destroy(self.cb)
+            self.cb = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_preks(self, preks):
+        a = np.ascontiguousarray(preks, np.int32)
+        self._chk(self.lib.tfhe_amd_cb_load_preks(self.cb, _np_ptr(a)))
+
+    def load_bk_fft(self, bk):
+        a = np.ascontiguousarray(bk, np.float64)
+        self._chk(self.lib.tfhe_amd_cb_load_bk_fft(self.cb, _np_ptr(a)))
+
+    def load_bk_torus(self, bk):
+        a = np.ascontiguousarray(bk, np.int64)
+        self._chk(self.lib.tfhe_amd_cb_load_bk_torus(self.cb, _np_ptr(a)))
+
+    def load_privks(self, privks):
+        a = np.ascontiguousarray(privks, np.int32)
+        a = a.reshape(2, -1)
+        for u in range(2):
+            self._chk(self.lib.tfhe_amd_cb_load_privks_plane(self.cb, u, _np_ptr(a[u])))
+
+    def _dev(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        self._chk(self.lib.tfhe_amd_malloc(self.ctx, C.byref(p), max(arr.nbytes, 1)))
+        self._chk(self.lib.tfhe_amd_memcpy_h2d(self.ctx, p, _np_ptr(arr), arr.nbytes))
+        return p
+
+    def _out(self, p, dtype, shape):
+        out = np.empty(shape, dtype)
+        self._chk(self.lib.tfhe_amd_memcpy_d2h(self.ctx, _np_ptr(out), p, out.nbytes))
+        self.lib.tfhe_amd_free(self.ctx, p)
+        return out
+
+    def privks(self, u, x):
+        x = np.ascontiguousarray(x, np.int64).reshape(-1, self.p.N2 + 1)
+        B = x.shape[0]
+        d_x = self._dev(x)
+        d_o = self._dev(np.zeros((B, 2, self.p.N1), np.int32))
+        self._chk(self.lib.tfhe_amd_privks(self.cb, d_o, u, d_x, B))
+        self.lib.tfhe_amd_free(self.ctx, d_x)
+        return self._out(d_o, np.int32, (B, 2, self.p.N1))
+
+    def circuit_bootstrap(self, x):
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, self.p.N1 + 1)
+        B = x.shape[0]
+        d_x = self._dev(x)
+        d_o = self._dev(np.zeros((B, 2, self.p.l1, 2, self.p.N1), np.int32))
+        self._chk(self.lib.tfhe_amd_circuit_bootstrap(self.cb, d_o, d_x, B))
+        self.lib.tfhe_amd_free(self.ctx, d_x)
+        return self._out(d_o, np.int32, (B, 2, self.p.l1, 2, self.p.N1))
 
 
 # ---- harness wrappers (host side of the ABI; usable without a GPU) --------------------

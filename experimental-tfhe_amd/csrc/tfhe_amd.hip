@@ -771,3 +771,180 @@ int tfhe_amd_modswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *x_d, int 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- circuit bootstrap
+struct tfhe_amd_cb {
+    tfhe_amd_cb_params p;
+    tfhe_amd_ctx *c10;  // Torus32, ring N1: preKeySwitch (n_in = N1 -> n_out = n0)
+    tfhe_amd_ctx *c2;   // Torus64, ring N2, n = n0: modswitch to 2*N2, blind rotation
+    tfhe_amd_gsw *bk;
+    int32_t *privks_d[2];
+    void *ws_pre, *ws_abar, *ws_boot;
+    size_t ws_pre_bytes, ws_abar_bytes, ws_boot_bytes;
+    std::string err;
+};
+
+namespace {
+int cb_fail(tfhe_amd_cb *cb, int code, const std::string &m) {
+    if (cb) cb->err = m;
+    return code;
+}
+int cb_pass(tfhe_amd_cb *cb, tfhe_amd_ctx *c, int rc) {
+    if (rc && cb) cb->err = c->err;
+    return rc;
+}
+template <int BB>
+int launch_privks_t(tfhe_amd_cb *cb, int32_t *out_d, long long out_stride, const int64_t *x_d, const int32_t *tab,
+                    int batch) {
+    constexpr int TB = (BB == 3) ? 8 : 16;
+    tfhe_amd_ctx *c = cb->c2;
+    const int n2 = cb->p.N2, row = 2 * cb->p.N1;
+    const int tiles = (batch + TB - 1) / TB;
+    // enough i-slices to fill the chip: ~4 workgroups per CU
+    int slices = (1024 + tiles - 1) / tiles;
+    if (slices < 1) slices = 1;
+    int i_per_block = ((n2 + 1 + slices - 1) / slices + 63) / 64 * 64;
+    slices = (n2 + 1 + i_per_block - 1) / i_per_block;
+    TFHE_LAUNCH((k_privks<TB, BB>), dim3(tiles, slices), dim3(256), 0, c->stream, out_d, out_stride, x_d, tab, n2,
+                cb->p.t21, row, batch, i_per_block);
+    if (hipGetLastError() != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "k_privks launch");
+    return TFHE_AMD_OK;
+}
+int launch_privks(tfhe_amd_cb *cb, int32_t *out_d, long long out_stride, int u, const int64_t *x_d, int batch) {
+    const int32_t *tab = cb->privks_d[u];
+    switch (cb->p.bb21) {
+        case 1: return launch_privks_t<1>(cb, out_d, out_stride, x_d, tab, batch);
+        case 2: return launch_privks_t<2>(cb, out_d, out_stride, x_d, tab, batch);
+        default: return launch_privks_t<3>(cb, out_d, out_stride, x_d, tab, batch);
+    }
+}
+}  // namespace
+
+extern "C" {
+
+int tfhe_amd_cb_create(const tfhe_amd_cb_params *p, int device, tfhe_amd_cb **out) {
+    if (!p || !out) return TFHE_AMD_ERR_PARAM;
+    *out = nullptr;
+    if (p->bb21 < 1 || p->bb21 > 3 || p->t21 < 1 || p->t21 * p->bb21 > 63 || p->l1 < 1 || p->l1 * p->Bgbit1 > 63)
+        return TFHE_AMD_ERR_PARAM;
+    if (p->N1 % 4 != 0) return TFHE_AMD_ERR_PARAM;
+    tfhe_amd_params p10 = {32, p->n0, p->N1, 1, p->l1, p->Bgbit1, p->t10, p->bb10, p->n0};
+    tfhe_amd_params p2 = {64, p->n0, p->N2, 1, p->l2, p->Bgbit2, 0, 0, 0};
+    tfhe_amd_cb *cb = new tfhe_amd_cb();
+    cb->p = *p;
+    cb->bk = nullptr;
+    cb->privks_d[0] = cb->privks_d[1] = nullptr;
+    cb->ws_pre = cb->ws_abar = cb->ws_boot = nullptr;
+    cb->ws_pre_bytes = cb->ws_abar_bytes = cb->ws_boot_bytes = 0;
+    cb->c10 = cb->c2 = nullptr;
+    int rc = tfhe_amd_ctx_create(&p10, device, &cb->c10);
+    if (!rc) rc = tfhe_amd_ctx_create(&p2, device, &cb->c2);
+    if (!rc) rc = tfhe_amd_set_stream(cb->c10, cb->c2->stream);  // one stream for the whole pipeline
+    if (rc) {
+        tfhe_amd_cb_destroy(cb);
+        return rc;
+    }
+    *out = cb;
+    return TFHE_AMD_OK;
+}
+
+void tfhe_amd_cb_destroy(tfhe_amd_cb *cb) {
+    if (!cb) return;
+    if (cb->c2) (void)hipStreamSynchronize(cb->c2->stream);
+    if (cb->bk) tfhe_amd_gsw_free(cb->bk);
+    for (int u = 0; u < 2; u++)
+        if (cb->privks_d[u]) (void)hipFree(cb->privks_d[u]);
+    if (cb->ws_pre) (void)hipFree(cb->ws_pre);
+    if (cb->ws_abar) (void)hipFree(cb->ws_abar);
+    if (cb->ws_boot) (void)hipFree(cb->ws_boot);
+    if (cb->c10) tfhe_amd_ctx_destroy(cb->c10);  // borrowed c2's stream: destroyed first, never owns it
+    if (cb->c2) tfhe_amd_ctx_destroy(cb->c2);
+    delete cb;
+}
+
+const char *tfhe_amd_cb_last_error(const tfhe_amd_cb *cb) { return cb ? cb->err.c_str() : "null handle"; }
+tfhe_amd_ctx *tfhe_amd_cb_ctx_lvl10(tfhe_amd_cb *cb) { return cb ? cb->c10 : nullptr; }
+tfhe_amd_ctx *tfhe_amd_cb_ctx_lvl2(tfhe_amd_cb *cb) { return cb ? cb->c2 : nullptr; }
+
+int tfhe_amd_cb_set_stream(tfhe_amd_cb *cb, void *s) {
+    if (!cb) return TFHE_AMD_ERR_PARAM;
+    int rc = cb_pass(cb, cb->c2, tfhe_amd_set_stream(cb->c2, s));
+    if (!rc) rc = cb_pass(cb, cb->c10, tfhe_amd_set_stream(cb->c10, cb->c2->stream));
+    return rc;
+}
+int tfhe_amd_cb_sync(tfhe_amd_cb *cb) {
+    if (!cb) return TFHE_AMD_ERR_PARAM;
+    return cb_pass(cb, cb->c2, tfhe_amd_sync(cb->c2));
+}
+
+int tfhe_amd_cb_load_preks(tfhe_amd_cb *cb, const int32_t *preks) {
+    if (!cb || !preks) return TFHE_AMD_ERR_PARAM;
+    return cb_pass(cb, cb->c10, tfhe_amd_load_keyswitch_key(cb->c10, preks));
+}
+static int cb_set_bk(tfhe_amd_cb *cb, tfhe_amd_gsw *g) {
+    if (cb->bk) tfhe_amd_gsw_free(cb->bk);
+    cb->bk = g;
+    return cb_pass(cb, cb->c2, tfhe_amd_set_bootstrap_key(cb->c2, g));
+}
+int tfhe_amd_cb_load_bk_torus(tfhe_amd_cb *cb, const int64_t *bk) {
+    if (!cb || !bk) return TFHE_AMD_ERR_PARAM;
+    tfhe_amd_gsw *g = nullptr;
+    int rc = cb_pass(cb, cb->c2, tfhe_amd_gsw_from_torus(cb->c2, bk, cb->p.n0, &g));
+    return rc ? rc : cb_set_bk(cb, g);
+}
+int tfhe_amd_cb_load_bk_fft(tfhe_amd_cb *cb, const double *bkfft) {
+    if (!cb || !bkfft) return TFHE_AMD_ERR_PARAM;
+    tfhe_amd_gsw *g = nullptr;
+    int rc = cb_pass(cb, cb->c2, tfhe_amd_gsw_from_fft(cb->c2, bkfft, cb->p.n0, &g));
+    return rc ? rc : cb_set_bk(cb, g);
+}
+int tfhe_amd_cb_load_privks_plane(tfhe_amd_cb *cb, int u, const int32_t *plane) {
+    if (!cb || !plane || u < 0 || u > 1) return TFHE_AMD_ERR_PARAM;
+    const size_t bytes = (size_t)(cb->p.N2 + 1) * cb->p.t21 * ((size_t)1 << cb->p.bb21) * 2 * cb->p.N1 * 4;
+    tfhe_amd_ctx *c = cb->c2;
+    if (!cb->privks_d[u] && hipMalloc((void **)&cb->privks_d[u], bytes) != hipSuccess)
+        return cb_fail(cb, TFHE_AMD_ERR_ALLOC, "hipMalloc(privKS plane)");
+    if (hipMemcpyAsync(cb->privks_d[u], plane, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess)
+        return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "upload privKS plane");
+    return TFHE_AMD_OK;
+}
+
+int tfhe_amd_privks(tfhe_amd_cb *cb, int32_t *out_d, int u, const int64_t *x_d, int batch) {
+    if (!cb || !out_d || !x_d || u < 0 || u > 1 || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (!cb->privks_d[u]) return cb_fail(cb, TFHE_AMD_ERR_STATE, "privKS plane not loaded");
+    if (batch == 0) return TFHE_AMD_OK;
+    const long long row = 2LL * cb->p.N1;
+    if (hipMemsetAsync(out_d, 0, (size_t)batch * row * 4, cb->c2->stream) != hipSuccess)
+        return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "memset");
+    return launch_privks(cb, out_d, row, u, x_d, batch);
+}
+
+int tfhe_amd_circuit_bootstrap(tfhe_amd_cb *cb, int32_t *out_d, const int32_t *x_d, int batch) {
+    if (!cb || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (!cb->bk || !cb->privks_d[0] || !cb->privks_d[1] || !cb->c10->ks_d)
+        return cb_fail(cb, TFHE_AMD_ERR_STATE, "preKS, bk and both privKS planes must be loaded");
+    if (batch == 0) return TFHE_AMD_OK;
+    const tfhe_amd_cb_params &p = cb->p;
+    tfhe_amd_ctx *c2 = cb->c2;
+    int rc = grow(c2, &cb->ws_pre, &cb->ws_pre_bytes, (size_t)batch * (p.n0 + 1) * 4);
+    if (!rc) rc = grow(c2, &cb->ws_abar, &cb->ws_abar_bytes, (size_t)batch * (p.n0 + 1) * 4);
+    if (!rc) rc = grow(c2, &cb->ws_boot, &cb->ws_boot_bytes, (size_t)batch * (p.N2 + 1) * 8);
+    if (rc) return cb_pass(cb, c2, rc);
+    // preKeySwitch lvl1 -> lvl0, then preModSwitch to [0, 2*N2)
+    rc = cb_pass(cb, cb->c10, tfhe_amd_keyswitch(cb->c10, (int32_t *)cb->ws_pre, x_d, batch));
+    if (!rc) rc = cb_pass(cb, c2, tfhe_amd_modswitch(c2, (int32_t *)cb->ws_abar, (const int32_t *)cb->ws_pre, batch));
+    if (rc) return rc;
+    const long long tlwe = 2LL * p.N1, out_stride = 2LL * p.l1 * tlwe;
+    if (hipMemsetAsync(out_d, 0, (size_t)batch * out_stride * 4, c2->stream) != hipSuccess)
+        return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "memset");
+    for (int w = 0; w < p.l1 && !rc; w++) {
+        const int64_t mu1 = (int64_t)(1ull << (64 - (w + 1) * p.Bgbit1));  // poc:846
+        rc = cb_pass(cb, c2, tfhe_amd_cb_bootstrap_woks(c2, (int64_t *)cb->ws_boot, mu1, (const int32_t *)cb->ws_abar, batch));
+        for (int u = 0; u <= 1 && !rc; u++)  // result->samples[u][w]
+            rc = launch_privks(cb, out_d + ((size_t)u * p.l1 + w) * tlwe, out_stride, u, (const int64_t *)cb->ws_boot, batch);
+    }
+    return rc;
+}
+
+}  // extern "C"

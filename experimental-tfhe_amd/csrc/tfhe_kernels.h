@@ -849,4 +849,87 @@ TFHE_GLOBAL void k_pack_ks(int32_t *__restrict__ dst, const int32_t *__restrict_
     dst[gid] = (h < row) ? src[(ij * base + d) * row + h] : 0;
 }
 
+// ------------------------------------------------ private key switch (circuit bootstrap)
+// circuitPrivKS (poc:667-698): LWE64 sample of dimension n2 -> TLWE32 sample, through the key
+// privKS[u][i][j][d] (TLWE32 rows of 2*N1 ints, poc:405-419).  Same digit loop as the LWE key
+// switch but on 64-bit coefficients (b included as index n2) and with 8 KB rows, so the key
+// (1.3 GB per u at the PoC parameters) streams from HBM: a workgroup owns a tile of TB samples
+// and a slice of the i range, reads each (i,j) block of base-1 candidate rows once for the whole
+// tile (16-byte loads, 8 ints per thread), and adds its partial sums into the pre-zeroed output
+// with integer atomics (exact and order-independent).
+//   tab: plane u, reference layout [n2+1][t][base][2*N1]; x: [batch][n2+1];
+//   out: sample b at out + b*out_stride, 2*N1 ints, zeroed by the caller
+template <int TB, int BB>
+TFHE_GLOBAL void __launch_bounds__(256)
+    k_privks(int32_t *__restrict__ out, long long out_stride, const int64_t *__restrict__ x,
+             const int32_t *__restrict__ tab, int n2, int t, int row_ints, int batch, int i_per_block) {
+    constexpr int NR = (1 << BB) - 1, BASE = 1 << BB;
+    constexpr uint64_t mask = (uint64_t)BASE - 1;
+    const int lane = threadIdx.x & 63;
+    const int tile0 = blockIdx.x * TB;
+    const int i_begin = blockIdx.y * i_per_block;
+    const int i_end = (i_begin + i_per_block < n2 + 1) ? i_begin + i_per_block : n2 + 1;
+    const uint64_t prec_offset = 1ull << (64 - (1 + BB * t));
+    // row segments of 2048 ints: thread owns ints [seg*2048 + 8*tid, +8)
+    for (int seg = 0; seg * 2048 < row_ints; seg++) {
+        const int e0 = seg * 2048 + 8 * (int)threadIdx.x;
+        if (e0 >= row_ints) continue;  // (row_ints is a multiple of 8)
+        uint32_t acc[TB][8];
+#pragma unroll
+        for (int b = 0; b < TB; b++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[b][e] = 0u;
+#pragma unroll 1
+        for (int i0 = i_begin; i0 < i_end; i0 += 64) {
+            int alo[TB], ahi[TB];  // lane L: x[b][i0+L] + prec_offset (0 => all digits 0)
+#pragma unroll
+            for (int b = 0; b < TB; b++) {
+                const bool ok = (tile0 + b < batch) && (i0 + lane < i_end);
+                const uint64_t v = ok ? (uint64_t)x[(size_t)(tile0 + b) * (n2 + 1) + i0 + lane] + prec_offset : 0ull;
+                alo[b] = (int)(uint32_t)v;
+                ahi[b] = (int)(uint32_t)(v >> 32);
+            }
+            const int cnt = (i_end - i0 < 64) ? (i_end - i0) : 64;
+#pragma unroll 1
+            for (int ii = 0; ii < cnt; ii++) {
+                uint64_t ab[TB];
+#pragma unroll
+                for (int b = 0; b < TB; b++)
+                    ab[b] = ((uint64_t)(uint32_t)TFHE_READLANE(ahi[b], ii) << 32) | (uint32_t)TFHE_READLANE(alo[b], ii);
+#pragma unroll 1
+                for (int j = 0; j < t; j++) {
+                    const int sh = 64 - (j + 1) * BB;
+                    const int32_t *rows = tab + (((size_t)(i0 + ii) * t + j) * BASE + 1) * row_ints + e0;
+                    uint32_t r[NR][8];
+#pragma unroll
+                    for (int d = 0; d < NR; d++)
+#pragma unroll
+                        for (int e = 0; e < 8; e++) r[d][e] = (uint32_t)rows[(size_t)d * row_ints + e];
+#pragma unroll
+                    for (int b = 0; b < TB; b++) {
+                        const uint32_t dig = (uint32_t)((ab[b] >> sh) & mask);  // wave-uniform
+                        if (dig == 0) continue;
+#pragma unroll
+                        for (int d = 0; d < NR; d++) {
+                            if (dig == (uint32_t)(d + 1)) {
+                                TFHE_KEEP_BRANCH();
+#pragma unroll
+                                for (int e = 0; e < 8; e++) acc[b][e] -= r[d][e];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < TB; b++) {
+            if (tile0 + b >= batch) continue;
+            uint32_t *o = reinterpret_cast<uint32_t *>(out) + (size_t)(tile0 + b) * out_stride + e0;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (acc[b][e]) atomicAdd(&o[e], acc[b][e]);
+        }
+    }
+}
+
 }  // namespace tfhe

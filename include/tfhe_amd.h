@@ -150,6 +150,45 @@ int tfhe_amd_cb_bootstrap_woks(tfhe_amd_ctx *ctx, int64_t *lwe_out_d, int64_t mu
 /* preModSwitch (poc:472-484): x_d [batch][n+1] Torus32 -> out_d [batch][n+1] in [0, 2N) */
 int tfhe_amd_modswitch(tfhe_amd_ctx *ctx, int32_t *out_d, const int32_t *x_d, int batch);
 
+/* ---- circuit bootstrapping (TLWE -> TRGSW), the PoC of circuit-bootstrapping/src ------------
+ * tfhe_CircuitBootstrapFFT (poc:823-873) = preKeySwitch lvl1->lvl0 (poc:437-465), preModSwitch
+ * (poc:472-484), then for w < l1: circuitBootstrapWoKS (poc:530-659, Torus64, ring N2) with
+ * mu = 2^(64-(w+1)Bgbit1) and k+1 circuitPrivKS (poc:667-698) back to TLWE32 rows of ring N1.
+ * Parameters: the PoC's Globals statics (poc:70-85, poc_types.h:267-283). */
+typedef struct tfhe_amd_cb_params {
+    int32_t n0, N1, N2; /* lvl0 LWE dimension; lvl1 ring degree (= lvl1 LWE dimension); lvl2 ring degree */
+    int32_t l1, Bgbit1; /* gadget of the output TGSW (lvl1) */
+    int32_t l2, Bgbit2; /* gadget of the bootstrapping key (lvl2, Torus64) */
+    int32_t t10, bb10;  /* preKS lvl1 -> lvl0: length, base bits */
+    int32_t t21, bb21;  /* privKS lvl2 -> lvl1: length, base bits (1..3) */
+} tfhe_amd_cb_params;
+typedef struct tfhe_amd_cb tfhe_amd_cb;
+
+int tfhe_amd_cb_create(const tfhe_amd_cb_params *params, int device, tfhe_amd_cb **out);
+void tfhe_amd_cb_destroy(tfhe_amd_cb *cb);
+const char *tfhe_amd_cb_last_error(const tfhe_amd_cb *cb);
+int tfhe_amd_cb_set_stream(tfhe_amd_cb *cb, void *hip_stream);
+int tfhe_amd_cb_sync(tfhe_amd_cb *cb);
+/* the two single-level contexts inside (borrowed, do not destroy): Torus32 lvl1->lvl0 context
+ * (preKeySwitch = tfhe_amd_keyswitch) and Torus64 lvl2 context (tfhe_amd_modswitch =
+ * preModSwitch, tfhe_amd_cb_bootstrap_woks = circuitBootstrapWoKS, memory helpers) */
+tfhe_amd_ctx *tfhe_amd_cb_ctx_lvl10(tfhe_amd_cb *cb);
+tfhe_amd_ctx *tfhe_amd_cb_ctx_lvl2(tfhe_amd_cb *cb);
+/* Globals::preKS, host layout [N1][t10][1<<bb10][n0+1] int32 (poc:375) */
+int tfhe_amd_cb_load_preks(tfhe_amd_cb *cb, const int32_t *preks);
+/* Globals::bk in coefficient form [n0][2*l2][2][N2] int64 (poc:388; converted on the GPU like
+ * poc:395-402) or already in Lagrange form [n0][2*l2][2][N2] doubles (Globals::bkFFT) */
+int tfhe_amd_cb_load_bk_torus(tfhe_amd_cb *cb, const int64_t *bk);
+int tfhe_amd_cb_load_bk_fft(tfhe_amd_cb *cb, const double *bkfft);
+/* Globals::privKS, host layout [2][N2+1][t21][1<<bb21][2][N1] int32 (poc:408); `u_plane` in
+ * {0,1} uploads one [N2+1][t21][base][2][N1] plane (1.3 GB each at the PoC parameters) */
+int tfhe_amd_cb_load_privks_plane(tfhe_amd_cb *cb, int u_plane, const int32_t *plane);
+/* circuitPrivKS: x_d [batch][N2+1] int64 -> out_d [batch][2][N1] int32 */
+int tfhe_amd_privks(tfhe_amd_cb *cb, int32_t *out_d, int u, const int64_t *x_d, int batch);
+/* tfhe_CircuitBootstrapFFT: x_d [batch][N1+1] LWE32 -> out_d [batch][2][l1][2][N1] int32
+ * (TGswSample32::samples[u][w], each a TLWE32 (a, b)) */
+int tfhe_amd_circuit_bootstrap(tfhe_amd_cb *cb, int32_t *out_d, const int32_t *x_d, int batch);
+
 /* ---- harness: synthetic keys and samples (the reference's keygen/encrypt/phase,
  *      poc:88-134,191-227,342-423; PRNG spec in DESIGN.md) -- host side ------------------ */
 int tfhe_amd_keygen_binary(int32_t *key, int n, uint64_t seed, uint64_t stream);

@@ -82,7 +82,7 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
     unsigned char *smem_raw = (unsigned char *)malloc(((smem_bytes + 15) / 16) * 16 + 16);
     b.smem = smem_raw;
     b.smem += 16 - ((uintptr_t)b.smem & 15);  // 16-byte aligned like the hardware carve-out
-    t_blockIdx = Dim3(bx);
+    t_blockIdx = Dim3(bx % grid.x, bx / grid.x);  // bx is the flattened (x, y) block index
     t_blockDim = block;
     t_gridDim = grid;
     for (unsigned t = 0; t < nt; t++) {
@@ -127,7 +127,7 @@ int readlane(int v, int lane) {
 }
 
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes) {
-    const unsigned nb = grid.x;
+    const unsigned nb = grid.x * grid.y;
     unsigned nthreads = std::min<unsigned>(nb, std::max(1u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("TFHE_EMU_THREADS")) nthreads = std::max(1, atoi(e));
     std::atomic<unsigned> next{0};

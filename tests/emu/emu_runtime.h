@@ -50,12 +50,8 @@ using dim3 = emu::Dim3;
 #define TFHE_LAUNCH_FLAT(kernel, grid, block, stream, ...) \
     emu::launch_flat([=]() { kernel(__VA_ARGS__); }, grid, block)
 
-// a workgroup runs on one OS thread (fibers), so a plain read-modify-write is atomic enough
-static inline unsigned atomicAdd(unsigned *p, unsigned v) {
-    const unsigned o = *p;
-    *p = o + v;
-    return o;
-}
+// workgroups of one launch run on several OS threads: global-memory atomics must be real ones
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 struct double2 {
     double x, y;

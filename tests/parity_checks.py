@@ -190,6 +190,35 @@ def check_torus64_path(lib_path, N, n, l, Bgbit, B, seed=31):
         e.close()
 
 
+# ------------------------------------------------------------ circuit bootstrap
+def check_circuit_bootstrap(lib_path, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, B, seed=61):
+    """circuitPrivKS and the whole tfhe_CircuitBootstrapFFT pipeline (preKeySwitch, preModSwitch,
+    Torus64 blind rotation, private key switch) against the oracle.  The bootstrapping key is a
+    real TGSW key; preKS / privKS are synthetic (uniformly random tables): parity does not need
+    them to decrypt, and generating a real privKS costs minutes of CPU."""
+    rs = np.random.RandomState(seed)
+    key0, key2 = O.keygen_binary(n0, SEED, 21), O.keygen_binary(N2, SEED, 23)
+    bk = O.bk_create64(N2, key0, key2, l2, bg2, 2.0 ** -44, SEED, 3000)
+    preks = O.fill32(101, N1 * t10 * (1 << bb10) * (n0 + 1)).reshape(N1, t10, 1 << bb10, n0 + 1)
+    privks = O.fill32(202, 2 * (N2 + 1) * t21 * (1 << bb21) * 2 * N1).reshape(2, N2 + 1, t21, 1 << bb21, 2, N1)
+    cb = T.CircuitBootstrap(n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, lib_path=lib_path)
+    try:
+        cb.load_preks(preks)
+        cb.load_bk_fft(bk)
+        cb.load_privks(privks)
+        x64 = rs.randint(-2 ** 63, 2 ** 63 - 1, size=(B, N2 + 1), dtype=np.int64)
+        x64[0, :3] = [0, -1, 1 << (63 - t21 * bb21)]  # digit rounding boundary
+        for u in (0, 1):
+            want = np.stack([O.privks(privks[u], x64[b], N2, N1, t21, bb21) for b in range(B)]).reshape(B, 2, N1)
+            assert np.array_equal(cb.privks(u, x64), want), f"circuitPrivKS u={u}"
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(B, N1 + 1)).astype(np.int32)
+        want = np.stack([O.circuit_bootstrap(x[b], preks, bk, privks, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10,
+                                             t21, bb21) for b in range(B)])
+        assert np.array_equal(cb.circuit_bootstrap(x), want), "tfhe_CircuitBootstrapFFT"
+    finally:
+        cb.close()
+
+
 # --------------------------------------------------------------- key switch only
 def check_keyswitch_shapes(lib_path, N, n_out, ks_t, ks_bb, B, seed=51):
     """lweKeySwitch / preKeySwitch on a synthetic (uniformly random) key: exercises the batch-tiled

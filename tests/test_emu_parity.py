@@ -31,6 +31,12 @@ def test_keyswitch_real_shapes_emu(emu_lib, n_out, t, bb, B):
     P.check_keyswitch_shapes(emu_lib, 1024, n_out, t, bb, B)
 
 
+def test_circuit_bootstrap_emu(emu_lib):
+    # N2 = 2048, l2 = 4, Bgbit2 = 9, privKS base 8 as in the PoC; short n0 / key-switch lengths
+    P.check_circuit_bootstrap(emu_lib, n0=2, N1=1024, N2=2048, l1=2, bg1=8, l2=4, bg2=9, t10=3, bb10=2, t21=2,
+                              bb21=3, B=2)
+
+
 @pytest.mark.parametrize("N,l,Bgbit,B", [(2048, 4, 9, 4), (1024, 3, 10, 5)])
 def test_torus64_path_emu(emu_lib, N, l, Bgbit, B):
     P.check_torus64_path(emu_lib, N=N, n=3, l=l, Bgbit=Bgbit, B=B)

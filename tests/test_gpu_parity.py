@@ -88,6 +88,17 @@ def test_circuit_bootstrap_blind_rotation_full(gpu_lib):
     P.check_torus64_path(gpu_lib, N=2048, n=500, l=4, Bgbit=9, B=4, seed=41)
 
 
+def test_circuit_bootstrap_pipeline(gpu_lib):
+    """BASELINE config 3: tfhe_CircuitBootstrapFFT with the PoC ring sizes and gadgets (N1=1024,
+    N2=2048, l2=4, Bgbit2=9, l1=2, Bgbit1=8, preKS 6x2, privKS base 8); n0 and the privKS length are
+    shortened so the oracle side finishes in seconds (the full-length blind rotation is covered by
+    test_circuit_bootstrap_blind_rotation_full, the full key-switch shapes by the key switch tests)."""
+    P.check_circuit_bootstrap(gpu_lib, n0=24, N1=1024, N2=2048, l1=2, bg1=8, l2=4, bg2=9, t10=6, bb10=2, t21=3,
+                              bb21=3, B=19)
+    P.check_circuit_bootstrap(gpu_lib, n0=5, N1=1024, N2=1024, l1=3, bg1=6, l2=3, bg2=10, t10=4, bb10=3, t21=5,
+                              bb21=2, B=3, seed=62)
+
+
 def test_batch_4096_properties(gpu_lib):
     """BASELINE config 2 at full size: 4096 gate bootstraps.  Checked by (i) decrypt-sign of every
     output, (ii) bit-equality with the oracle on a subset, (iii) persistent schedule == one launch
