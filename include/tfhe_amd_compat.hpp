@@ -1,0 +1,500 @@
+// tfhe_amd_compat.hpp -- the reference's C++ entry points, served by the MI355X engine.
+//
+// Header-only C++11 shims over the C ABI (include/tfhe_amd.h).  They keep the NAMES,
+// ARGUMENT ORDER and MEANING of the reference functions so that an existing driver links
+// against this engine instead of the CPU code:
+//
+//   library form (CB/lwe_functions.cpp, CB/tgsw_functions.cpp; the reference ships these
+//   without headers, struct fields are the ones those files use -- SURVEY 8b):
+//       tfhe_bootstrap_FFT            CB/lwe_functions.cpp:434-446
+//       tfhe_bootstrap_woKS_FFT       CB/lwe_functions.cpp:399-430
+//       tfhe_blindRotateAndExtract_FFT  :366-395     tfhe_blindRotate_FFT  :337-361
+//       tGswFFTExternMulToTLwe        CB/tgsw_functions.cpp:424-449
+//       lweKeySwitch                  CB/lwe_functions.cpp:163-171
+//   FFT plugin (CB/spqlios/lagrangehalfc_impl.h:8-36):
+//       class FFT_Processor_AMD  (same five execute_* methods as FFT_Processor_Spqlios),
+//       LagrangeHalfCPolynomialAddMulASM-compatible AddMul
+//   PoC form (CB/poc_CircuitBootstrapping.cpp, types of CB/poc_types.h): class template
+//       PocEngine<Globals>: tfhe_CircuitBootstrapFFT :823-873, circuitBootstrapWoKS :530-659,
+//       circuitPrivKS :667-698, preKeySwitch :437-465, preModSwitch :472-484.  It is a template
+//       so it compiles against the reference's own poc_types.h (include that first) or against
+//       any structs with the same members.
+//
+// Like the reference these calls process ONE sample and are synchronous; they copy the sample
+// to the GPU and back, so they are for drop-in correctness, not throughput -- throughput code
+// calls the batch entry points of tfhe_amd.h directly.  Keys are uploaded once, the first time a
+// key object is seen (keyed by its address), and stay resident until release().
+// Errors: the reference returns void and asserts/aborts (lwe_functions.cpp:480-481,
+// spqlios-fft-impl.cpp:92-97); the shims do the same (message on stderr, abort()).
+// circuitBootstrapWoKS follows the LIBRARY rotation semantics, not the PoC's defective loop
+// (DESIGN.md section 6).
+#ifndef TFHE_AMD_COMPAT_HPP
+#define TFHE_AMD_COMPAT_HPP
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "tfhe_amd.h"
+
+namespace tfhe_amd_compat {
+
+typedef int32_t Torus32;
+typedef int64_t Torus64;
+
+inline void check(int rc, tfhe_amd_ctx *c, const char *what) {
+    if (rc != TFHE_AMD_OK) {
+        std::fprintf(stderr, "tfhe_amd: %s failed (%d): %s\n", what, rc, c ? tfhe_amd_last_error(c) : "");
+        std::abort();
+    }
+}
+
+// ---- library-form structs (fields evidenced by use in CB/*_functions.cpp) --------
+#ifndef TFHE_AMD_COMPAT_NO_TYPES
+struct LweParams {
+    int n;
+    double alpha_min, alpha_max;
+};
+struct LweSample {  // lwe_functions.cpp:20-24
+    Torus32 *a;
+    Torus32 b;
+    double current_variance;
+};
+struct TorusPolynomial {  // numeric_functions.cpp:199-223
+    int N;
+    Torus32 *coefsT;
+};
+struct LagrangeHalfCPolynomial {  // N doubles re|im, poc_types.h:96-102
+    double *values;
+};
+struct TLweParams {
+    int N, k;
+    double alpha_min, alpha_max;
+    LweParams extracted_lweparams;
+};
+struct TLweSample {  // tlwe_functions.cpp:27-31
+    TorusPolynomial *a;
+    TorusPolynomial *b;
+    double current_variance;
+    int k;
+};
+struct TLweSampleFFT {  // tlwe_functions.cpp:34-38
+    LagrangeHalfCPolynomial *a;
+    LagrangeHalfCPolynomial *b;
+    double current_variance;
+    int k;
+};
+struct TGswParams {  // tgsw_functions.cpp:15-38
+    int l, Bgbit, Bg;
+    int32_t halfBg;
+    uint32_t maskMod;
+    const TLweParams *tlwe_params;
+    int kpl;
+    Torus32 *h;
+    uint32_t offset;
+};
+struct TGswSampleFFT {  // tgsw_functions.cpp:47-53
+    TLweSampleFFT *all_samples;
+    TLweSampleFFT **sample;
+    int k, l;
+};
+struct LweKeySwitchKey {  // lwe_functions.cpp:96-110
+    int n, t, basebit, base;
+    const LweParams *out_params;
+    LweSample *ks0_raw;
+    LweSample **ks1_raw;
+    LweSample ***ks;
+};
+struct LweBootstrappingKeyFFT {  // lwe_functions.cpp:272-281
+    const LweParams *in_out_params;
+    const TGswParams *bk_params;
+    const TLweParams *accum_params;
+    const LweParams *extract_params;
+    const TGswSampleFFT *bkFFT;
+    const LweKeySwitchKey *ks;
+};
+#endif
+
+// ---- one resident engine per key object ------------------------------------------------------
+struct Resident {
+    tfhe_amd_ctx *ctx = nullptr;
+    tfhe_amd_gsw *gsw = nullptr;
+    int n = 0, N = 0, l = 0;
+    void *d_in = nullptr, *d_out = nullptr, *d_aux = nullptr;  // one-sample staging buffers
+};
+inline std::map<const void *, Resident> &registry() {
+    static std::map<const void *, Resident> r;
+    return r;
+}
+inline int &device_ordinal() {
+    static int d = 0;
+    return d;
+}
+inline void set_device(int d) { device_ordinal() = d; }
+
+inline void staging(Resident &R, size_t bytes) {
+    if (R.d_in) return;
+    check(tfhe_amd_malloc(R.ctx, &R.d_in, bytes), R.ctx, "malloc");
+    check(tfhe_amd_malloc(R.ctx, &R.d_out, bytes), R.ctx, "malloc");
+    check(tfhe_amd_malloc(R.ctx, &R.d_aux, bytes), R.ctx, "malloc");
+}
+
+// flatten n TGswSampleFFT (pointer-rich) into [n][2l][2][N] doubles and upload
+template <class GswT>
+inline Resident &attach_gsw(const GswT *bkFFT, int n, int N, int l, int Bgbit, const LweKeySwitchKey *ks = nullptr) {
+    auto &reg = registry();
+    auto it = reg.find((const void *)bkFFT);
+    if (it != reg.end()) return it->second;
+    Resident R;
+    R.n = n;
+    R.N = N;
+    R.l = l;
+    tfhe_amd_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.torus_bits = 32;
+    p.n = n;
+    p.N = N;
+    p.k = 1;
+    p.l = l;
+    p.Bgbit = Bgbit;
+    if (ks) {
+        p.ks_t = ks->t;
+        p.ks_basebit = ks->basebit;
+        p.ks_n_out = ks->out_params->n;
+    }
+    check(tfhe_amd_ctx_create(&p, device_ordinal(), &R.ctx), nullptr, "tfhe_amd_ctx_create");
+    std::vector<double> flat((size_t)n * 2 * l * 2 * N);
+    for (int i = 0; i < n; i++)
+        for (int r = 0; r < 2 * l; r++)
+            for (int q = 0; q < 2; q++)
+                std::memcpy(&flat[(((size_t)i * 2 * l + r) * 2 + q) * N], bkFFT[i].all_samples[r].a[q].values,
+                            sizeof(double) * (size_t)N);
+    check(tfhe_amd_gsw_from_fft(R.ctx, flat.data(), n, &R.gsw), R.ctx, "tfhe_amd_gsw_from_fft");
+    check(tfhe_amd_set_bootstrap_key(R.ctx, R.gsw), R.ctx, "tfhe_amd_set_bootstrap_key");
+    if (ks) {
+        const int rows = ks->base, row = ks->out_params->n + 1;
+        std::vector<int32_t> kflat((size_t)ks->n * ks->t * rows * row);
+        for (int i = 0; i < ks->n; i++)
+            for (int j = 0; j < ks->t; j++)
+                for (int h = 0; h < rows; h++) {
+                    int32_t *dst = &kflat[(((size_t)i * ks->t + j) * rows + h) * row];
+                    std::memcpy(dst, ks->ks[i][j][h].a, sizeof(int32_t) * (size_t)(row - 1));
+                    dst[row - 1] = ks->ks[i][j][h].b;
+                }
+        check(tfhe_amd_load_keyswitch_key(R.ctx, kflat.data()), R.ctx, "tfhe_amd_load_keyswitch_key");
+    }
+    staging(R, sizeof(int32_t) * (size_t)(2 * N + n + 2));
+    return reg.emplace((const void *)bkFFT, R).first->second;
+}
+inline void release(const void *key_object) {
+    auto &reg = registry();
+    auto it = reg.find(key_object);
+    if (it == reg.end()) return;
+    Resident &R = it->second;
+    tfhe_amd_free(R.ctx, R.d_in);
+    tfhe_amd_free(R.ctx, R.d_out);
+    tfhe_amd_free(R.ctx, R.d_aux);
+    tfhe_amd_gsw_free(R.gsw);
+    tfhe_amd_ctx_destroy(R.ctx);
+    reg.erase(it);
+}
+inline void release_all() {
+    while (!registry().empty()) release(registry().begin()->first);
+}
+
+inline Resident &attach(const LweBootstrappingKeyFFT *bk) {
+    return attach_gsw(bk->bkFFT, bk->in_out_params->n, bk->accum_params->N, bk->bk_params->l, bk->bk_params->Bgbit,
+                      bk->ks);
+}
+
+// ---- library-form entry points ----------------------------------------------------------------
+inline void put_lwe(Resident &R, void *dst_d, const LweSample *x, int n) {
+    std::vector<int32_t> f((size_t)n + 1);
+    std::memcpy(f.data(), x->a, sizeof(int32_t) * (size_t)n);
+    f[n] = x->b;
+    check(tfhe_amd_memcpy_h2d(R.ctx, dst_d, f.data(), f.size() * 4), R.ctx, "h2d");
+}
+inline void get_lwe(Resident &R, LweSample *res, const void *src_d, int n) {
+    std::vector<int32_t> f((size_t)n + 1);
+    check(tfhe_amd_memcpy_d2h(R.ctx, f.data(), src_d, f.size() * 4), R.ctx, "d2h");
+    std::memcpy(res->a, f.data(), sizeof(int32_t) * (size_t)n);
+    res->b = f[n];
+}
+inline void put_tlwe(Resident &R, void *dst_d, const TLweSample *s, int N) {
+    std::vector<int32_t> f((size_t)2 * N);
+    for (int q = 0; q < 2; q++) std::memcpy(&f[(size_t)q * N], s->a[q].coefsT, sizeof(int32_t) * (size_t)N);
+    check(tfhe_amd_memcpy_h2d(R.ctx, dst_d, f.data(), f.size() * 4), R.ctx, "h2d");
+}
+inline void get_tlwe(Resident &R, TLweSample *s, const void *src_d, int N) {
+    std::vector<int32_t> f((size_t)2 * N);
+    check(tfhe_amd_memcpy_d2h(R.ctx, f.data(), src_d, f.size() * 4), R.ctx, "d2h");
+    for (int q = 0; q < 2; q++) std::memcpy(s->a[q].coefsT, &f[(size_t)q * N], sizeof(int32_t) * (size_t)N);
+}
+
+inline void tfhe_bootstrap_woKS_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x) {
+    Resident &R = attach(bk);
+    put_lwe(R, R.d_in, x, R.n);
+    check(tfhe_amd_bootstrap_woks(R.ctx, (int32_t *)R.d_out, mu, (const int32_t *)R.d_in, 1), R.ctx, "bootstrap_woks");
+    get_lwe(R, result, R.d_out, R.N);
+}
+inline void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x) {
+    Resident &R = attach(bk);
+    put_lwe(R, R.d_in, x, R.n);
+    check(tfhe_amd_bootstrap(R.ctx, (int32_t *)R.d_out, mu, (const int32_t *)R.d_in, 1), R.ctx, "bootstrap");
+    get_lwe(R, result, R.d_out, R.n);
+}
+inline void tfhe_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bkFFT, const int *bara, const int n,
+                                 const TGswParams *bk_params) {
+    Resident &R = attach_gsw(bkFFT, n, bk_params->tlwe_params->N, bk_params->l, bk_params->Bgbit);
+    put_tlwe(R, R.d_in, accum, R.N);
+    check(tfhe_amd_memcpy_h2d(R.ctx, R.d_aux, bara, sizeof(int) * (size_t)n), R.ctx, "h2d");
+    check(tfhe_amd_blind_rotate(R.ctx, R.d_in, (const int32_t *)R.d_aux, 1), R.ctx, "blind_rotate");
+    get_tlwe(R, accum, R.d_in, R.N);
+}
+inline void tfhe_blindRotateAndExtract_FFT(LweSample *result, const TorusPolynomial *v, const TGswSampleFFT *bk,
+                                           const int barb, const int *bara, const int n, const TGswParams *bk_params) {
+    Resident &R = attach_gsw(bk, n, bk_params->tlwe_params->N, bk_params->l, bk_params->Bgbit);
+    std::vector<int32_t> rot((size_t)n + 1);
+    std::memcpy(rot.data(), bara, sizeof(int) * (size_t)n);
+    rot[n] = barb;
+    check(tfhe_amd_memcpy_h2d(R.ctx, R.d_aux, rot.data(), rot.size() * 4), R.ctx, "h2d");
+    check(tfhe_amd_memcpy_h2d(R.ctx, R.d_in, v->coefsT, sizeof(int32_t) * (size_t)R.N), R.ctx, "h2d");
+    check(tfhe_amd_blind_rotate_extract(R.ctx, R.d_out, R.d_in, 0, (const int32_t *)R.d_aux, 1), R.ctx, "bre");
+    get_lwe(R, result, R.d_out, R.N);
+}
+inline void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, const TGswParams *params) {
+    Resident &R = attach_gsw(gsw, 1, params->tlwe_params->N, params->l, params->Bgbit);
+    put_tlwe(R, R.d_in, accum, R.N);
+    check(tfhe_amd_extern_mul(R.ctx, R.d_in, R.gsw, 0, 1), R.ctx, "extern_mul");
+    get_tlwe(R, accum, R.d_in, R.N);
+}
+// lweKeySwitch(result, ks, sample): a key-switch key seen on its own gets its own resident engine
+// (input dimension ks->n must be a ring degree the engine supports: 1024 or 2048)
+inline void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample) {
+    auto &reg = registry();
+    auto it = reg.find((const void *)ks);
+    if (it == reg.end()) {
+        Resident R;
+        R.n = ks->out_params->n;
+        R.N = ks->n;
+        tfhe_amd_params p;
+        std::memset(&p, 0, sizeof(p));
+        p.torus_bits = 32;
+        p.n = R.n;
+        p.N = R.N;
+        p.k = 1;
+        p.l = 1;
+        p.Bgbit = 1;
+        p.ks_t = ks->t;
+        p.ks_basebit = ks->basebit;
+        p.ks_n_out = R.n;
+        check(tfhe_amd_ctx_create(&p, device_ordinal(), &R.ctx), nullptr, "tfhe_amd_ctx_create");
+        const int row = R.n + 1;
+        std::vector<int32_t> kflat((size_t)ks->n * ks->t * ks->base * row);
+        for (int i = 0; i < ks->n; i++)
+            for (int j = 0; j < ks->t; j++)
+                for (int h = 0; h < ks->base; h++) {
+                    int32_t *dst = &kflat[(((size_t)i * ks->t + j) * ks->base + h) * row];
+                    std::memcpy(dst, ks->ks[i][j][h].a, sizeof(int32_t) * (size_t)R.n);
+                    dst[R.n] = ks->ks[i][j][h].b;
+                }
+        check(tfhe_amd_load_keyswitch_key(R.ctx, kflat.data()), R.ctx, "tfhe_amd_load_keyswitch_key");
+        staging(R, sizeof(int32_t) * (size_t)(2 * R.N + R.n + 2));
+        it = reg.emplace((const void *)ks, R).first;
+    }
+    Resident &R = it->second;
+    put_lwe(R, R.d_in, sample, R.N);
+    check(tfhe_amd_keyswitch(R.ctx, (int32_t *)R.d_out, (const int32_t *)R.d_in, 1), R.ctx, "keyswitch");
+    get_lwe(R, result, R.d_out, R.n);
+}
+
+// ---- FFT plugin look-alike (CB/spqlios/lagrangehalfc_impl.h:8-31) -----------------------------
+class FFT_Processor_AMD {
+   public:
+    const int _2N, N, Ns2;
+    explicit FFT_Processor_AMD(int N_) : _2N(2 * N_), N(N_), Ns2(N_ / 2), ctx_(nullptr), a_(nullptr), b_(nullptr), c_(nullptr) {
+        tfhe_amd_params p;
+        std::memset(&p, 0, sizeof(p));
+        p.torus_bits = 64;  // the width only selects gadget defaults; all four conversions are available
+        p.n = 1;
+        p.N = N_;
+        p.k = 1;
+        p.l = 1;
+        p.Bgbit = 1;
+        check(tfhe_amd_ctx_create(&p, device_ordinal(), &ctx_), nullptr, "tfhe_amd_ctx_create");
+        check(tfhe_amd_malloc(ctx_, &a_, 8 * (size_t)N), ctx_, "malloc");
+        check(tfhe_amd_malloc(ctx_, &b_, 8 * (size_t)N), ctx_, "malloc");
+        check(tfhe_amd_malloc(ctx_, &c_, 8 * (size_t)N), ctx_, "malloc");
+    }
+    ~FFT_Processor_AMD() {
+        tfhe_amd_free(ctx_, a_);
+        tfhe_amd_free(ctx_, b_);
+        tfhe_amd_free(ctx_, c_);
+        tfhe_amd_ctx_destroy(ctx_);
+    }
+    void execute_reverse_int(double *res, const int *a) {
+        check(tfhe_amd_memcpy_h2d(ctx_, a_, a, 4 * (size_t)N), ctx_, "h2d");
+        check(tfhe_amd_ifft_int32(ctx_, (double *)b_, (const int32_t *)a_, 1), ctx_, "ifft");
+        check(tfhe_amd_memcpy_d2h(ctx_, res, b_, 8 * (size_t)N), ctx_, "d2h");
+    }
+    void execute_reverse_torus32(double *res, const int32_t *a) { execute_reverse_int(res, (const int *)a); }
+    void execute_direct_torus32(int32_t *res, const double *a) {
+        check(tfhe_amd_memcpy_h2d(ctx_, a_, a, 8 * (size_t)N), ctx_, "h2d");
+        check(tfhe_amd_fft_torus32(ctx_, (int32_t *)b_, (const double *)a_, 1), ctx_, "fft");
+        check(tfhe_amd_memcpy_d2h(ctx_, res, b_, 4 * (size_t)N), ctx_, "d2h");
+    }
+    void execute_reverse_torus64(double *res, const int64_t *a) {
+        check(tfhe_amd_memcpy_h2d(ctx_, a_, a, 8 * (size_t)N), ctx_, "h2d");
+        check(tfhe_amd_ifft_torus64(ctx_, (double *)b_, (const int64_t *)a_, 1), ctx_, "ifft");
+        check(tfhe_amd_memcpy_d2h(ctx_, res, b_, 8 * (size_t)N), ctx_, "d2h");
+    }
+    void execute_direct_torus64(int64_t *res, const double *a) {
+        check(tfhe_amd_memcpy_h2d(ctx_, a_, a, 8 * (size_t)N), ctx_, "h2d");
+        check(tfhe_amd_fft_torus64(ctx_, (int64_t *)b_, (const double *)a_, 1), ctx_, "fft");
+        check(tfhe_amd_memcpy_d2h(ctx_, res, b_, 8 * (size_t)N), ctx_, "d2h");
+    }
+    // LagrangeHalfCPolynomialAddMulASM(res, a, b, Ns2)
+    void AddMul(double *res, const double *a, const double *b) {
+        check(tfhe_amd_memcpy_h2d(ctx_, c_, res, 8 * (size_t)N), ctx_, "h2d");
+        check(tfhe_amd_memcpy_h2d(ctx_, a_, a, 8 * (size_t)N), ctx_, "h2d");
+        check(tfhe_amd_memcpy_h2d(ctx_, b_, b, 8 * (size_t)N), ctx_, "h2d");
+        check(tfhe_amd_lagrange_addmul(ctx_, (double *)c_, (const double *)a_, (const double *)b_, 1, 0), ctx_, "addmul");
+        check(tfhe_amd_memcpy_d2h(ctx_, res, c_, 8 * (size_t)N), ctx_, "d2h");
+    }
+
+   private:
+    FFT_Processor_AMD(const FFT_Processor_AMD &);
+    FFT_Processor_AMD &operator=(const FFT_Processor_AMD &);
+    tfhe_amd_ctx *ctx_;
+    void *a_, *b_, *c_;
+};
+
+// ---- PoC form: works on the reference's own poc_types.h structs (duck-typed template) ----------
+// GlobalsT needs: n_lvl0, n_lvl1, n_lvl2, bgbit_lvl1, ell_lvl1, bgbit_lvl2, ell_lvl2, kslength_lvl10,
+// ksbasebit_lvl10, kslength_lvl21, ksbasebit_lvl21, preKS[i][j][u].a[h], bkFFT[i].allsamples[r].a[q].values,
+// privKS[u][i][j][d].a[q].coefs[p]   (CB/poc_types.h:267-312)
+template <class GlobalsT>
+class PocEngine {
+   public:
+    explicit PocEngine(const GlobalsT *env, int device = 0) : cb_(nullptr) {
+        tfhe_amd_cb_params p;
+        p.n0 = env->n_lvl0;
+        p.N1 = env->n_lvl1;
+        p.N2 = env->n_lvl2;
+        p.l1 = env->ell_lvl1;
+        p.Bgbit1 = env->bgbit_lvl1;
+        p.l2 = env->ell_lvl2;
+        p.Bgbit2 = env->bgbit_lvl2;
+        p.t10 = env->kslength_lvl10;
+        p.bb10 = env->ksbasebit_lvl10;
+        p.t21 = env->kslength_lvl21;
+        p.bb21 = env->ksbasebit_lvl21;
+        p_ = p;
+        die(tfhe_amd_cb_create(&p, device, &cb_), "tfhe_amd_cb_create");
+        const int base10 = 1 << p.bb10, base21 = 1 << p.bb21;
+        {  // Globals::preKS -> [N1][t10][base10][n0+1]
+            std::vector<int32_t> f((size_t)p.N1 * p.t10 * base10 * (p.n0 + 1));
+            size_t o = 0;
+            for (int i = 0; i < p.N1; i++)
+                for (int j = 0; j < p.t10; j++)
+                    for (int u = 0; u < base10; u++, o += (size_t)p.n0 + 1)
+                        std::memcpy(&f[o], env->preKS[i][j][u].a, sizeof(int32_t) * (size_t)(p.n0 + 1));
+            die(tfhe_amd_cb_load_preks(cb_, f.data()), "load preKS");
+        }
+        {  // Globals::bkFFT -> [n0][2 l2][2][N2]
+            std::vector<double> f((size_t)p.n0 * 2 * p.l2 * 2 * p.N2);
+            size_t o = 0;
+            for (int i = 0; i < p.n0; i++)
+                for (int r = 0; r < 2 * p.l2; r++)
+                    for (int q = 0; q < 2; q++, o += (size_t)p.N2)
+                        std::memcpy(&f[o], env->bkFFT[i].allsamples[r].a[q].values, sizeof(double) * (size_t)p.N2);
+            die(tfhe_amd_cb_load_bk_fft(cb_, f.data()), "load bkFFT");
+        }
+        for (int u = 0; u < 2; u++) {  // Globals::privKS plane u -> [N2+1][t21][base21][2][N1]
+            std::vector<int32_t> f((size_t)(p.N2 + 1) * p.t21 * base21 * 2 * p.N1);
+            size_t o = 0;
+            for (int i = 0; i <= p.N2; i++)
+                for (int j = 0; j < p.t21; j++)
+                    for (int d = 0; d < base21; d++)
+                        for (int q = 0; q < 2; q++, o += (size_t)p.N1)
+                            std::memcpy(&f[o], env->privKS[u][i][j][d].a[q].coefs, sizeof(int32_t) * (size_t)p.N1);
+            die(tfhe_amd_cb_load_privks_plane(cb_, u, f.data()), "load privKS");
+        }
+        c2_ = tfhe_amd_cb_ctx_lvl2(cb_);
+        c10_ = tfhe_amd_cb_ctx_lvl10(cb_);
+        const size_t big = sizeof(int32_t) * (size_t)2 * p.l1 * 2 * p.N1 + sizeof(int64_t) * (size_t)(p.N2 + 1);
+        check(tfhe_amd_malloc(c2_, &d_a_, big), c2_, "malloc");
+        check(tfhe_amd_malloc(c2_, &d_b_, big), c2_, "malloc");
+    }
+    ~PocEngine() {
+        if (cb_) {
+            tfhe_amd_free(c2_, d_a_);
+            tfhe_amd_free(c2_, d_b_);
+            tfhe_amd_cb_destroy(cb_);
+        }
+    }
+    // tfhe_CircuitBootstrapFFT(TGswSample32* result, const LweSample32* sample, env)   poc:823-873
+    template <class TGswSample32T, class LweSample32T>
+    void tfhe_CircuitBootstrapFFT(TGswSample32T *result, const LweSample32T *sample) {
+        check(tfhe_amd_memcpy_h2d(c2_, d_a_, sample->a, sizeof(int32_t) * (size_t)(p_.N1 + 1)), c2_, "h2d");
+        die(tfhe_amd_circuit_bootstrap(cb_, (int32_t *)d_b_, (const int32_t *)d_a_, 1), "circuit_bootstrap");
+        std::vector<int32_t> f((size_t)2 * p_.l1 * 2 * p_.N1);
+        check(tfhe_amd_memcpy_d2h(c2_, f.data(), d_b_, f.size() * 4), c2_, "d2h");
+        for (int u = 0; u < 2; u++)
+            for (int w = 0; w < p_.l1; w++)
+                for (int q = 0; q < 2; q++)
+                    std::memcpy(result->samples[u][w].a[q].coefs, &f[(((size_t)u * p_.l1 + w) * 2 + q) * p_.N1],
+                                sizeof(int32_t) * (size_t)p_.N1);
+    }
+    // circuitBootstrapWoKS(LweSample64* result, Torus64 mu, const int* abar, env)   poc:530-659
+    template <class LweSample64T>
+    void circuitBootstrapWoKS(LweSample64T *result, const Torus64 mu, const int *abar) {
+        check(tfhe_amd_memcpy_h2d(c2_, d_a_, abar, sizeof(int) * (size_t)(p_.n0 + 1)), c2_, "h2d");
+        check(tfhe_amd_cb_bootstrap_woks(c2_, (int64_t *)d_b_, mu, (const int32_t *)d_a_, 1), c2_, "cb_bootstrap_woks");
+        check(tfhe_amd_memcpy_d2h(c2_, result->a, d_b_, sizeof(int64_t) * (size_t)(p_.N2 + 1)), c2_, "d2h");
+    }
+    // circuitPrivKS(TLweSample32* result, int u, const LweSample64* x, env)   poc:667-698
+    template <class TLweSample32T, class LweSample64T>
+    void circuitPrivKS(TLweSample32T *result, const int u, const LweSample64T *x) {
+        check(tfhe_amd_memcpy_h2d(c2_, d_a_, x->a, sizeof(int64_t) * (size_t)(p_.N2 + 1)), c2_, "h2d");
+        die(tfhe_amd_privks(cb_, (int32_t *)d_b_, u, (const int64_t *)d_a_, 1), "privks");
+        std::vector<int32_t> f((size_t)2 * p_.N1);
+        check(tfhe_amd_memcpy_d2h(c2_, f.data(), d_b_, f.size() * 4), c2_, "d2h");
+        for (int q = 0; q < 2; q++) std::memcpy(result->a[q].coefs, &f[(size_t)q * p_.N1], sizeof(int32_t) * (size_t)p_.N1);
+    }
+    // preKeySwitch(LweSample32* result, const LweSample32* x, env)   poc:437-465
+    template <class LweSample32T>
+    void preKeySwitch(LweSample32T *result, const LweSample32T *x) {
+        check(tfhe_amd_memcpy_h2d(c10_, d_a_, x->a, sizeof(int32_t) * (size_t)(p_.N1 + 1)), c10_, "h2d");
+        check(tfhe_amd_keyswitch(c10_, (int32_t *)d_b_, (const int32_t *)d_a_, 1), c10_, "keyswitch");
+        check(tfhe_amd_memcpy_d2h(c10_, result->a, d_b_, sizeof(int32_t) * (size_t)(p_.n0 + 1)), c10_, "d2h");
+    }
+    // preModSwitch(int* result, const LweSample32* x, env)   poc:472-484
+    template <class LweSample32T>
+    void preModSwitch(int *result, const LweSample32T *x) {
+        check(tfhe_amd_memcpy_h2d(c2_, d_a_, x->a, sizeof(int32_t) * (size_t)(p_.n0 + 1)), c2_, "h2d");
+        check(tfhe_amd_modswitch(c2_, (int32_t *)d_b_, (const int32_t *)d_a_, 1), c2_, "modswitch");
+        check(tfhe_amd_memcpy_d2h(c2_, result, d_b_, sizeof(int) * (size_t)(p_.n0 + 1)), c2_, "d2h");
+    }
+    tfhe_amd_cb *handle() { return cb_; }
+
+   private:
+    void die(int rc, const char *what) {
+        if (rc != TFHE_AMD_OK) {
+            std::fprintf(stderr, "tfhe_amd: %s failed (%d): %s\n", what, rc, cb_ ? tfhe_amd_cb_last_error(cb_) : "");
+            std::abort();
+        }
+    }
+    PocEngine(const PocEngine &);
+    PocEngine &operator=(const PocEngine &);
+    tfhe_amd_cb *cb_;
+    tfhe_amd_cb_params p_;
+    tfhe_amd_ctx *c2_, *c10_;
+    void *d_a_, *d_b_;
+};
+
+}  // namespace tfhe_amd_compat
+#endif

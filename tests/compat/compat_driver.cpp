@@ -1,0 +1,265 @@
+// compat_driver.cpp -- test program for include/tfhe_amd_compat.hpp: builds the reference's
+// pointer-rich structs from flat arrays, calls the reference-named entry points, and dumps the
+// results for tests/test_compat.py to compare with the oracle.  Links against whichever library
+// implements the C ABI (the HIP library on a GPU box, the tests/emu build on the CPU).
+//
+//   compat_driver lib   <in.bin> <out.bin>     library-form functions + FFT plugin look-alike
+//   compat_driver poc   <in.bin> <out.bin>     PoC-form functions (PocEngine<Globals>)
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tfhe_amd_compat.hpp"
+
+using namespace tfhe_amd_compat;
+
+static std::vector<uint8_t> slurp(const char *path) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); exit(2); }
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> b((size_t)sz);
+    if (sz && fread(b.data(), 1, (size_t)sz, f) != (size_t)sz) { perror("read"); exit(2); }
+    fclose(f);
+    return b;
+}
+struct Out {
+    std::vector<uint8_t> buf;
+    void put(const void *p, size_t n) { buf.insert(buf.end(), (const uint8_t *)p, (const uint8_t *)p + n); }
+    void save(const char *path) {
+        FILE *f = fopen(path, "wb");
+        fwrite(buf.data(), 1, buf.size(), f);
+        fclose(f);
+    }
+};
+struct In {
+    const uint8_t *p;
+    template <class T> const T *take(size_t n) {
+        const T *r = (const T *)p;
+        p += sizeof(T) * n;
+        return r;
+    }
+};
+
+// ---------------------------------------------------------------- library form
+static int run_lib(const char *inp, const char *outp) {
+    auto blob = slurp(inp);
+    In in{blob.data()};
+    const int32_t *hdr = in.take<int32_t>(8);  // n N l Bgbit ks_t ks_bb count mu
+    const int n = hdr[0], N = hdr[1], l = hdr[2], Bgbit = hdr[3], t = hdr[4], bb = hdr[5], count = hdr[6];
+    const Torus32 mu = hdr[7];
+    const int kpl = 2 * l, base = 1 << bb;
+    const double *bkflat = in.take<double>((size_t)n * kpl * 2 * N);
+    const int32_t *ksflat = in.take<int32_t>((size_t)N * t * base * (n + 1));
+    const int32_t *xs = in.take<int32_t>((size_t)count * (n + 1));
+    const int32_t *rot = in.take<int32_t>((size_t)count * (n + 1));   // bara..., barb
+    const int32_t *accs = in.take<int32_t>((size_t)count * 2 * N);
+    const int32_t *v = in.take<int32_t>((size_t)N);
+
+    LweParams in_out{n, 0, 0};
+    TLweParams tlwe{N, 1, 0, 0, LweParams{N, 0, 0}};
+    TGswParams gp;
+    memset(&gp, 0, sizeof(gp));
+    gp.l = l;
+    gp.Bgbit = Bgbit;
+    gp.Bg = 1 << Bgbit;
+    gp.tlwe_params = &tlwe;
+    gp.kpl = kpl;
+    // TGswSampleFFT array of n samples, each kpl TLweSampleFFT rows of 2 LagrangeHalfC polynomials
+    std::vector<LagrangeHalfCPolynomial> polys((size_t)n * kpl * 2);
+    std::vector<TLweSampleFFT> rows((size_t)n * kpl);
+    std::vector<TGswSampleFFT> gsw((size_t)n);
+    for (int i = 0; i < n; i++) {
+        for (int r = 0; r < kpl; r++) {
+            for (int q = 0; q < 2; q++)
+                polys[((size_t)i * kpl + r) * 2 + q].values = (double *)bkflat + (((size_t)i * kpl + r) * 2 + q) * N;
+            TLweSampleFFT &row = rows[(size_t)i * kpl + r];
+            row.a = &polys[((size_t)i * kpl + r) * 2];
+            row.b = row.a + 1;
+            row.k = 1;
+        }
+        gsw[i].all_samples = &rows[(size_t)i * kpl];
+        gsw[i].sample = nullptr;
+        gsw[i].k = 1;
+        gsw[i].l = l;
+    }
+    // LweKeySwitchKey ks[N][t][base] of LweSample (n)
+    std::vector<LweSample> ks0((size_t)N * t * base);
+    std::vector<LweSample *> ks1((size_t)N * t);
+    std::vector<LweSample **> ks2((size_t)N);
+    for (size_t e = 0; e < ks0.size(); e++) {
+        ks0[e].a = (Torus32 *)ksflat + e * (n + 1);
+        ks0[e].b = ksflat[e * (n + 1) + n];
+    }
+    for (size_t e = 0; e < ks1.size(); e++) ks1[e] = &ks0[e * base];
+    for (int i = 0; i < N; i++) ks2[i] = &ks1[(size_t)i * t];
+    LweKeySwitchKey ksk{N, t, bb, base, &in_out, ks0.data(), ks1.data(), ks2.data()};
+    LweBootstrappingKeyFFT bk{&in_out, &gp, &tlwe, &tlwe.extracted_lweparams, gsw.data(), &ksk};
+
+    Out out;
+    std::vector<Torus32> ra((size_t)N + 1), rb((size_t)n + 1);
+    for (int c = 0; c < count; c++) {
+        LweSample x{(Torus32 *)xs + (size_t)c * (n + 1), xs[(size_t)c * (n + 1) + n], 0};
+        LweSample u{ra.data(), 0, 0}, r{rb.data(), 0, 0};
+        tfhe_bootstrap_woKS_FFT(&u, &bk, mu, &x);
+        out.put(u.a, 4 * (size_t)N);
+        out.put(&u.b, 4);
+        tfhe_bootstrap_FFT(&r, &bk, mu, &x);
+        out.put(r.a, 4 * (size_t)n);
+        out.put(&r.b, 4);
+        lweKeySwitch(&r, &ksk, &u);
+        out.put(r.a, 4 * (size_t)n);
+        out.put(&r.b, 4);
+        // blind rotate + extract with an explicit test vector
+        TorusPolynomial tv{N, (Torus32 *)v};
+        const int32_t *rt = rot + (size_t)c * (n + 1);
+        tfhe_blindRotateAndExtract_FFT(&u, &tv, gsw.data(), rt[n], (const int *)rt, n, &gp);
+        out.put(u.a, 4 * (size_t)N);
+        out.put(&u.b, 4);
+        // in-place blind rotation and external product on a TLWE sample
+        std::vector<Torus32> acc(accs + (size_t)c * 2 * N, accs + (size_t)(c + 1) * 2 * N);
+        TorusPolynomial ap[2] = {{N, acc.data()}, {N, acc.data() + N}};
+        TLweSample as{ap, ap + 1, 0, 1};
+        tfhe_blindRotate_FFT(&as, gsw.data(), (const int *)rt, n, &gp);
+        out.put(acc.data(), 4 * (size_t)2 * N);
+        std::vector<Torus32> acc2(accs + (size_t)c * 2 * N, accs + (size_t)(c + 1) * 2 * N);
+        TorusPolynomial ap2[2] = {{N, acc2.data()}, {N, acc2.data() + N}};
+        TLweSample as2{ap2, ap2 + 1, 0, 1};
+        tGswFFTExternMulToTLwe(&as2, &gsw[n - 1], &gp);
+        out.put(acc2.data(), 4 * (size_t)2 * N);
+    }
+    // FFT plugin look-alike on the first accumulator polynomial
+    {
+        FFT_Processor_AMD P(N);
+        std::vector<double> lag((size_t)N), lag2((size_t)N);
+        std::vector<int32_t> back((size_t)N);
+        P.execute_reverse_int(lag.data(), (const int *)accs);
+        out.put(lag.data(), 8 * (size_t)N);
+        P.execute_direct_torus32(back.data(), lag.data());
+        out.put(back.data(), 4 * (size_t)N);
+        P.execute_reverse_torus32(lag2.data(), accs + N);
+        P.AddMul(lag2.data(), lag.data(), bkflat);
+        out.put(lag2.data(), 8 * (size_t)N);
+        std::vector<int64_t> a64((size_t)N), b64((size_t)N);
+        for (int j = 0; j < N; j++) a64[j] = ((int64_t)accs[j] << 32) ^ (int64_t)accs[N + j];
+        P.execute_reverse_torus64(lag.data(), a64.data());
+        out.put(lag.data(), 8 * (size_t)N);
+        P.execute_direct_torus64(b64.data(), lag.data());
+        out.put(b64.data(), 8 * (size_t)N);
+    }
+    release_all();
+    out.save(outp);
+    return 0;
+}
+
+// ---------------------------------------------------------------- PoC form
+// mirrors of the member names of CB/poc_types.h (the real header works the same way)
+struct PLwe32 { int32_t *a; int32_t *b; };
+struct PLwe64 { int64_t *a; int64_t *b; };
+struct PPoly32 { int32_t *coefs; };
+struct PTLwe32 { PPoly32 *a; PPoly32 *b; };
+struct PTGsw32 { PTLwe32 **samples; PTLwe32 *allsamples; };
+struct PLag { double *values; };
+struct PTLweFFT { PLag *a; PLag *b; };
+struct PTGswFFT { PTLweFFT **samples; PTLweFFT *allsamples; };
+struct PGlobals {
+    int n_lvl0, n_lvl1, n_lvl2, bgbit_lvl1, ell_lvl1, bgbit_lvl2, ell_lvl2;
+    int kslength_lvl10, ksbasebit_lvl10, kslength_lvl21, ksbasebit_lvl21;
+    PLwe32 ***preKS;
+    PTGswFFT *bkFFT;
+    PTLwe32 ****privKS;
+};
+
+static int run_poc(const char *inp, const char *outp) {
+    auto blob = slurp(inp);
+    In in{blob.data()};
+    const int32_t *h = in.take<int32_t>(12);  // n0 N1 N2 l1 bg1 l2 bg2 t10 bb10 t21 bb21 count
+    PGlobals g;
+    g.n_lvl0 = h[0]; g.n_lvl1 = h[1]; g.n_lvl2 = h[2]; g.ell_lvl1 = h[3]; g.bgbit_lvl1 = h[4];
+    g.ell_lvl2 = h[5]; g.bgbit_lvl2 = h[6]; g.kslength_lvl10 = h[7]; g.ksbasebit_lvl10 = h[8];
+    g.kslength_lvl21 = h[9]; g.ksbasebit_lvl21 = h[10];
+    const int count = h[11];
+    const int n0 = h[0], N1 = h[1], N2 = h[2], l1 = h[3], l2 = h[5], t10 = h[7], b10 = 1 << h[8], t21 = h[9], b21 = 1 << h[10];
+    const int32_t *preks = in.take<int32_t>((size_t)N1 * t10 * b10 * (n0 + 1));
+    const double *bk = in.take<double>((size_t)n0 * 2 * l2 * 2 * N2);
+    const int32_t *priv = in.take<int32_t>((size_t)2 * (N2 + 1) * t21 * b21 * 2 * N1);
+    const int32_t *xs = in.take<int32_t>((size_t)count * (N1 + 1));
+    const int64_t *x64 = in.take<int64_t>((size_t)count * (N2 + 1));
+    // pointer structures
+    std::vector<PLwe32> pk0((size_t)N1 * t10 * b10);
+    std::vector<PLwe32 *> pk1((size_t)N1 * t10);
+    std::vector<PLwe32 **> pk2((size_t)N1);
+    for (size_t e = 0; e < pk0.size(); e++) { pk0[e].a = (int32_t *)preks + e * (n0 + 1); pk0[e].b = pk0[e].a + n0; }
+    for (size_t e = 0; e < pk1.size(); e++) pk1[e] = &pk0[e * b10];
+    for (int i = 0; i < N1; i++) pk2[i] = &pk1[(size_t)i * t10];
+    g.preKS = pk2.data();
+    std::vector<PLag> lag((size_t)n0 * 2 * l2 * 2);
+    std::vector<PTLweFFT> frow((size_t)n0 * 2 * l2);
+    std::vector<PTGswFFT> fg((size_t)n0);
+    for (size_t e = 0; e < lag.size(); e++) lag[e].values = (double *)bk + e * N2;
+    for (size_t e = 0; e < frow.size(); e++) { frow[e].a = &lag[e * 2]; frow[e].b = frow[e].a + 1; }
+    for (int i = 0; i < n0; i++) { fg[i].allsamples = &frow[(size_t)i * 2 * l2]; fg[i].samples = nullptr; }
+    g.bkFFT = fg.data();
+    const size_t nrow = (size_t)2 * (N2 + 1) * t21 * b21;
+    std::vector<PPoly32> pp(nrow * 2);
+    std::vector<PTLwe32> pr(nrow);
+    for (size_t e = 0; e < pp.size(); e++) pp[e].coefs = (int32_t *)priv + e * N1;
+    for (size_t e = 0; e < nrow; e++) { pr[e].a = &pp[e * 2]; pr[e].b = pr[e].a + 1; }
+    std::vector<PTLwe32 *> pr1((size_t)2 * (N2 + 1) * t21);
+    std::vector<PTLwe32 **> pr2((size_t)2 * (N2 + 1));
+    std::vector<PTLwe32 ***> pr3(2);
+    for (size_t e = 0; e < pr1.size(); e++) pr1[e] = &pr[e * b21];
+    for (size_t e = 0; e < pr2.size(); e++) pr2[e] = &pr1[e * t21];
+    for (int u = 0; u < 2; u++) pr3[u] = &pr2[(size_t)u * (N2 + 1)];
+    g.privKS = pr3.data();
+
+    PocEngine<PGlobals> eng(&g);
+    Out out;
+    for (int c = 0; c < count; c++) {
+        PLwe32 x{(int32_t *)xs + (size_t)c * (N1 + 1), nullptr};
+        // preKeySwitch + preModSwitch
+        std::vector<int32_t> pre((size_t)n0 + 1);
+        std::vector<int> abar((size_t)n0 + 1);
+        PLwe32 pres{pre.data(), pre.data() + n0};
+        eng.preKeySwitch(&pres, &x);
+        eng.preModSwitch(abar.data(), &pres);
+        out.put(pre.data(), 4 * pre.size());
+        out.put(abar.data(), 4 * abar.size());
+        // circuitBootstrapWoKS + circuitPrivKS
+        std::vector<int64_t> boot((size_t)N2 + 1);
+        PLwe64 bs{boot.data(), boot.data() + N2};
+        eng.circuitBootstrapWoKS(&bs, (int64_t)1 << 56, abar.data());
+        out.put(boot.data(), 8 * boot.size());
+        PLwe64 xin{(int64_t *)x64 + (size_t)c * (N2 + 1), nullptr};
+        std::vector<int32_t> tl((size_t)2 * N1);
+        PPoly32 tp[2] = {{tl.data()}, {tl.data() + N1}};
+        PTLwe32 tls{tp, tp + 1};
+        eng.circuitPrivKS(&tls, 1, &xin);
+        out.put(tl.data(), 4 * tl.size());
+        // the whole circuit bootstrap
+        std::vector<int32_t> res((size_t)2 * l1 * 2 * N1);
+        std::vector<PPoly32> rp((size_t)2 * l1 * 2);
+        std::vector<PTLwe32> rr((size_t)2 * l1);
+        std::vector<PTLwe32 *> rs(2);
+        for (size_t e = 0; e < rp.size(); e++) rp[e].coefs = res.data() + e * N1;
+        for (size_t e = 0; e < rr.size(); e++) { rr[e].a = &rp[e * 2]; rr[e].b = rr[e].a + 1; }
+        for (int u = 0; u < 2; u++) rs[u] = &rr[(size_t)u * l1];
+        PTGsw32 tg{rs.data(), rr.data()};
+        eng.tfhe_CircuitBootstrapFFT(&tg, &x);
+        out.put(res.data(), 4 * res.size());
+    }
+    out.save(outp);
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc != 4) {
+        fprintf(stderr, "usage: %s lib|poc in.bin out.bin\n", argv[0]);
+        return 2;
+    }
+    return std::string(argv[1]) == "lib" ? run_lib(argv[2], argv[3]) : run_poc(argv[2], argv[3]);
+}

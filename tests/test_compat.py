@@ -1,0 +1,139 @@
+"""include/tfhe_amd_compat.hpp: the reference-named C++ entry points (tfhe_bootstrap_FFT,
+tfhe_blindRotateAndExtract_FFT, tGswFFTExternMulToTLwe, lweKeySwitch, the FFT processor look-alike,
+and the PoC's tfhe_CircuitBootstrapFFT / circuitBootstrapWoKS / circuitPrivKS / preKeySwitch /
+preModSwitch) give the oracle's results.  The C++ driver (tests/compat/compat_driver.cpp) is
+linked against the tests/emu build here; on a GPU box the same driver links against the HIP
+library (test_compat_gpu)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = 0x5446484500000001
+
+
+def build_driver(lib_path, tag):
+    out = os.path.join(ROOT, "tests", "emu", "_build", f"compat_driver_{tag}")
+    src = os.path.join(ROOT, "tests", "compat", "compat_driver.cpp")
+    hdr = os.path.join(ROOT, "include", "tfhe_amd_compat.hpp")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if (not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr),
+                                                                os.path.getmtime(lib_path))):
+        libdir, libname = os.path.dirname(lib_path), os.path.basename(lib_path)
+        subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+                               "-L" + libdir, "-l:" + libname, "-Wl,-rpath," + libdir, "-lpthread"])
+    return out
+
+
+def run_lib_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=2):
+    rs = np.random.RandomState(7)
+    lk, tk = O.keygen_binary(n, SEED, 1), O.keygen_binary(N, SEED, 2)
+    bk = O.bk_create32(N, lk, tk, l, Bgbit, 2.0 ** -25, SEED, 1000)
+    ks = O.ks_create32(tk, lk, t, bb, 2.0 ** -15, SEED, 100000)
+    mu = 1 << 29
+    x = np.stack([O.lwe_encrypt32(mu if i % 2 else -mu, 2.0 ** -15, lk, O.rng(SEED, 40 + i)) for i in range(count)])
+    rot = rs.randint(0, 2 * N, size=(count, n + 1)).astype(np.int32)
+    acc = rs.randint(-2 ** 31, 2 ** 31, size=(count, 2, N)).astype(np.int32)
+    v = rs.randint(-2 ** 31, 2 ** 31, size=N).astype(np.int32)
+    hdr = np.array([n, N, l, Bgbit, t, bb, count, mu], np.int32)
+    fi, fo = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fi, "wb") as f:
+        for a in (hdr, bk, ks, x, rot, acc, v):
+            f.write(np.ascontiguousarray(a).tobytes())
+    subprocess.check_call([driver, "lib", fi, fo])
+    raw = open(fo, "rb").read()
+    pos = 0
+
+    def take(dtype, cnt):
+        nonlocal pos
+        a = np.frombuffer(raw, dtype=dtype, count=cnt, offset=pos)
+        pos += a.nbytes
+        return a
+
+    for c in range(count):
+        woks = O.bootstrap_woks32(N, bk, mu, x[c], l, Bgbit)
+        assert np.array_equal(take(np.int32, N + 1), woks), "tfhe_bootstrap_woKS_FFT"
+        full = O.bootstrap32(N, bk, ks, mu, x[c], l, Bgbit, t, bb)
+        assert np.array_equal(take(np.int32, n + 1), full), "tfhe_bootstrap_FFT"
+        assert np.array_equal(take(np.int32, n + 1), O.keyswitch32(ks, woks, N, n, t, bb)), "lweKeySwitch"
+        assert np.array_equal(take(np.int32, N + 1),
+                              O.blind_rotate_extract32(N, v, bk, rot[c, n], rot[c, :n], l, Bgbit)), "blindRotateAndExtract"
+        assert np.array_equal(take(np.int32, 2 * N), O.blind_rotate32(N, acc[c], bk, rot[c, :n], l, Bgbit).ravel()), "blindRotate"
+        assert np.array_equal(take(np.int32, 2 * N), O.extprod32(N, acc[c], bk[n - 1], l, Bgbit).ravel()), "tGswFFTExternMulToTLwe"
+    lag = O.execute_reverse_int(N, acc[0, 0])
+    assert np.array_equal(take(np.float64, N).view(np.uint64), lag.view(np.uint64)), "execute_reverse_int"
+    assert np.array_equal(take(np.int32, N), O.execute_direct_torus32(N, lag)), "execute_direct_torus32"
+    want = O.lagrange_addmul(N, O.execute_reverse_int(N, acc[0, 1]), lag, bk[0, 0, 0])
+    assert np.array_equal(take(np.float64, N).view(np.uint64), want.view(np.uint64)), "AddMul"
+    a64 = (acc[0, 0].astype(np.int64) << 32) ^ acc[0, 1].astype(np.int64)
+    l64 = O.execute_reverse_torus64(N, a64)
+    assert np.array_equal(take(np.float64, N).view(np.uint64), l64.view(np.uint64)), "execute_reverse_torus64"
+    assert np.array_equal(take(np.int64, N), O.execute_direct_torus64(N, l64)), "execute_direct_torus64"
+    assert pos == len(raw)
+
+
+def run_poc_form(driver, tmp_path, n0=3, N1=1024, N2=1024, l1=2, bg1=8, l2=3, bg2=10, t10=3, bb10=2, t21=2, bb21=2,
+                 count=2):
+    rs = np.random.RandomState(8)
+    key0, key2 = O.keygen_binary(n0, SEED, 21), O.keygen_binary(N2, SEED, 23)
+    bk = O.bk_create64(N2, key0, key2, l2, bg2, 2.0 ** -44, SEED, 3000)
+    preks = O.fill32(303, N1 * t10 * (1 << bb10) * (n0 + 1)).reshape(N1, t10, 1 << bb10, n0 + 1)
+    privks = O.fill32(404, 2 * (N2 + 1) * t21 * (1 << bb21) * 2 * N1).reshape(2, N2 + 1, t21, 1 << bb21, 2, N1)
+    x = rs.randint(-2 ** 31, 2 ** 31, size=(count, N1 + 1)).astype(np.int32)
+    x64 = rs.randint(-2 ** 63, 2 ** 63 - 1, size=(count, N2 + 1), dtype=np.int64)
+    hdr = np.array([n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, count], np.int32)
+    fi, fo = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fi, "wb") as f:
+        for a in (hdr, preks, bk, privks, x, x64):
+            f.write(np.ascontiguousarray(a).tobytes())
+    subprocess.check_call([driver, "poc", fi, fo])
+    raw = open(fo, "rb").read()
+    pos = 0
+
+    def take(dtype, cnt):
+        nonlocal pos
+        a = np.frombuffer(raw, dtype=dtype, count=cnt, offset=pos)
+        pos += a.nbytes
+        return a
+
+    for c in range(count):
+        pre = O.keyswitch32(preks, x[c], N1, n0, t10, bb10)
+        assert np.array_equal(take(np.int32, n0 + 1), pre), "preKeySwitch"
+        abar = O.pre_modswitch(pre, N2)
+        assert np.array_equal(take(np.int32, n0 + 1), abar), "preModSwitch"
+        assert np.array_equal(take(np.int64, N2 + 1), O.cb_bootstrap_woks64(N2, 1 << 56, abar, bk, l2, bg2)), "circuitBootstrapWoKS"
+        assert np.array_equal(take(np.int32, 2 * N1), O.privks(privks[1], x64[c], N2, N1, t21, bb21)), "circuitPrivKS"
+        want = O.circuit_bootstrap(x[c], preks, bk, privks, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21)
+        assert np.array_equal(take(np.int32, 2 * l1 * 2 * N1), want.ravel()), "tfhe_CircuitBootstrapFFT"
+    assert pos == len(raw)
+
+
+def test_library_form_shims_emu(emu_lib, tmp_path):
+    run_lib_form(build_driver(emu_lib, "emu"), tmp_path)
+
+
+def test_poc_form_shims_emu(emu_lib, tmp_path):
+    run_poc_form(build_driver(emu_lib, "emu"), tmp_path)
+
+
+@pytest.fixture(scope="module")
+def gpu_driver():
+    """built at collection-independent time, BEFORE any GPU use in this process (no fork/exec after
+    GPU init); the driver itself is a separate process"""
+    import importlib
+    T = importlib.import_module("experimental-tfhe_amd")
+    return build_driver(T.DEFAULT_LIB, "hip")
+
+
+@pytest.mark.gpu
+def test_library_form_shims_gpu(gpu_driver, tmp_path):
+    run_lib_form(gpu_driver, tmp_path, n=16, count=3)
+
+
+@pytest.mark.gpu
+def test_poc_form_shims_gpu(gpu_driver, tmp_path):
+    run_poc_form(gpu_driver, tmp_path, n0=8, N2=2048, l2=4, bg2=9, t21=2, bb21=3, count=2)
