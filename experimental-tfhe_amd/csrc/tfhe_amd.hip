@@ -140,10 +140,10 @@ int set_lds(tfhe_amd_ctx *c, KernelT kernel, size_t bytes) {
 }
 
 // one instantiation per (torus, N): waves per workgroup chosen so LDS fits 160 KiB
-template <typename T, int LOGN, int WAVES>
+template <typename T, int LOGN, int WAVES, int PAIR>
 int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
     using Lds = BlindRotateLds<T, LOGN, WAVES>;
-    auto kernel = k_blind_rotate<T, LOGN, WAVES>;
+    auto kernel = k_blind_rotate<T, LOGN, WAVES, PAIR>;
     static bool configured = false;  // per process; the attribute is per function
     if (!configured) {
         int rc = set_lds(c, kernel, Lds::total);
@@ -151,15 +151,17 @@ int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
         configured = true;
     }
     const int blocks = (a.batch + WAVES - 1) / WAVES;
-    TFHE_LAUNCH((k_blind_rotate<T, LOGN, WAVES>), dim3(blocks), dim3(WAVES * 64), Lds::total, c->stream, a);
+    TFHE_LAUNCH((k_blind_rotate<T, LOGN, WAVES, PAIR>), dim3(blocks), dim3(WAVES * 64), Lds::total, c->stream, a);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
 int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
-    return c->logn == 10 ? launch_br_t<int32_t, 10, 8>(c, a) : launch_br_t<int32_t, 11, 4>(c, a);
+    // N=1024/Torus32: 2 waves per SIMD (256 VGPRs): digits in pairs.  PPL=16 shapes transform
+    // one digit at a time (a pair would need 128 more registers than the file has).
+    return c->logn == 10 ? launch_br_t<int32_t, 10, 8, 2>(c, a) : launch_br_t<int32_t, 11, 4, 1>(c, a);
 }
 int launch_br64(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
-    return c->logn == 10 ? launch_br_t<int64_t, 10, 4>(c, a) : launch_br_t<int64_t, 11, 3>(c, a);
+    return c->logn == 10 ? launch_br_t<int64_t, 10, 4, 2>(c, a) : launch_br_t<int64_t, 11, 3, 1>(c, a);
 }
 
 template <typename TIN, int LOGN>

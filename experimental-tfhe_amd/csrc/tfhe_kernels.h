@@ -372,6 +372,46 @@ TFHE_DEVICE void mac_row(double (&fr)[2][PPL], double (&fi)[2][PPL], const doubl
     }
 }
 
+// ND consecutive gadget digits (d .. d+ND-1) of one accumulator polynomial: extract, transform
+// together, multiply-accumulate with their key rows in digit order (the MAC chain is sequential in
+// the row index: lagrangehalfc AddMul accumulates in place, tgsw_functions.cpp:441-443).
+template <typename T, int LOGN, int ND>
+TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int row0, int d0,
+                                 const typename Torus<T>::U (&lo)[Geom<LOGN>::PPL],
+                                 const typename Torus<T>::U (&hi)[Geom<LOGN>::PPL], const Gadget &gd,
+                                 double (&fr)[2][Geom<LOGN>::PPL], double (&fi)[2][Geom<LOGN>::PPL], int t) {
+    using U = typename Torus<T>::U;
+    constexpr int PPL = Geom<LOGN>::PPL;
+    const U mask = ((U)1 << gd.Bgbit) - 1;
+    const int32_t halfBg = 1 << (gd.Bgbit - 1);
+    double2 bk[2][PPL];  // key row of the first digit, fetched underneath the transform
+#pragma unroll
+    for (int qq = 0; qq < 2; qq++)
+#pragma unroll
+        for (int m = 0; m < PPL; m++) bk[qq][m] = bkrow[((row0 * 2 + qq) * PPL + m) * 64 + t];
+    double xr[ND][PPL], xi[ND][PPL];
+#pragma unroll
+    for (int e = 0; e < ND; e++) {
+        const int decal = Torus<T>::BITS - (d0 + e + 1) * gd.Bgbit;
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            xr[e][m] = (double)((int32_t)((lo[m] >> decal) & mask) - halfBg);
+            xi[e][m] = (double)((int32_t)((hi[m] >> decal) & mask) - halfBg);
+        }
+    }
+    WaveFFT<LOGN>::template ifft<ND>(xr, xi, w.tw, w.xch, t);
+#pragma unroll
+    for (int e = 0; e < ND; e++) {
+        if (e > 0) {
+#pragma unroll
+            for (int qq = 0; qq < 2; qq++)
+#pragma unroll
+                for (int m = 0; m < PPL; m++) bk[qq][m] = bkrow[(((row0 + e) * 2 + qq) * PPL + m) * 64 + t];
+        }
+        mac_row<PPL>(fr, fi, xr[e], xi[e], bk);
+    }
+}
+
 // One CMux step on the wave's accumulator:
 //   rotate:  acc <- bk_row (x) ((X^a - 1) * acc) + acc   (tfhe_MuxRotate_FFT, a != 0)
 //   !rotate: acc <- bk_row (x) acc                       (tGswFFTExternMulToTLwe)
@@ -379,15 +419,13 @@ TFHE_DEVICE void mac_row(double (&fr)[2][PPL], double (&fi)[2][PPL], const doubl
 // The 2l inverse transforms run one at a time (their key row is prefetched into registers
 // under the transform); the two forward transforms run together, in place on the Fourier
 // accumulator, sharing every twiddle read.
-template <typename T, int LOGN>
+template <typename T, int LOGN, int PAIR>
 TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
                            const Gadget &gd, int t) {
     using G = Geom<LOGN>;
     using U = typename Torus<T>::U;
     constexpr int PPL = G::PPL, N = G::N, NC = G::NC;
     const U offset = (U)gd.offset;
-    const U mask = ((U)1 << gd.Bgbit) - 1;
-    const int32_t halfBg = 1 << (gd.Bgbit - 1);
 
     double fr[2][PPL], fi[2][PPL];  // Fourier accumulator (tLweFFTClear)
 #pragma unroll
@@ -415,22 +453,14 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
             }
         }
 #pragma unroll 1
-        for (int d = 0; d < gd.l; d++) {
-            const int row = q * gd.l + d;  // p = bloc*l + i  (tgsw_functions.cpp:435-443)
-            double2 bk[2][PPL];
-#pragma unroll
-            for (int qq = 0; qq < 2; qq++)
-#pragma unroll
-                for (int m = 0; m < PPL; m++) bk[qq][m] = bkrow[((row * 2 + qq) * PPL + m) * 64 + t];
-            const int decal = Torus<T>::BITS - (d + 1) * gd.Bgbit;
-            double xr[1][PPL], xi[1][PPL];
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                xr[0][m] = (double)((int32_t)((lo[m] >> decal) & mask) - halfBg);
-                xi[0][m] = (double)((int32_t)((hi[m] >> decal) & mask) - halfBg);
+        for (int d = 0; d < gd.l; d += PAIR) {
+            // p = bloc*l + i  (tgsw_functions.cpp:435-443); PAIR = 2: digits d, d+1 transformed
+            // together (one twiddle read serves both); a trailing odd digit goes alone
+            if (PAIR == 2 && d + 1 < gd.l) {
+                ifft_mac_digits<T, LOGN, 2>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
+            } else {
+                ifft_mac_digits<T, LOGN, 1>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
             }
-            WaveFFT<LOGN>::template ifft<1>(xr, xi, w.tw, w.xch, t);
-            mac_row<PPL>(fr, fi, xr[0], xi[0], bk);
         }
     }
     // back to coefficients (both polynomials together), round, accumulate into acc
@@ -509,7 +539,7 @@ struct BlindRotateLds {
 #define TFHE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
-template <typename T, int LOGN, int WAVES>
+template <typename T, int LOGN, int WAVES, int PAIR>
 TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T> A) {
     using G = Geom<LOGN>;
     using U = typename Torus<T>::U;
@@ -573,7 +603,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             a = TFHE_UNIFORM(a);
             if (a == 0) continue;  // :348-350
         }
-        cmux_step<T, LOGN>(w, bkrow, a, rotate, A.gd, t);
+        cmux_step<T, LOGN, PAIR>(w, bkrow, a, rotate, A.gd, t);
     }
 
     // ---- output
