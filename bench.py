@@ -46,7 +46,9 @@ FLOP_PER_CMUX = 173056
 def cpu_baseline(cfg, seconds=10.0):
     """bounded CPU sample on this host: returns the cpu_baseline object"""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    cores = os.cpu_count() or 1
+    # one single-threaded process per core, ~125 MB each (key tables); capped so a many-core host
+    # cannot be pushed into memory pressure by a baseline measurement
+    cores = min(os.cpu_count() or 1, 64)
     if os.path.exists(ref) and os.access(ref, os.X_OK) and cfg.N == 1024:
         args = [ref, "bench32", "/dev/null", "/dev/null", str(cfg.n), str(cfg.l), str(cfg.Bgbit), str(cfg.ks_t),
                 str(cfg.ks_basebit), str(int(seconds))]

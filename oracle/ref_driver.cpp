@@ -384,7 +384,9 @@ int main(int argc, char **argv) {
         offset *= 1u << (Bgbit - 1);
         const uint32_t mask = (1u << Bgbit) - 1;
         const int32_t halfBg = 1 << (Bgbit - 1);
-        std::vector<int32_t> acc(2 * N), tmp(2 * N), deca((size_t)kpl * N), u(N + 1), out(count * (n + 1));
+        // bench32 keeps one output row (its `count` is only a loop bound: never size a buffer by it)
+        std::vector<int32_t> acc(2 * N), tmp(2 * N), deca((size_t)kpl * N), u(N + 1),
+            out((op == "boot32" ? count : 1) * (size_t)(n + 1));
         std::vector<double> decaF((size_t)kpl * N), tmpa(2 * N);
         auto modsw = [&](int32_t ph) { return (int)((((uint64_t)(uint32_t)ph << 32) + (1ull << 52)) >> 53); };
         struct timespec t0, t1;
