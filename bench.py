@@ -20,6 +20,11 @@ The JSON line also carries
                 (oracle/_ref/ref_driver bench32), one process per host core, bounded to ~10 s;
                 falls back to the C oracle ("port") where the reference binary is absent.
 Only that cpu_baseline leg touches oracle/.
+
+Process hygiene on the GPU pool: every child process (library build, CPU baseline) is spawned
+BEFORE this process touches the GPU; the single-GPU path does not import torch at all (device
+memory, stream and HIP events come through the engine's own C ABI); with N > 1 torch is imported
+first -- before the engine library is loaded -- so that one HIP runtime serves both.
 """
 import argparse
 import importlib
@@ -89,78 +94,78 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    T = importlib.import_module("experimental-tfhe_amd")
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    T = importlib.import_module("experimental-tfhe_amd")  # pure python so far: nothing dlopen'ed yet
     shard = importlib.import_module("experimental-tfhe_amd.shard")
     cfg = shard.GateConfig()
-    # Everything that spawns a child process happens HERE, before this process initialises the
-    # GPU (a fork/exec from a GPU-initialised process is not allowed on the GPU pool):
-    # the library build if missing, and the CPU baseline (rank 0, single-GPU runs only).
+    # ---- children first (see module docstring)
     if not os.path.exists(T.DEFAULT_LIB):
         importlib.import_module("experimental-tfhe_amd.build").build()
     cpu_line = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu_line = cpu_baseline(cfg, a.cpu_seconds)
 
-    import torch
-    import torch.distributed as dist
+    dist = None
     if world > 1:
+        import torch  # BEFORE the engine library: one HIP runtime in the process
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        dev = torch.device("cuda", local)
 
-    job = shard.GateJob(cfg, SEED, device=local)  # identical key replicas on every rank
+    try:
+        job = shard.GateJob(cfg, SEED, device=local)  # identical key replicas on every rank
+    except T.TfheAmdError as e:
+        raise SystemExit(f"bench.py needs a GPU: the engine has no CPU path ({e})")
     eng, lib = job.eng, job.eng.lib
-    stream = torch.cuda.Stream(device=dev)
-    eng.set_stream(stream.cuda_stream)
 
     B = a.batch
     x_host = shard.synthetic_samples(cfg, B, seed=1234 + rank)
     # a few real encryptions at the front: decrypt-checked after the timed region
     msgs = [(1 << 29) if (i & 1) else -(1 << 29) for i in range(16)]
     x_host[:16] = job.encrypt(msgs)
-    with torch.cuda.stream(stream):
-        x_d = torch.from_numpy(x_host).to(dev)
-        u_d = torch.empty((B, cfg.N + 1), dtype=torch.int32, device=dev)
-        out_d = torch.empty((B, cfg.n + 1), dtype=torch.int32, device=dev)
+    x_d = eng.to_device(x_host)                     # inputs resident in HBM before timing
+    u_d = eng.alloc(B * (cfg.N + 1) * 4)
+    out_d = eng.alloc(B * (cfg.n + 1) * 4)
     mu = 1 << 29
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
+    ev = [[eng.event() for _ in range(3)] for _ in range(a.steps)]
 
     def step(k=None):
         if k is not None:
-            ev[k][0].record(stream)
-        eng._chk(lib.tfhe_amd_bootstrap_woks(eng.ctx, u_d.data_ptr(), mu, x_d.data_ptr(), B))
+            eng.record(ev[k][0])
+        eng._chk(lib.tfhe_amd_bootstrap_woks(eng.ctx, u_d.ptr, mu, x_d.ptr, B))
         if k is not None:
-            ev[k][1].record(stream)
-        eng._chk(lib.tfhe_amd_keyswitch(eng.ctx, out_d.data_ptr(), u_d.data_ptr(), B))
+            eng.record(ev[k][1])
+        eng._chk(lib.tfhe_amd_keyswitch(eng.ctx, out_d.ptr, u_d.ptr, B))
         if k is not None:
-            ev[k][2].record(stream)
+            eng.record(ev[k][2])
+
+    def fence():
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+            import torch
+            torch.cuda.synchronize()
+            eng.sync()
 
     for _ in range(a.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(k)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dev)
+    if dist is not None:
+        elapsed = shard.max_over_ranks(elapsed, dev)
 
     # outside the timed region: the real encryptions must decrypt to their sign
-    out = out_d[:16].cpu().numpy()
+    out = out_d.download(np.int32, (B, cfg.n + 1))[:16]
     ok = all((job.phase(out[i]) > 0) == (msgs[i] > 0) for i in range(16))
-    br_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(a.steps)]))
-    ks_ms = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(a.steps)]))
+    br_ms = float(np.mean([eng.elapsed_ms(ev[k][0], ev[k][1]) for k in range(a.steps)]))
+    ks_ms = float(np.mean([eng.elapsed_ms(ev[k][1], ev[k][2]) for k in range(a.steps)]))
 
     if rank == 0:
         total = B * world * a.steps
@@ -195,7 +200,7 @@ def main():
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
     job.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
     if not ok:
         raise SystemExit("decrypt check failed")

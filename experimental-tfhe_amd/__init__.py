@@ -23,6 +23,7 @@ OK, ERR_PARAM, ERR_DEVICE, ERR_STATE, ERR_ALLOC = range(5)
 ABI_SYMBOLS = [
     "tfhe_amd_ctx_create", "tfhe_amd_ctx_destroy", "tfhe_amd_last_error", "tfhe_amd_version",
     "tfhe_amd_set_stream", "tfhe_amd_sync", "tfhe_amd_get_tables",
+    "tfhe_amd_event_create", "tfhe_amd_event_record", "tfhe_amd_event_elapsed_ms", "tfhe_amd_event_destroy",
     "tfhe_amd_malloc", "tfhe_amd_free", "tfhe_amd_memcpy_h2d", "tfhe_amd_memcpy_d2h",
     "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
     "tfhe_amd_set_bootstrap_key", "tfhe_amd_load_keyswitch_key",
@@ -79,6 +80,10 @@ def load_library(path=None):
     lib.tfhe_amd_set_stream.argtypes = [vp, vp]
     lib.tfhe_amd_sync.argtypes = [vp]
     lib.tfhe_amd_get_tables.argtypes = [vp, f64p, f64p]
+    lib.tfhe_amd_event_create.argtypes = [vp, C.POINTER(vp)]
+    lib.tfhe_amd_event_record.argtypes = [vp, vp]
+    lib.tfhe_amd_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
+    lib.tfhe_amd_event_destroy.argtypes = [vp, vp]
     lib.tfhe_amd_malloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
     lib.tfhe_amd_free.argtypes = [vp, vp]
     lib.tfhe_amd_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
@@ -215,6 +220,19 @@ class Engine:
 
     def sync(self):
         self._chk(self.lib.tfhe_amd_sync(self.ctx))
+
+    def event(self):
+        e = C.c_void_p()
+        self._chk(self.lib.tfhe_amd_event_create(self.ctx, C.byref(e)))
+        return e
+
+    def record(self, ev):
+        self._chk(self.lib.tfhe_amd_event_record(self.ctx, ev))
+
+    def elapsed_ms(self, start, stop):
+        ms = C.c_float()
+        self._chk(self.lib.tfhe_amd_event_elapsed_ms(self.ctx, start, stop, C.byref(ms)))
+        return float(ms.value)
 
     def set_stream(self, stream_ptr):
         self._chk(self.lib.tfhe_amd_set_stream(self.ctx, stream_ptr))

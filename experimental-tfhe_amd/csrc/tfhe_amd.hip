@@ -382,6 +382,30 @@ int tfhe_amd_sync(tfhe_amd_ctx *c) {
     return TFHE_AMD_OK;
 }
 
+int tfhe_amd_event_create(tfhe_amd_ctx *c, void **event) {
+    if (!c || !event) return TFHE_AMD_ERR_PARAM;
+    hipEvent_t e;
+    HIPCHECK(c, hipEventCreate(&e));
+    *event = (void *)e;
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_event_record(tfhe_amd_ctx *c, void *event) {
+    if (!c || !event) return TFHE_AMD_ERR_PARAM;
+    HIPCHECK(c, hipEventRecord((hipEvent_t)event, c->stream));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_event_elapsed_ms(tfhe_amd_ctx *c, void *start, void *stop, float *ms) {
+    if (!c || !start || !stop || !ms) return TFHE_AMD_ERR_PARAM;
+    HIPCHECK(c, hipEventSynchronize((hipEvent_t)stop));
+    HIPCHECK(c, hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_event_destroy(tfhe_amd_ctx *c, void *event) {
+    if (!c) return TFHE_AMD_ERR_PARAM;
+    if (event) HIPCHECK(c, hipEventDestroy((hipEvent_t)event));
+    return TFHE_AMD_OK;
+}
+
 int tfhe_amd_get_tables(const tfhe_amd_ctx *c, double *fft_trig, double *ifft_trig) {
     if (!c) return TFHE_AMD_ERR_PARAM;
     if (fft_trig) memcpy(fft_trig, c->fft_trig.data(), c->fft_trig.size() * 8);

@@ -69,6 +69,13 @@ const char *tfhe_amd_version(void);
 /* use an existing hipStream_t (passed as void*); NULL = the context's own stream */
 int tfhe_amd_set_stream(tfhe_amd_ctx *ctx, void *hip_stream);
 int tfhe_amd_sync(tfhe_amd_ctx *ctx);
+/* HIP events on the context's stream, for timing kernels without a HIP binding in the host
+ * language: create, record (asynchronous), elapsed milliseconds between two recorded events
+ * (waits for `stop`), destroy */
+int tfhe_amd_event_create(tfhe_amd_ctx *ctx, void **event);
+int tfhe_amd_event_record(tfhe_amd_ctx *ctx, void *event);
+int tfhe_amd_event_elapsed_ms(tfhe_amd_ctx *ctx, void *start, void *stop, float *ms);
+int tfhe_amd_event_destroy(tfhe_amd_ctx *ctx, void *event);
 /* twiddle tables as the reference lays them out (new_fft_table / new_ifft_table,
  * CB/spqlios/spqlios-fft-impl.cpp:158-193,400-437): 2N-8 doubles each; for SHA pinning. */
 int tfhe_amd_get_tables(const tfhe_amd_ctx *ctx, double *fft_trig, double *ifft_trig);

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <sys/mman.h>
+#include <time.h>
 #include <ucontext.h>
 
 #include <algorithm>
@@ -177,6 +178,12 @@ void launch_flat(const std::function<void()> &body, Dim3 grid, Dim3 block) {
 }
 
 }  // namespace emu
+
+double emu_now_ms() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 hipError_t hipMalloc(void **p, size_t bytes) {
     // exact size: ASan then flags any out-of-bounds device-pointer access made by a kernel
