@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="bootstraps per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--br-variant", type=int, default=0,
+                    help="TFHE_AMD_OPT_BR_VARIANT: 0 default schedule, 1 register twiddles (1 wave/SIMD), 2 unpaired digits")
+    ap.add_argument("--ks-gather", action="store_true", help="per-sample gather key switch instead of the tiled one")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,6 +123,8 @@ def main():
     except T.TfheAmdError as e:
         raise SystemExit(f"bench.py needs a GPU: the engine has no CPU path ({e})")
     eng, lib = job.eng, job.eng.lib
+    eng.set_option(T.OPT_BR_VARIANT, a.br_variant)
+    eng.set_option(T.OPT_KS_GATHER, int(a.ks_gather))
 
     B = a.batch
     x_host = shard.synthetic_samples(cfg, B, seed=1234 + rank)
@@ -187,7 +192,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"batch {B} gate bootstraps per GPU per step, {cfg.describe()}, persistent "
                                    "blind-rotation kernel + key-switch kernel, inputs resident in HBM",
-                       "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, keys replicated"},
+                       "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, keys replicated",
+                       "br_variant": a.br_variant, "ks_kernel": "gather" if a.ks_gather else "tiled"},
             "roofline": {"bound": "hbm", "kernel": "k_blind_rotate<int32,N=1024>", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
                          "kernel_ms": br_ms, "algorithmic_bytes_per_launch": algo_bytes,

@@ -18,11 +18,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libtfhe_amd.so")
 
 OK, ERR_PARAM, ERR_DEVICE, ERR_STATE, ERR_ALLOC = range(5)
+OPT_BR_VARIANT, OPT_KS_GATHER = 1, 2
 
 # every symbol include/tfhe_amd.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "tfhe_amd_ctx_create", "tfhe_amd_ctx_destroy", "tfhe_amd_last_error", "tfhe_amd_version",
-    "tfhe_amd_set_stream", "tfhe_amd_sync", "tfhe_amd_get_tables",
+    "tfhe_amd_set_stream", "tfhe_amd_sync", "tfhe_amd_set_option", "tfhe_amd_get_tables",
     "tfhe_amd_event_create", "tfhe_amd_event_record", "tfhe_amd_event_elapsed_ms", "tfhe_amd_event_destroy",
     "tfhe_amd_malloc", "tfhe_amd_free", "tfhe_amd_memcpy_h2d", "tfhe_amd_memcpy_d2h",
     "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
@@ -79,6 +80,7 @@ def load_library(path=None):
     lib.tfhe_amd_version.restype = C.c_char_p
     lib.tfhe_amd_set_stream.argtypes = [vp, vp]
     lib.tfhe_amd_sync.argtypes = [vp]
+    lib.tfhe_amd_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.tfhe_amd_get_tables.argtypes = [vp, f64p, f64p]
     lib.tfhe_amd_event_create.argtypes = [vp, C.POINTER(vp)]
     lib.tfhe_amd_event_record.argtypes = [vp, vp]
@@ -217,6 +219,10 @@ class Engine:
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)
         return self.alloc(max(arr.nbytes, 1)).upload(arr)
+
+    def set_option(self, option, value):
+        """TFHE_AMD_OPT_BR_VARIANT = 1, TFHE_AMD_OPT_KS_GATHER = 2 (include/tfhe_amd.h)"""
+        self._chk(self.lib.tfhe_amd_set_option(self.ctx, option, value))
 
     def sync(self):
         self._chk(self.lib.tfhe_amd_sync(self.ctx))

@@ -41,7 +41,8 @@ struct tfhe_amd_ctx {
     size_t ws_lwe_bytes;
     void *ws_acc;
     size_t ws_acc_bytes;
-    bool ks_force_gather;  // test hook: use the per-sample gather kernel even when the tiled one applies
+    bool ks_force_gather;  // TFHE_AMD_OPT_KS_GATHER: per-sample gather kernel even when the tiled one applies
+    int br_variant;        // TFHE_AMD_OPT_BR_VARIANT
 };
 
 namespace {
@@ -140,10 +141,10 @@ int set_lds(tfhe_amd_ctx *c, KernelT kernel, size_t bytes) {
 }
 
 // one instantiation per (torus, N): waves per workgroup chosen so LDS fits 160 KiB
-template <typename T, int LOGN, int WAVES, int PAIR>
+template <typename T, int LOGN, int WAVES, int PAIR, bool TWREG = false>
 int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
-    using Lds = BlindRotateLds<T, LOGN, WAVES>;
-    auto kernel = k_blind_rotate<T, LOGN, WAVES, PAIR>;
+    using Lds = BlindRotateLds<T, LOGN, WAVES, TWREG>;
+    auto kernel = k_blind_rotate<T, LOGN, WAVES, PAIR, TWREG>;
     static bool configured = false;  // per process; the attribute is per function
     if (!configured) {
         int rc = set_lds(c, kernel, Lds::total);
@@ -151,14 +152,19 @@ int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
         configured = true;
     }
     const int blocks = (a.batch + WAVES - 1) / WAVES;
-    TFHE_LAUNCH((k_blind_rotate<T, LOGN, WAVES, PAIR>), dim3(blocks), dim3(WAVES * 64), Lds::total, c->stream, a);
+    TFHE_LAUNCH((k_blind_rotate<T, LOGN, WAVES, PAIR, TWREG>), dim3(blocks), dim3(WAVES * 64), Lds::total, c->stream, a);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
 int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
     // N=1024/Torus32: 2 waves per SIMD (256 VGPRs): digits in pairs.  PPL=16 shapes transform
     // one digit at a time (a pair would need 128 more registers than the file has).
-    return c->logn == 10 ? launch_br_t<int32_t, 10, 8, 2>(c, a) : launch_br_t<int32_t, 11, 4, 1>(c, a);
+    if (c->logn == 11) return launch_br_t<int32_t, 11, 4, 1>(c, a);
+    switch (c->br_variant) {  // schedules of the same arithmetic (TFHE_AMD_OPT_BR_VARIANT), identical results
+        case 1: return launch_br_t<int32_t, 10, 4, 2, true>(c, a);  // 1 wave/SIMD, twiddles in registers
+        case 2: return launch_br_t<int32_t, 10, 8, 1>(c, a);        // digits one at a time
+        default: return launch_br_t<int32_t, 10, 8, 2>(c, a);       // 2 waves/SIMD, LDS twiddles, digit pairs
+    }
 }
 int launch_br64(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
     return c->logn == 10 ? launch_br_t<int64_t, 10, 4, 2>(c, a) : launch_br_t<int64_t, 11, 3, 1>(c, a);
@@ -300,6 +306,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->ks_d = nullptr;
     c->ksd_d = nullptr;
     c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") != nullptr;
+    c->br_variant = getenv("TFHE_AMD_BR_VARIANT") ? atoi(getenv("TFHE_AMD_BR_VARIANT")) : 0;
     c->ws_lwe = c->ws_acc = nullptr;
     c->ws_lwe_bytes = c->ws_acc_bytes = 0;
     if (hipSetDevice(device) != hipSuccess) {
@@ -374,6 +381,21 @@ int tfhe_amd_set_stream(tfhe_amd_ctx *c, void *s) {
     (void)s;
 #endif
     return TFHE_AMD_OK;
+}
+
+int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
+    if (!c) return TFHE_AMD_ERR_PARAM;
+    switch (option) {
+        case TFHE_AMD_OPT_BR_VARIANT:
+            REQUIRE(c, value >= 0 && value <= 2, "blind-rotation variant must be 0, 1 or 2");
+            c->br_variant = value;
+            return TFHE_AMD_OK;
+        case TFHE_AMD_OPT_KS_GATHER:
+            c->ks_force_gather = value != 0;
+            return TFHE_AMD_OK;
+        default:
+            return fail(c, TFHE_AMD_ERR_PARAM, "unknown option");
+    }
 }
 
 int tfhe_amd_sync(tfhe_amd_ctx *c) {

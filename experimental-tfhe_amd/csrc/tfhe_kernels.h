@@ -26,6 +26,8 @@
 #pragma once
 #include "devport.h"
 
+#include <type_traits>
+
 namespace tfhe {
 
 // ------------------------------------------------------------------ geometry
@@ -84,6 +86,48 @@ TFHE_DEVICE void dit_bfly(double &ar, double &ai, double &br, double &bi, double
 // directions; the fft butterflies flip the sign of c on exactly those entries.
 TFHE_DEVICE double flip_sign_if(double c, bool cond) { return cond ? -c : c; }
 
+// ---- where the butterflies get their twiddles -----------------------------------------
+// TwLds: the workgroup's LDS copy of the table (one ds_read_b128 per use).
+// TwRegs: the lane's own 3*PPL-2 twiddles (twist, pass A, pass B) held in registers for the whole
+//         kernel, pass C (lane-uniform) too -- no LDS twiddle traffic at all; costs 4*(3*PPL+2)
+//         VGPRs, so it goes with one wave per SIMD.
+template <int LOGN>
+struct TwLds {
+    using G = Geom<LOGN>;
+    const double2 *tw;
+    int t;
+    TFHE_DEVICE double2 twist(int m) const { return tw[G::jA(t, m)]; }
+    TFHE_DEVICE double2 passA(int s, int m) const { return tw[G::tw_base(64 * s) + t + 64 * (m & (s - 1))]; }
+    TFHE_DEVICE double2 passB(int s, int m) const {
+        return tw[G::tw_base(s << G::CB) + ((m & (s - 1)) << G::CB) + (t & ((1 << G::CB) - 1))];
+    }
+    TFHE_DEVICE double2 passC(int m) const { return tw[G::tw_base(4) + (m & 3)]; }
+};
+template <int LOGN>
+struct TwRegs {
+    using G = Geom<LOGN>;
+    static constexpr int PPL = G::PPL;
+    double2 tws[PPL], a[PPL - 1], b[PPL - 1], c[4];
+    // table: the [2*NC] complex table in global (or LDS) memory
+    TFHE_DEVICE void load(const double2 *table, int t) {
+#pragma unroll
+        for (int m = 0; m < PPL; m++) tws[m] = table[G::jA(t, m)];
+#pragma unroll
+        for (int s = 1; s <= PPL / 2; s <<= 1)
+#pragma unroll
+            for (int k = 0; k < s; k++) {
+                a[s - 1 + k] = table[G::tw_base(64 * s) + t + 64 * k];
+                b[s - 1 + k] = table[G::tw_base(s << G::CB) + (k << G::CB) + (t & ((1 << G::CB) - 1))];
+            }
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[k] = table[G::tw_base(4) + k];
+    }
+    TFHE_DEVICE double2 twist(int m) const { return tws[m]; }
+    TFHE_DEVICE double2 passA(int s, int m) const { return a[s - 1 + (m & (s - 1))]; }
+    TFHE_DEVICE double2 passB(int s, int m) const { return b[s - 1 + (m & (s - 1))]; }
+    TFHE_DEVICE double2 passC(int m) const { return c[m & 3]; }
+};
+
 template <int LOGN>
 struct WaveFFT {
     using G = Geom<LOGN>;
@@ -103,12 +147,12 @@ struct WaveFFT {
     // coefficient -> Lagrange for NP polynomials at once (every twiddle is read from LDS once
     // and used by all NP).  In: lane t register m = point jA(t,m) (re = coef j, im = coef j+N/2).
     // Out: register m = position jC(t,m) of the reference's output order.
-    template <int NP>
-    TFHE_DEVICE static void ifft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const double2 *tw, double *xch, int t) {
+    template <int NP, class TW>
+    TFHE_DEVICE static void ifft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, double *xch, int t) {
         // twist by omega^j (spqlios-ifft-fma.s:63-78)
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
-            const double2 w = tw[G::jA(t, m)];
+            const double2 w = tw.twist(m);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 const double r = xr[p][m], i = xi[p][m];
@@ -122,7 +166,7 @@ struct WaveFFT {
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 if (m & s) continue;
-                const double2 w = tw[G::tw_base(64 * s) + t + 64 * (m & (s - 1))];
+                const double2 w = tw.passA(s, m);
 #pragma unroll
                 for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], w.x, w.y);
             }
@@ -135,13 +179,12 @@ struct WaveFFT {
             transpose(xi[p], xch, wA, rB);
         }
         // pass B: strides s<<CB
-        const int c = t & ((1 << G::CB) - 1);
 #pragma unroll
         for (int s = PPL / 2; s >= 1; s >>= 1) {
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 if (m & s) continue;
-                const double2 w = tw[G::tw_base(s << G::CB) + ((m & (s - 1)) << G::CB) + c];
+                const double2 w = tw.passB(s, m);
 #pragma unroll
                 for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], w.x, w.y);
             }
@@ -158,7 +201,7 @@ struct WaveFFT {
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 if (m & 4) continue;
-                const double2 w = tw[G::tw_base(4) + (m & 3)];
+                const double2 w = tw.passC(m);
 #pragma unroll
                 for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + 4], xi[p][m + 4], w.x, w.y);
             }
@@ -191,8 +234,8 @@ struct WaveFFT {
 
     // Lagrange -> coefficient for NP polynomials (caller has applied the 2/N scale).
     // In: register m = position jC(t,m).  Out: register m = point jA(t,m).
-    template <int NP>
-    TFHE_DEVICE static void fft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const double2 *tw, double *xch, int t) {
+    template <int NP, class TW>
+    TFHE_DEVICE static void fft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, double *xch, int t) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
 #pragma unroll
@@ -221,7 +264,7 @@ struct WaveFFT {
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 if (m & 4) continue;
-                const double2 w = tw[G::tw_base(4) + (m & 3)];
+                const double2 w = tw.passC(m);
                 const double wc = (m & 3) == 2 ? -w.x : w.x;  // quarter turn
 #pragma unroll
                 for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + 4], xi[p][m + 4], wc, w.y);
@@ -240,7 +283,7 @@ struct WaveFFT {
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 if (m & s) continue;
-                const double2 w = tw[G::tw_base(s << G::CB) + ((m & (s - 1)) << G::CB) + c];
+                const double2 w = tw.passB(s, m);
                 // quarter turn: off == (s<<CB)/2
                 const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
                 const bool lq = (s == 1) ? (c == (1 << (G::CB - 1))) : (c == 0);
@@ -261,7 +304,7 @@ struct WaveFFT {
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 if (m & s) continue;
-                const double2 w = tw[G::tw_base(64 * s) + t + 64 * (m & (s - 1))];
+                const double2 w = tw.passA(s, m);
                 // quarter turn: off == 32*s
                 const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
                 const bool lq = (s == 1) ? (t == 32) : (t == 0);
@@ -274,7 +317,7 @@ struct WaveFFT {
         // re' = re*c - im*(-s) = re*c + im*s ; im' = re*(-s) + im*c = im*c - re*s
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
-            const double2 w = tw[G::jA(t, m)];
+            const double2 w = tw.twist(m);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 const double r = xr[p][m], i = xi[p][m];
@@ -347,11 +390,11 @@ TFHE_DEVICE T rot_only(const T *p, int i, int a) {
 
 // --------------------------------------------------------------- CMux step
 // Shared (LDS) state of one wave.
-template <typename T, int LOGN>
+template <typename T, int LOGN, class TW>
 struct WaveLds {
-    T *acc;              // [2][N] accumulator
-    double *xch;         // [Geom::XCH] transpose buffer
-    const double2 *tw;   // [Geom::TW] twiddles (shared by the workgroup)
+    T *acc;       // [2][N] accumulator
+    double *xch;  // [Geom::XCH] transpose buffer
+    TW tw;        // twiddle source (TwLds / TwRegs)
 };
 
 // Fourier-domain multiply-accumulate of one decomposed limb with one key row
@@ -375,8 +418,8 @@ TFHE_DEVICE void mac_row(double (&fr)[2][PPL], double (&fi)[2][PPL], const doubl
 // ND consecutive gadget digits (d .. d+ND-1) of one accumulator polynomial: extract, transform
 // together, multiply-accumulate with their key rows in digit order (the MAC chain is sequential in
 // the row index: lagrangehalfc AddMul accumulates in place, tgsw_functions.cpp:441-443).
-template <typename T, int LOGN, int ND>
-TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int row0, int d0,
+template <typename T, int LOGN, int ND, class TW>
+TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN, TW> &w, const double2 *__restrict__ bkrow, int row0, int d0,
                                  const typename Torus<T>::U (&lo)[Geom<LOGN>::PPL],
                                  const typename Torus<T>::U (&hi)[Geom<LOGN>::PPL], const Gadget &gd,
                                  double (&fr)[2][Geom<LOGN>::PPL], double (&fi)[2][Geom<LOGN>::PPL], int t) {
@@ -399,7 +442,7 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
             xi[e][m] = (double)((int32_t)((hi[m] >> decal) & mask) - halfBg);
         }
     }
-    WaveFFT<LOGN>::template ifft<ND>(xr, xi, w.tw, w.xch, t);
+    WaveFFT<LOGN>::template ifft<ND, TW>(xr, xi, w.tw, w.xch, t);
 #pragma unroll
     for (int e = 0; e < ND; e++) {
         if (e > 0) {
@@ -419,8 +462,8 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
 // The 2l inverse transforms run one at a time (their key row is prefetched into registers
 // under the transform); the two forward transforms run together, in place on the Fourier
 // accumulator, sharing every twiddle read.
-template <typename T, int LOGN, int PAIR>
-TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
+template <typename T, int LOGN, int PAIR, class TW>
+TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
                            const Gadget &gd, int t) {
     using G = Geom<LOGN>;
     using U = typename Torus<T>::U;
@@ -457,15 +500,15 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
             // p = bloc*l + i  (tgsw_functions.cpp:435-443); PAIR = 2: digits d, d+1 transformed
             // together (one twiddle read serves both); a trailing odd digit goes alone
             if (PAIR == 2 && d + 1 < gd.l) {
-                ifft_mac_digits<T, LOGN, 2>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
+                ifft_mac_digits<T, LOGN, 2, TW>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
             } else {
-                ifft_mac_digits<T, LOGN, 1>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
+                ifft_mac_digits<T, LOGN, 1, TW>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
             }
         }
     }
     // back to coefficients (both polynomials together), round, accumulate into acc
     // (tLweFromFFTConvert + tLweAddTo)
-    WaveFFT<LOGN>::template fft<2>(fr, fi, w.tw, w.xch, t);
+    WaveFFT<LOGN>::template fft<2, TW>(fr, fi, w.tw, w.xch, t);
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         T *p = w.acc + q * N;
@@ -484,6 +527,16 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
         }
     }
     TFHE_WAVE_FENCE();
+}
+
+template <int LOGN>
+TFHE_DEVICE void init_twiddles(TwLds<LOGN> &tw, const double2 *lds_table, const double2 *, int t) {
+    tw.tw = lds_table;
+    tw.t = t;
+}
+template <int LOGN>
+TFHE_DEVICE void init_twiddles(TwRegs<LOGN> &tw, const double2 *, const double2 *global_table, int t) {
+    tw.load(global_table, t);
 }
 
 // ----------------------------------------------------- blind-rotation kernel
@@ -523,10 +576,10 @@ TFHE_DEVICE int modswitch_2N(int32_t phase) {
     return (int)((((uint64_t)(uint32_t)phase << 32) + half) >> sh);
 }
 
-template <typename T, int LOGN, int WAVES>
+template <typename T, int LOGN, int WAVES, bool TWREG = false>
 struct BlindRotateLds {
     using G = Geom<LOGN>;
-    static constexpr size_t tw_bytes = sizeof(double2) * G::TW;
+    static constexpr size_t tw_bytes = TWREG ? 0 : sizeof(double2) * G::TW;
     static constexpr size_t acc_bytes = sizeof(T) * 2 * G::N;
     static constexpr size_t xch_bytes = sizeof(double) * G::XCH;
     static constexpr size_t wave_bytes = acc_bytes + xch_bytes;
@@ -539,27 +592,30 @@ struct BlindRotateLds {
 #define TFHE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
-template <typename T, int LOGN, int WAVES, int PAIR>
+template <typename T, int LOGN, int WAVES, int PAIR, bool TWREG>
 TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T> A) {
     using G = Geom<LOGN>;
     using U = typename Torus<T>::U;
-    using Lds = BlindRotateLds<T, LOGN, WAVES>;
+    using Lds = BlindRotateLds<T, LOGN, WAVES, TWREG>;
+    using TW = typename std::conditional<TWREG, TwRegs<LOGN>, TwLds<LOGN>>::type;
     constexpr int N = G::N, PPL = G::PPL;
     TFHE_DYN_LDS(smem);
-    double2 *tw = reinterpret_cast<double2 *>(smem);
-    for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = A.tw[i];
-    __syncthreads();
+    if (!TWREG) {
+        double2 *tw = reinterpret_cast<double2 *>(smem);
+        for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = A.tw[i];
+        __syncthreads();
+    }
 
     const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
     const int t = threadIdx.x & 63;
     const int ct = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
     if (ct >= A.batch) return;
 
-    WaveLds<T, LOGN> w;
+    WaveLds<T, LOGN, TW> w;
     unsigned char *mine = smem + Lds::tw_bytes + (size_t)wave * Lds::wave_bytes;
     w.acc = reinterpret_cast<T *>(mine);
     w.xch = reinterpret_cast<double *>(mine + Lds::acc_bytes);
-    w.tw = tw;
+    init_twiddles(w.tw, reinterpret_cast<const double2 *>(smem), A.tw, t);
 
     const int32_t *rot = A.rot + (size_t)ct * A.rot_stride;
     // ---- accumulator initialisation
@@ -603,7 +659,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             a = TFHE_UNIFORM(a);
             if (a == 0) continue;  // :348-350
         }
-        cmux_step<T, LOGN, PAIR>(w, bkrow, a, rotate, A.gd, t);
+        cmux_step<T, LOGN, PAIR, TW>(w, bkrow, a, rotate, A.gd, t);
     }
 
     // ---- output
@@ -654,7 +710,8 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
         xr[0][m] = (double)p[G::jA(t, m)];
         xi[0][m] = (double)p[G::jA(t, m) + NC];
     }
-    WaveFFT<LOGN>::template ifft<1>(xr, xi, tw, xch, t);
+    const TwLds<LOGN> twp{tw, t};
+    WaveFFT<LOGN>::template ifft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
     double *o = out + (size_t)b * N;
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
@@ -686,7 +743,8 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
         xr[0][m] = p[G::jC(t, m)] * scale;
         xi[0][m] = p[G::jC(t, m) + NC] * scale;
     }
-    WaveFFT<LOGN>::template fft<1>(xr, xi, tw, xch, t);
+    const TwLds<LOGN> twp{tw, t};
+    WaveFFT<LOGN>::template fft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
     TOUT *o = out + (size_t)b * N;
 #pragma unroll
     for (int m = 0; m < PPL; m++) {

@@ -69,6 +69,15 @@ const char *tfhe_amd_version(void);
 /* use an existing hipStream_t (passed as void*); NULL = the context's own stream */
 int tfhe_amd_set_stream(tfhe_amd_ctx *ctx, void *hip_stream);
 int tfhe_amd_sync(tfhe_amd_ctx *ctx);
+/* Scheduling options.  They select among kernels that compute the SAME results bit for bit; they
+ * exist so the alternatives can be measured against each other on the hardware.
+ *   TFHE_AMD_OPT_BR_VARIANT  blind-rotation kernel for N=1024/Torus32:
+ *        0 (default) 8 waves per workgroup (2 per SIMD), twiddles in LDS, gadget digits in pairs
+ *        1           4 waves per workgroup (1 per SIMD), twiddles held in registers, digits in pairs
+ *        2           8 waves per workgroup, twiddles in LDS, digits one at a time
+ *   TFHE_AMD_OPT_KS_GATHER   != 0: per-sample gather key switch instead of the batch-tiled kernel */
+enum { TFHE_AMD_OPT_BR_VARIANT = 1, TFHE_AMD_OPT_KS_GATHER = 2 };
+int tfhe_amd_set_option(tfhe_amd_ctx *ctx, int option, int value);
 /* HIP events on the context's stream, for timing kernels without a HIP binding in the host
  * language: create, record (asynchronous), elapsed milliseconds between two recorded events
  * (waits for `stop`), destroy */

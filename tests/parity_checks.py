@@ -30,7 +30,8 @@ class GateSetup:
     """keys + engine for one Torus32 parameter set; keys come from the ORACLE's generator and
     are cross-checked against the library's own generator (same PRNG specification)."""
 
-    def __init__(self, lib_path, N, n, l, Bgbit, ks_t, ks_bb, bk_stdev=2.0 ** -25, ks_stdev=2.0 ** -15, seed=SEED):
+    def __init__(self, lib_path, N, n, l, Bgbit, ks_t, ks_bb, bk_stdev=2.0 ** -25, ks_stdev=2.0 ** -15, seed=SEED,
+                 br_variant=0):
         self.N, self.n, self.l, self.Bgbit, self.ks_t, self.ks_bb = N, n, l, Bgbit, ks_t, ks_bb
         self.lib_path, self.seed = lib_path, seed
         self.lwe_key = O.keygen_binary(n, seed, 1)
@@ -39,6 +40,7 @@ class GateSetup:
         self.ks = O.ks_create32(self.tkey, self.lwe_key, ks_t, ks_bb, ks_stdev, seed, 100000)
         self.bk_stdev, self.ks_stdev = bk_stdev, ks_stdev
         self.eng = T.Engine(torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=ks_t, ks_basebit=ks_bb, lib_path=lib_path)
+        self.eng.set_option(T.OPT_BR_VARIANT, br_variant)  # same arithmetic, different schedule
         self.gsw = self.eng.gsw_from_fft(self.bk)
         self.eng.set_bootstrap_key(self.gsw)
         self.eng.load_keyswitch_key(self.ks)
@@ -94,9 +96,9 @@ def check_fft_plugin(lib_path, N, count=4, seed=11):
 
 
 # ------------------------------------------------------------ Torus32 path
-def check_gate_path(lib_path, N, n, l, Bgbit, ks_t, ks_bb, B, seed=21, check_export=True):
+def check_gate_path(lib_path, N, n, l, Bgbit, ks_t, ks_bb, B, seed=21, check_export=True, br_variant=0):
     rs = np.random.RandomState(seed)
-    s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb)
+    s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb, br_variant=br_variant)
     e = s.eng
     try:
         # harness parity: the library's key generator == the oracle's (same PRNG spec)
@@ -229,15 +231,11 @@ def check_keyswitch_shapes(lib_path, N, n_out, ks_t, ks_bb, B, seed=51):
     x = rs.randint(-2 ** 31, 2 ** 31, size=(B, N + 1)).astype(np.int32)
     x[0, :4] = [0, -1, 1 << 31 - ks_t * ks_bb, -(1 << 31 - ks_t * ks_bb)]  # rounding-boundary digits
     want = np.stack([O.keyswitch32(ks, x[b], N, n_out, ks_t, ks_bb) for b in range(B)])
-    for force_gather in (False, True):
-        if force_gather:
-            os.environ["TFHE_AMD_KS_GATHER"] = "1"
-        try:
-            e = T.Engine(torus_bits=32, n=n_out, N=N, l=2, Bgbit=10, ks_t=ks_t, ks_basebit=ks_bb, lib_path=lib_path)
-            try:
-                e.load_keyswitch_key(ks)
-                assert np.array_equal(e.keyswitch(x), want), f"key switch (gather={force_gather})"
-            finally:
-                e.close()
-        finally:
-            os.environ.pop("TFHE_AMD_KS_GATHER", None)
+    e = T.Engine(torus_bits=32, n=n_out, N=N, l=2, Bgbit=10, ks_t=ks_t, ks_basebit=ks_bb, lib_path=lib_path)
+    try:
+        e.load_keyswitch_key(ks)
+        for force_gather in (0, 1):
+            e.set_option(T.OPT_KS_GATHER, force_gather)
+            assert np.array_equal(e.keyswitch(x), want), f"key switch (gather={force_gather})"
+    finally:
+        e.close()

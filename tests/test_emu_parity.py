@@ -16,6 +16,15 @@ def test_gate_path_emu_n1024(emu_lib):
     P.check_gate_path(emu_lib, N=1024, n=6, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=3)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gate_path_emu_schedule_variants(emu_lib, variant):
+    """TFHE_AMD_OPT_BR_VARIANT: register-resident twiddles / unpaired digits give the same bits"""
+    P.check_gate_path(emu_lib, N=1024, n=4, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=5, check_export=False,
+                      br_variant=variant)
+    P.check_gate_path(emu_lib, N=1024, n=2, l=3, Bgbit=7, ks_t=8, ks_bb=2, B=2, check_export=False, seed=9,
+                      br_variant=variant)
+
+
 def test_gate_path_emu_other_gadgets(emu_lib):
     P.check_gate_path(emu_lib, N=1024, n=3, l=3, Bgbit=7, ks_t=16, ks_bb=1, B=2, seed=5)
     P.check_gate_path(emu_lib, N=1024, n=2, l=1, Bgbit=12, ks_t=5, ks_bb=3, B=9, seed=6)  # ragged: 9 = 8 + 1 waves

@@ -61,6 +61,15 @@ def test_gate_path_other_gadgets(gpu_lib):
     P.check_gate_path(gpu_lib, N=2048, n=5, l=2, Bgbit=9, ks_t=4, ks_bb=3, B=7, seed=7)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gate_path_schedule_variants(gpu_lib, variant):
+    """the alternative blind-rotation schedules (TFHE_AMD_OPT_BR_VARIANT) are bit-identical too"""
+    P.check_gate_path(gpu_lib, N=1024, n=630, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=9, check_export=False,
+                      br_variant=variant)
+    P.check_gate_path(gpu_lib, N=1024, n=6, l=3, Bgbit=7, ks_t=8, ks_bb=2, B=5, check_export=False, seed=9,
+                      br_variant=variant)
+
+
 def test_gate_path_full_parameters(gpu_lib):
     """BASELINE config 1/2 parameter set: n=630, N=1024, k=1, l=2, Bgbit=10, ks 8x2"""
     P.check_gate_path(gpu_lib, N=1024, n=630, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=6, check_export=True)
