@@ -43,6 +43,7 @@ struct tfhe_amd_ctx {
     size_t ws_acc_bytes;
     bool ks_force_gather;  // TFHE_AMD_OPT_KS_GATHER: per-sample gather kernel even when the tiled one applies
     int br_variant;        // TFHE_AMD_OPT_BR_VARIANT
+    std::vector<const void *> lds_configured;  // kernels whose dynamic-LDS limit is raised on this device
 };
 
 namespace {
@@ -133,10 +134,16 @@ int ilog2(int v) {
     return r;
 }
 
+// dynamic LDS above 64 KiB must be allowed per function AND per device: remembered per context
+// (a process may hold contexts on several GPUs)
 template <typename KernelT>
 int set_lds(tfhe_amd_ctx *c, KernelT kernel, size_t bytes) {
-    HIPCHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const void *key = reinterpret_cast<const void *>(kernel);
+    for (const void *k : c->lds_configured)
+        if (k == key) return TFHE_AMD_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    c->lds_configured.push_back(key);
     return TFHE_AMD_OK;
 }
 
@@ -145,12 +152,7 @@ template <typename T, int LOGN, int WAVES, int PAIR, bool TWREG = false>
 int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
     using Lds = BlindRotateLds<T, LOGN, WAVES, TWREG>;
     auto kernel = k_blind_rotate<T, LOGN, WAVES, PAIR, TWREG>;
-    static bool configured = false;  // per process; the attribute is per function
-    if (!configured) {
-        int rc = set_lds(c, kernel, Lds::total);
-        if (rc) return rc;
-        configured = true;
-    }
+    if (int rc = set_lds(c, kernel, Lds::total)) return rc;
     const int blocks = (a.batch + WAVES - 1) / WAVES;
     TFHE_LAUNCH((k_blind_rotate<T, LOGN, WAVES, PAIR, TWREG>), dim3(blocks), dim3(WAVES * 64), Lds::total, c->stream, a);
     HIPCHECK(c, hipGetLastError());
@@ -175,12 +177,7 @@ int launch_ifft_t(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
     constexpr int WAVES = 4;
     using Lds = FftLds<LOGN, WAVES>;
     auto kernel = k_ifft_batch<TIN, LOGN, WAVES>;
-    static bool configured = false;
-    if (!configured) {
-        int rc = set_lds(c, kernel, Lds::total);
-        if (rc) return rc;
-        configured = true;
-    }
+    if (int rc = set_lds(c, kernel, Lds::total)) return rc;
     TFHE_LAUNCH((k_ifft_batch<TIN, LOGN, WAVES>), dim3((batch + WAVES - 1) / WAVES), dim3(WAVES * 64), Lds::total,
                 c->stream, out_d, in_d, (const double2 *)c->tw_d, batch);
     HIPCHECK(c, hipGetLastError());
@@ -191,12 +188,7 @@ int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
     constexpr int WAVES = 4;
     using Lds = FftLds<LOGN, WAVES>;
     auto kernel = k_fft_batch<TOUT, LOGN, WAVES>;
-    static bool configured = false;
-    if (!configured) {
-        int rc = set_lds(c, kernel, Lds::total);
-        if (rc) return rc;
-        configured = true;
-    }
+    if (int rc = set_lds(c, kernel, Lds::total)) return rc;
     TFHE_LAUNCH((k_fft_batch<TOUT, LOGN, WAVES>), dim3((batch + WAVES - 1) / WAVES), dim3(WAVES * 64), Lds::total,
                 c->stream, out_d, in_d, (const double2 *)c->tw_d, batch);
     HIPCHECK(c, hipGetLastError());
