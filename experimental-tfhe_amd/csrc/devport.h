@@ -27,6 +27,8 @@
     } while (0)
 
 #define TFHE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// true in every lane iff `cond` holds in at least one active lane of the wave
+#define TFHE_WAVE_ANY(cond) (__builtin_amdgcn_ballot_w64(cond) != 0ull)
 // placed at the top of a wave-uniform `if` body: keeps it a real scalar branch (hipcc otherwise
 // if-converts short bodies into per-lane selects, which costs VALU work on the skipped paths)
 #define TFHE_KEEP_BRANCH() asm volatile("" ::: "memory")

@@ -336,14 +336,29 @@ template <>
 struct Torus<int32_t> {
     using U = uint32_t;
     static constexpr int BITS = 32;
+    static constexpr bool HAS_FAST = true;
     // int32_t(int64_t(x)), fft_processor_spqlios.cpp:102 (truncate toward zero, wrap)
     TFHE_DEVICE static int32_t from_double(double x) { return (int32_t)(int64_t)x; }
+    // The same value for |x| < 2^51 in 2 fp64 operations instead of 5: t = trunc(x) is an integer
+    // below 2^51, so t + 1.5*2^52 is exact (ulp 1) and carries t mod 2^32 in its low word.
+    // `guard` ORs the high words of t; guard_ok() then bounds every exponent seen with one compare
+    // (an OR can only over-estimate), and callers fall back to from_double when it fails.
+    TFHE_DEVICE static int32_t from_double_fast(double x, uint32_t &guard) {
+        const double tr = __builtin_trunc(x);
+        guard |= (uint32_t)((uint64_t)__builtin_bit_cast(int64_t, tr) >> 32);
+        const double y = tr + 0x1.8p52;
+        return (int32_t)(uint32_t)(uint64_t)__builtin_bit_cast(int64_t, y);
+    }
+    TFHE_DEVICE static bool guard_ok(uint32_t guard) { return (guard & 0x7FF00000u) < 0x43200000u; }
     TFHE_DEVICE static double to_double(int32_t v) { return (double)v; }
 };
 template <>
 struct Torus<int64_t> {
     using U = uint64_t;
     static constexpr int BITS = 64;
+    static constexpr bool HAS_FAST = false;
+    TFHE_DEVICE static int64_t from_double_fast(double x, uint32_t &) { return from_double(x); }
+    TFHE_DEVICE static bool guard_ok(uint32_t) { return true; }
     // fft_processor_spqlios.cpp:131-142: mantissa shifted by (exponent-1075), truncation,
     // modulo 2^64; shifts of 64 or more (|x| < 2^-11: undefined in the reference) give 0.
     TFHE_DEVICE static int64_t from_double(double x) {
@@ -509,20 +524,41 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
     // back to coefficients (both polynomials together), round, accumulate into acc
     // (tLweFromFFTConvert + tLweAddTo)
     WaveFFT<LOGN>::template fft<2, TW>(fr, fi, w.tw, w.xch, t);
+    U r0[2][PPL], r1[2][PPL];
+    bool exact_path = true;
+    if (Torus<T>::HAS_FAST) {  // Torus32: short rounding sequence, valid while every |x| < 2^51
+        uint32_t guard = 0;
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                r0[q][m] = (U)Torus<T>::from_double_fast(fr[q][m], guard);
+                r1[q][m] = (U)Torus<T>::from_double_fast(fi[q][m], guard);
+            }
+        exact_path = TFHE_WAVE_ANY(!Torus<T>::guard_ok(guard));  // wave-uniform
+    }
+    if (exact_path) {
+        TFHE_KEEP_BRANCH();
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                r0[q][m] = (U)Torus<T>::from_double(fr[q][m]);
+                r1[q][m] = (U)Torus<T>::from_double(fi[q][m]);
+            }
+    }
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         T *p = w.acc + q * N;
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
             const int j = G::jA(t, m);
-            const U r0 = (U)Torus<T>::from_double(fr[q][m]);
-            const U r1 = (U)Torus<T>::from_double(fi[q][m]);
             if (rotate) {
-                p[j] = (T)((U)p[j] + r0);
-                p[j + NC] = (T)((U)p[j + NC] + r1);
+                p[j] = (T)((U)p[j] + r0[q][m]);
+                p[j + NC] = (T)((U)p[j + NC] + r1[q][m]);
             } else {
-                p[j] = (T)r0;
-                p[j + NC] = (T)r1;
+                p[j] = (T)r0[q][m];
+                p[j + NC] = (T)r1[q][m];
             }
         }
     }

@@ -118,6 +118,16 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
 void syncthreads() { arrive(t_blk->all); }
 void wave_fence() { arrive(t_blk->waves[t_threadIdx.x / 64]); }
 unsigned char *dyn_smem() { return t_blk->smem; }
+bool wave_any(bool cond) {
+    const unsigned tid = t_threadIdx.x, base = tid & ~63u;
+    t_blk->lane_xchg[tid] = cond ? 1 : 0;
+    wave_fence();
+    bool any = false;
+    const unsigned end = std::min<unsigned>(base + 64, (unsigned)t_blk->lane_xchg.size());
+    for (unsigned i = base; i < end; i++) any |= (t_blk->fibers[i].done ? false : t_blk->lane_xchg[i] != 0);
+    wave_fence();
+    return any;
+}
 int readlane(int v, int lane) {
     const unsigned tid = t_threadIdx.x;
     t_blk->lane_xchg[tid] = v;

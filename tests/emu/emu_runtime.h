@@ -28,6 +28,7 @@ void syncthreads();
 void wave_fence();
 unsigned char *dyn_smem();
 int readlane(int v, int lane);
+bool wave_any(bool cond);
 }  // namespace emu
 
 using dim3 = emu::Dim3;
@@ -43,6 +44,7 @@ using dim3 = emu::Dim3;
 #define TFHE_HOST_DEVICE inline
 #define TFHE_WAVE_FENCE() emu::wave_fence()
 #define TFHE_UNIFORM(x) (x)
+#define TFHE_WAVE_ANY(cond) emu::wave_any(cond)
 #define TFHE_KEEP_BRANCH() ((void)0)
 #define TFHE_READLANE(v, lane) emu::readlane((v), (lane))
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \

@@ -192,6 +192,40 @@ def check_torus64_path(lib_path, N, n, l, Bgbit, B, seed=31):
         e.close()
 
 
+# ------------------------------------------------------- rounding range extremes
+def check_rounding_extremes(lib_path, br_variant=0):
+    """Torus32 rounding has a short sequence valid for |x| < 2^51 and an exact fallback (DESIGN.md,
+    bit-exactness rules).  Drive the external product to its worst-case magnitude 2*l*N*(Bg/2)*2^31 =
+    2^52: all digits -Bg/2, all key coefficients -2^31, which no random input
+    reaches; plus mixed samples around the 2^51 threshold, in one batch (the choice is per wave)."""
+    N, l, Bgbit = 1024, 2, 10
+    halfBg = 1 << (Bgbit - 1)
+    offset = (halfBg * sum(1 << (32 - (i + 1) * Bgbit) for i in range(l))) & 0xFFFFFFFF
+    rs = np.random.RandomState(77)
+    e = T.Engine(torus_bits=32, n=3, N=N, l=l, Bgbit=Bgbit, ks_t=0, lib_path=lib_path)
+    try:
+        e.set_option(T.OPT_BR_VARIANT, br_variant)
+        coef = np.full((3, 2 * l, 2, N), -2 ** 31, np.int64)
+        coef[1] = rs.randint(-2 ** 31, 2 ** 31, size=(2 * l, 2, N))           # ordinary key
+        coef[2, :, :, ::2] = 2 ** 31 - 1                                        # alternating extremes
+        gsw_lag = O.execute_reverse_int(N, coef.astype(np.int32).reshape(-1, N)).reshape(3, 2 * l, 2, N)
+        g = e.gsw_from_fft(gsw_lag)
+        allneg = np.full(2 * N, (-offset) & 0xFFFFFFFF, np.uint32).view(np.int32)  # every digit = -Bg/2
+        acc = np.stack([allneg,
+                        rs.randint(-2 ** 31, 2 ** 31, size=2 * N).astype(np.int32),
+                        np.where(np.arange(2 * N) % 3 == 0, allneg, 0).astype(np.int32),
+                        allneg, allneg, rs.randint(-2 ** 31, 2 ** 31, size=2 * N).astype(np.int32),
+                        allneg, allneg, allneg]).reshape(9, 2, N)   # 9 samples: two workgroups / waves differ
+        for idx in range(3):
+            want = np.stack([O.extprod32(N, acc[b], gsw_lag[idx], l, Bgbit) for b in range(9)]).reshape(9, 2, N)
+            assert np.array_equal(e.extern_mul(acc, g, idx), want), f"external product at extreme magnitude (key {idx})"
+        ba = np.array([1, 5, N, 2 * N - 1, 7, 9, 11, 13, 1000], np.int32)
+        want = np.stack([O.mux_rotate32(N, acc[b], gsw_lag[0], ba[b], l, Bgbit) for b in range(9)]).reshape(9, 2, N)
+        assert np.array_equal(e.mux_rotate(acc, g, 0, ba), want), "CMux at extreme magnitude"
+    finally:
+        e.close()
+
+
 # ------------------------------------------------------------ circuit bootstrap
 def check_circuit_bootstrap(lib_path, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, B, seed=61):
     """circuitPrivKS and the whole tfhe_CircuitBootstrapFFT pipeline (preKeySwitch, preModSwitch,

@@ -25,6 +25,11 @@ def test_gate_path_emu_schedule_variants(emu_lib, variant):
                       br_variant=variant)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_rounding_extremes_emu(emu_lib, variant):
+    P.check_rounding_extremes(emu_lib, variant)
+
+
 def test_gate_path_emu_other_gadgets(emu_lib):
     P.check_gate_path(emu_lib, N=1024, n=3, l=3, Bgbit=7, ks_t=16, ks_bb=1, B=2, seed=5)
     P.check_gate_path(emu_lib, N=1024, n=2, l=1, Bgbit=12, ks_t=5, ks_bb=3, B=9, seed=6)  # ragged: 9 = 8 + 1 waves

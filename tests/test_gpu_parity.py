@@ -70,6 +70,12 @@ def test_gate_path_schedule_variants(gpu_lib, variant):
                       br_variant=variant)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_rounding_extremes(gpu_lib, variant):
+    """worst-case magnitude 2^52 of the external product: exact fallback of the Torus32 rounding"""
+    P.check_rounding_extremes(gpu_lib, variant)
+
+
 def test_gate_path_full_parameters(gpu_lib):
     """BASELINE config 1/2 parameter set: n=630, N=1024, k=1, l=2, Bgbit=10, ks 8x2"""
     P.check_gate_path(gpu_lib, N=1024, n=630, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=6, check_export=True)
