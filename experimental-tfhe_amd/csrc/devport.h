@@ -32,6 +32,9 @@
 // placed at the top of a wave-uniform `if` body: keeps it a real scalar branch (hipcc otherwise
 // if-converts short bodies into per-lane selects, which costs VALU work on the skipped paths)
 #define TFHE_KEEP_BRANCH() asm volatile("" ::: "memory")
+// makes a register value opaque at this point: arithmetic on it cannot be hoisted above (used to
+// keep a rarely taken fallback from being computed speculatively on the hot path)
+#define TFHE_OPAQUE(x) asm volatile("" : "+v"(x))
 // value of `v` held by lane `lane` (wave-uniform lane index) -> scalar register
 #define TFHE_READLANE(v, lane) __builtin_amdgcn_readlane((v), (lane))
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \

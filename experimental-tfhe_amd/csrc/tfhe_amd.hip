@@ -329,10 +329,12 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
         uint32_t s = 0;
         for (int i = 0; i < p->l; i++) s += 1u << (32 - (i + 1) * p->Bgbit);
         c->gd.offset = (uint32_t)(s * (1u << (p->Bgbit - 1)));
+        c->gd.flip = (uint32_t)(s * (1u << (p->Bgbit - 1)));  // Bg/2 << (32-(i+1)Bgbit), every i: same bits
     } else {
         uint64_t s = 0;
         for (int i = 0; i <= p->l; i++) s |= 1ull << (63 - i * p->Bgbit);
         c->gd.offset = s;
+        c->gd.flip = 0;
     }
     *out = c;
     return TFHE_AMD_OK;

@@ -379,6 +379,7 @@ struct Torus<int64_t> {
 // Torus32: no rounding bit; poc:349-350 for Torus64: with rounding bit)
 struct Gadget {
     uint64_t offset;
+    uint64_t flip;  // Torus32 only: Bg/2 at every digit position (see ifft_mac_digits); else 0
     int32_t Bgbit;
     int32_t l;
 };
@@ -453,8 +454,15 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN, TW> &w, const double2 *_
         const int decal = Torus<T>::BITS - (d0 + e + 1) * gd.Bgbit;
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
-            xr[e][m] = (double)((int32_t)((lo[m] >> decal) & mask) - halfBg);
-            xi[e][m] = (double)((int32_t)((hi[m] >> decal) & mask) - halfBg);
+            if (Torus<T>::BITS == 32) {
+                // lo/hi arrive with the top bit of every digit field flipped (Gadget::flip), so the
+                // field read as a signed Bgbit-bit number IS (field - Bg/2): one v_bfe_i32 per digit
+                xr[e][m] = (double)(((int32_t)((uint32_t)lo[m] << (32 - decal - gd.Bgbit))) >> (32 - gd.Bgbit));
+                xi[e][m] = (double)(((int32_t)((uint32_t)hi[m] << (32 - decal - gd.Bgbit))) >> (32 - gd.Bgbit));
+            } else {
+                xr[e][m] = (double)((int32_t)((lo[m] >> decal) & mask) - halfBg);
+                xi[e][m] = (double)((int32_t)((hi[m] >> decal) & mask) - halfBg);
+            }
         }
     }
     WaveFFT<LOGN>::template ifft<ND, TW>(xr, xi, w.tw, w.xch, t);
@@ -483,7 +491,7 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
     using G = Geom<LOGN>;
     using U = typename Torus<T>::U;
     constexpr int PPL = G::PPL, N = G::N, NC = G::NC;
-    const U offset = (U)gd.offset;
+    const U offset = (U)gd.offset, flip = (U)gd.flip;
 
     double fr[2][PPL], fi[2][PPL];  // Fourier accumulator (tLweFFTClear)
 #pragma unroll
@@ -499,15 +507,15 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 const int j = G::jA(t, m);
-                lo[m] = rot_minus_one<T, LOGN>(p, j, a) + offset;
-                hi[m] = rot_minus_one<T, LOGN>(p, j + NC, a) + offset;
+                lo[m] = (rot_minus_one<T, LOGN>(p, j, a) + offset) ^ flip;
+                hi[m] = (rot_minus_one<T, LOGN>(p, j + NC, a) + offset) ^ flip;
             }
         } else {
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 const int j = G::jA(t, m);
-                lo[m] = (U)p[j] + offset;
-                hi[m] = (U)p[j + NC] + offset;
+                lo[m] = ((U)p[j] + offset) ^ flip;
+                hi[m] = ((U)p[j + NC] + offset) ^ flip;
             }
         }
 #pragma unroll 1
@@ -543,6 +551,8 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
         for (int q = 0; q < 2; q++)
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
+                TFHE_OPAQUE(fr[q][m]);
+                TFHE_OPAQUE(fi[q][m]);
                 r0[q][m] = (U)Torus<T>::from_double(fr[q][m]);
                 r1[q][m] = (U)Torus<T>::from_double(fi[q][m]);
             }

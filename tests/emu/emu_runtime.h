@@ -46,6 +46,7 @@ using dim3 = emu::Dim3;
 #define TFHE_UNIFORM(x) (x)
 #define TFHE_WAVE_ANY(cond) emu::wave_any(cond)
 #define TFHE_KEEP_BRANCH() ((void)0)
+#define TFHE_OPAQUE(x) ((void)0)
 #define TFHE_READLANE(v, lane) emu::readlane((v), (lane))
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu::launch([=]() { kernel(__VA_ARGS__); }, grid, block, smem)
