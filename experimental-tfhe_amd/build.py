@@ -13,6 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtfhe_amd.so")
+OUT_ABLATE = os.path.join(HERE, "libtfhe_amd_ablate.so")  # diagnostic build (tools/ablate.py), never loaded by default
 SOURCES = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "devport.h"),
                   os.path.join(os.path.dirname(HERE), "include", "tfhe_amd.h")]
@@ -34,7 +35,16 @@ def stale():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, ablate=False):
+    if ablate:  # timing-only diagnostic library: results are wrong by design when a mask is set
+        out = OUT_ABLATE
+        if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in DEPS):
+            return out
+        res = subprocess.run([hipcc()] + FLAGS + ["-DTFHE_ABLATE"] + SOURCES + ["-o", out], capture_output=True, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout + res.stderr)
+            raise RuntimeError("hipcc failed")
+        return out
     if not force and not stale():
         return OUT
     cmd = [hipcc()] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + SOURCES + ["-o", OUT]
@@ -47,4 +57,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, ablate="--ablate" in sys.argv))

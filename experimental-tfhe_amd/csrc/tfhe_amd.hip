@@ -814,6 +814,18 @@ int tfhe_amd_modswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *x_d, int 
 
 }  // extern "C"
 
+#ifdef TFHE_ABLATE
+// diagnostic build only (build.py --ablate): switch cost components off, see tfhe_kernels.h
+extern "C" int tfhe_amd_debug_set_ablation(unsigned mask) {
+#ifdef TFHE_EMU
+    tfhe::g_ablate = mask;
+    return TFHE_AMD_OK;
+#else
+    return hipMemcpyToSymbol(HIP_SYMBOL(tfhe::g_ablate), &mask, sizeof(mask)) == hipSuccess ? TFHE_AMD_OK : TFHE_AMD_ERR_DEVICE;
+#endif
+}
+#endif
+
 // ---------------------------------------------------------------- circuit bootstrap
 struct tfhe_amd_cb {
     tfhe_amd_cb_params p;

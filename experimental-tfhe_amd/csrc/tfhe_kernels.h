@@ -30,6 +30,20 @@
 
 namespace tfhe {
 
+// ---- ablation hooks (DIAGNOSTIC build only: build.py --ablate, tools/ablate.py) -------------
+// With -DTFHE_ABLATE a mask in device memory switches off one cost component at a time (results
+// are then WRONG on purpose; only the timing is read).  The shipped build contains none of this:
+// every hook is inside #ifdef TFHE_ABLATE.
+enum : uint32_t { ABL_NO_BK_LOADS = 1u, ABL_NO_TRANSPOSES = 2u, ABL_NO_TWIDDLE_READS = 4u, ABL_NO_ROTATE_READS = 8u };
+#ifdef TFHE_ABLATE
+#ifdef TFHE_EMU
+static uint32_t g_ablate = 0;
+#else
+__device__ uint32_t g_ablate = 0;
+#endif
+#define TFHE_ABL(bit) ((g_ablate & (bit)) != 0)
+#endif
+
 // ------------------------------------------------------------------ geometry
 template <int LOGN>
 struct Geom {
@@ -96,12 +110,24 @@ struct TwLds {
     using G = Geom<LOGN>;
     const double2 *tw;
     int t;
-    TFHE_DEVICE double2 twist(int m) const { return tw[G::jA(t, m)]; }
-    TFHE_DEVICE double2 passA(int s, int m) const { return tw[G::tw_base(64 * s) + t + 64 * (m & (s - 1))]; }
+#ifdef TFHE_ABLATE
+    struct Fetch {
+        const double2 *p;
+        TFHE_DEVICE double2 operator[](int i) const {
+            return TFHE_ABL(ABL_NO_TWIDDLE_READS) ? make_double2(0.70710678118654757, 0.70710678118654746) : p[i];
+        }
+    };
+#define TFHE_TW_SRC (Fetch{tw})
+#else
+#define TFHE_TW_SRC tw
+#endif
+    TFHE_DEVICE double2 twist(int m) const { return TFHE_TW_SRC[G::jA(t, m)]; }
+    TFHE_DEVICE double2 passA(int s, int m) const { return TFHE_TW_SRC[G::tw_base(64 * s) + t + 64 * (m & (s - 1))]; }
     TFHE_DEVICE double2 passB(int s, int m) const {
-        return tw[G::tw_base(s << G::CB) + ((m & (s - 1)) << G::CB) + (t & ((1 << G::CB) - 1))];
+        return TFHE_TW_SRC[G::tw_base(s << G::CB) + ((m & (s - 1)) << G::CB) + (t & ((1 << G::CB) - 1))];
     }
-    TFHE_DEVICE double2 passC(int m) const { return tw[G::tw_base(4) + (m & 3)]; }
+    TFHE_DEVICE double2 passC(int m) const { return TFHE_TW_SRC[G::tw_base(4) + (m & 3)]; }
+#undef TFHE_TW_SRC
 };
 template <int LOGN>
 struct TwRegs {
@@ -136,6 +162,9 @@ struct WaveFFT {
     // one wave-wide transpose through LDS: write with map widx, read with map ridx
     template <class WIdx, class RIdx>
     TFHE_DEVICE static void transpose(double (&x)[PPL], double *xch, WIdx widx, RIdx ridx) {
+#ifdef TFHE_ABLATE
+        if (TFHE_ABL(ABL_NO_TRANSPOSES)) return;
+#endif
 #pragma unroll
         for (int m = 0; m < PPL; m++) xch[widx(m)] = x[m];
         TFHE_WAVE_FENCE();
@@ -444,10 +473,16 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN, TW> &w, const double2 *_
     const U mask = ((U)1 << gd.Bgbit) - 1;
     const int32_t halfBg = 1 << (gd.Bgbit - 1);
     double2 bk[2][PPL];  // key row of the first digit, fetched underneath the transform
+#ifdef TFHE_ABLATE
+    const bool abl_bk = TFHE_ABL(ABL_NO_BK_LOADS);
+#define TFHE_BK(idx, fake) (abl_bk ? (fake) : bkrow[idx])
+#else
+#define TFHE_BK(idx, fake) bkrow[idx]
+#endif
 #pragma unroll
     for (int qq = 0; qq < 2; qq++)
 #pragma unroll
-        for (int m = 0; m < PPL; m++) bk[qq][m] = bkrow[((row0 * 2 + qq) * PPL + m) * 64 + t];
+        for (int m = 0; m < PPL; m++) bk[qq][m] = TFHE_BK(((row0 * 2 + qq) * PPL + m) * 64 + t, make_double2(1.0 + m, 0.5 * t));
     double xr[ND][PPL], xi[ND][PPL];
 #pragma unroll
     for (int e = 0; e < ND; e++) {
@@ -472,10 +507,12 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN, TW> &w, const double2 *_
 #pragma unroll
             for (int qq = 0; qq < 2; qq++)
 #pragma unroll
-                for (int m = 0; m < PPL; m++) bk[qq][m] = bkrow[(((row0 + e) * 2 + qq) * PPL + m) * 64 + t];
+                for (int m = 0; m < PPL; m++)
+                    bk[qq][m] = TFHE_BK((((row0 + e) * 2 + qq) * PPL + m) * 64 + t, make_double2(2.0 + m, 0.25 * t));
         }
         mac_row<PPL>(fr, fi, xr[e], xi[e], bk);
     }
+#undef TFHE_BK
 }
 
 // One CMux step on the wave's accumulator:
@@ -503,7 +540,11 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
     for (int q = 0; q < 2; q++) {
         const T *p = w.acc + q * N;
         U lo[PPL], hi[PPL];  // coefficients j and j+N/2 of the (rotated) polynomial, offset added
+#ifdef TFHE_ABLATE
+        if (rotate && !TFHE_ABL(ABL_NO_ROTATE_READS)) {
+#else
         if (rotate) {
+#endif
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 const int j = G::jA(t, m);
