@@ -37,6 +37,9 @@ except Exception as e:
 PY
 done
 
+echo "== ablation table (diagnostic build, wrong results by design, times only)" | tee -a "$OUT/log.txt"
+timeout 600 python3 tools/ablate.py --reps 3 2> "$OUT/ablate.err" | tee "$OUT/ablate.txt" | tee -a "$OUT/log.txt"
+
 echo "== rocprofv3 kernel trace + stats" | tee -a "$OUT/log.txt"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
     python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
