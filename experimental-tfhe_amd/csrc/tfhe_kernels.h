@@ -536,8 +536,15 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
 #pragma unroll
         for (int m = 0; m < PPL; m++) fr[q][m] = fi[q][m] = 0.0;
 
+    // one iteration per group of PAIR digits of one accumulator polynomial.  The (rotated)
+    // coefficients are re-read from LDS for every group instead of being kept across groups:
+    // they then die at the digit extraction, which is what lets the transform pair + key row +
+    // Fourier accumulator fit the register file; for l == PAIR (the gate set) nothing is read twice.
+    const int groups = (gd.l + PAIR - 1) / PAIR;
 #pragma unroll 1
-    for (int q = 0; q < 2; q++) {
+    for (int g = 0; g < 2 * groups; g++) {
+        const int q = (g >= groups) ? 1 : 0;
+        const int d = (g - q * groups) * PAIR;
         const T *p = w.acc + q * N;
         U lo[PPL], hi[PPL];  // coefficients j and j+N/2 of the (rotated) polynomial, offset added
 #ifdef TFHE_ABLATE
@@ -559,15 +566,11 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
                 hi[m] = ((U)p[j + NC] + offset) ^ flip;
             }
         }
-#pragma unroll 1
-        for (int d = 0; d < gd.l; d += PAIR) {
-            // p = bloc*l + i  (tgsw_functions.cpp:435-443); PAIR = 2: digits d, d+1 transformed
-            // together (one twiddle read serves both); a trailing odd digit goes alone
-            if (PAIR == 2 && d + 1 < gd.l) {
-                ifft_mac_digits<T, LOGN, 2, TW>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
-            } else {
-                ifft_mac_digits<T, LOGN, 1, TW>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
-            }
+        // p = bloc*l + i  (tgsw_functions.cpp:435-443); a trailing odd digit goes alone
+        if (PAIR == 2 && d + 1 < gd.l) {
+            ifft_mac_digits<T, LOGN, 2, TW>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
+        } else {
+            ifft_mac_digits<T, LOGN, 1, TW>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
         }
     }
     // back to coefficients (both polynomials together), round, accumulate into acc
