@@ -47,4 +47,21 @@ if max_stage >= 5:
     say("stage 5: Torus64 N=2048 l=4, n=5, B=4")
     P.check_torus64_path(T.DEFAULT_LIB, N=2048, n=5, l=4, Bgbit=9, B=4)
     say("   ok")
+if max_stage >= 6:
+    say("stage 6: key switch shapes (tiled + gather), n_out=630 8x2 and n_out=500 6x2")
+    P.check_keyswitch_shapes(T.DEFAULT_LIB, 1024, 630, 8, 2, 35)
+    P.check_keyswitch_shapes(T.DEFAULT_LIB, 1024, 500, 6, 2, 9)
+    say("   ok")
+if max_stage >= 7:
+    say("stage 7: schedule variants 1, 2 and rounding extremes")
+    for v in (1, 2):
+        P.check_gate_path(T.DEFAULT_LIB, N=1024, n=8, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=9, check_export=False, br_variant=v)
+    for v in (0, 1, 2):
+        P.check_rounding_extremes(T.DEFAULT_LIB, v)
+    say("   ok")
+if max_stage >= 8:
+    say("stage 8: circuit bootstrap pipeline (private key switch), N2=2048")
+    P.check_circuit_bootstrap(T.DEFAULT_LIB, n0=6, N1=1024, N2=2048, l1=2, bg1=8, l2=4, bg2=9, t10=6, bb10=2, t21=2,
+                              bb21=3, B=5)
+    say("   ok")
 say("done")
