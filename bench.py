@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--br-variant", type=int, default=0,
                     help="TFHE_AMD_OPT_BR_VARIANT: 0 default schedule, 1 register twiddles (1 wave/SIMD), 2 unpaired digits")
     ap.add_argument("--ks-gather", action="store_true", help="per-sample gather key switch instead of the tiled one")
+    ap.add_argument("--streamed", action="store_true",
+                    help="also time BASELINE config 2's literal schedule (one launch per CMux) after the timed region; "
+                         "off by default so a rocprofv3 --stats run of the default command sees k_blind_rotate only "
+                         "in its persistent form")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,6 +176,25 @@ def main():
     br_ms = float(np.mean([eng.elapsed_ms(ev[k][0], ev[k][1]) for k in range(a.steps)]))
     ks_ms = float(np.mean([eng.elapsed_ms(ev[k][1], ev[k][2]) for k in range(a.steps)]))
 
+    # Also outside the timed region (single-GPU runs): BASELINE config 2's literal schedule, one
+    # external-product launch per CMux with the accumulators round-tripping through HBM (n + 2
+    # launches + key switch).  Same results bit for bit; reported next to the persistent kernel.
+    streamed = None
+    if world == 1 and a.streamed:
+        out2_d = eng.alloc(B * (cfg.n + 1) * 4)
+        s0, s1 = eng.event(), eng.event()
+        eng._chk(lib.tfhe_amd_bootstrap_streamed(eng.ctx, out2_d.ptr, mu, x_d.ptr, B))  # warm-up
+        eng.record(s0)
+        eng._chk(lib.tfhe_amd_bootstrap_streamed(eng.ctx, out2_d.ptr, mu, x_d.ptr, B))
+        eng.record(s1)
+        st_ms = eng.elapsed_ms(s0, s1)
+        same = bool(np.array_equal(out2_d.download(np.int32, (B, cfg.n + 1)), out_d.download(np.int32, (B, cfg.n + 1))))
+        per_launch_s = max(st_ms - ks_ms, 1e-9) * 1e-3 / cfg.n
+        streamed = {"ms_per_step": st_ms, "value": B / (st_ms * 1e-3), "unit": "bootstraps/s",
+                    "launches": cfg.n + 3, "identical_to_persistent": same,
+                    "extprod_launch_us": per_launch_s * 1e6,
+                    "hbm_frac": (B * BYTES_PER_CMUX + BYTES_PER_ROW) / per_launch_s / HBM_PEAK}
+
     if rank == 0:
         total = B * world * a.steps
         algo_bytes = B * cfg.n * BYTES_PER_CMUX + cfg.n * BYTES_PER_ROW
@@ -202,6 +225,8 @@ def main():
             "kernels_ms": {"blind_rotate_extract": br_ms, "keyswitch": ks_ms},
             "decrypt_check": bool(ok),
         }
+        if streamed is not None:
+            line["streamed_schedule"] = streamed
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)

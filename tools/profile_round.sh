@@ -19,7 +19,7 @@ mkdir -p "$OUT"
 VARIANTS=${VARIANTS:-"0 1 2"}
 
 echo "== plain bench (default schedule, with CPU baseline)" | tee "$OUT/log.txt"
-timeout 600 python3 bench.py --steps 5 --warmup 1 > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 600 python3 bench.py --steps 5 --warmup 1 --streamed > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -c 600 "$OUT/bench.json" | tee -a "$OUT/log.txt"
 
 for v in $VARIANTS; do
