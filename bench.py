@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--br-variant", type=int, default=0,
                     help="TFHE_AMD_OPT_BR_VARIANT: 0 default schedule, 1 register twiddles (1 wave/SIMD), 2 unpaired digits")
     ap.add_argument("--ks-gather", action="store_true", help="per-sample gather key switch instead of the tiled one")
+    ap.add_argument("--lib", default=None,
+                    help="alternative build of the engine library to time (e.g. libtfhe_amd_asmlds.so from "
+                         "`build.py --asm-lds`); default: the shipped libtfhe_amd.so")
     ap.add_argument("--streamed", action="store_true",
                     help="also time BASELINE config 2's literal schedule (one launch per CMux) after the timed region; "
                          "off by default so a rocprofv3 --stats run of the default command sees k_blind_rotate only "
@@ -106,7 +109,7 @@ def main():
     shard = importlib.import_module("experimental-tfhe_amd.shard")
     cfg = shard.GateConfig()
     # ---- children first (see module docstring)
-    if not os.path.exists(T.DEFAULT_LIB):
+    if a.lib is None and not os.path.exists(T.DEFAULT_LIB):
         importlib.import_module("experimental-tfhe_amd.build").build()
     cpu_line = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -123,7 +126,7 @@ def main():
         dev = torch.device("cuda", local)
 
     try:
-        job = shard.GateJob(cfg, SEED, device=local)  # identical key replicas on every rank
+        job = shard.GateJob(cfg, SEED, device=local, lib_path=a.lib)  # identical key replicas on every rank
     except T.TfheAmdError as e:
         raise SystemExit(f"bench.py needs a GPU: the engine has no CPU path ({e})")
     eng, lib = job.eng, job.eng.lib
@@ -216,7 +219,8 @@ def main():
             "config": {"workload": f"batch {B} gate bootstraps per GPU per step, {cfg.describe()}, persistent "
                                    "blind-rotation kernel + key-switch kernel, inputs resident in HBM",
                        "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, keys replicated",
-                       "br_variant": a.br_variant, "ks_kernel": "gather" if a.ks_gather else "tiled"},
+                       "br_variant": a.br_variant, "ks_kernel": "gather" if a.ks_gather else "tiled",
+                       "library": os.path.basename(a.lib) if a.lib else "libtfhe_amd.so"},
             "roofline": {"bound": "hbm", "kernel": "k_blind_rotate<int32,N=1024>", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
                          "kernel_ms": br_ms, "algorithmic_bytes_per_launch": algo_bytes,

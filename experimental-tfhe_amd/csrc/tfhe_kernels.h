@@ -70,6 +70,15 @@ struct Geom {
     // both directions of both transposes are bank-conflict free (LDS)
     TFHE_HOST_DEVICE static int idx1(int j) { return j + ((j >> 6) << CB); }
     TFHE_HOST_DEVICE static int idx2(int j) { return j + (j >> R); }
+    // padded index of register m relative to register 0 of the same lane, for the four
+    // (map, padding) pairs the transposes read with; independent of the lane (compile-time)
+    enum ReadMap { RD_A1 = 0, RD_B1 = 1, RD_B2 = 2, RD_C2 = 3 };
+    TFHE_HOST_DEVICE static constexpr int roff(int map, int m) {
+        return map == RD_A1 ? m * (64 + (1 << CB))                 // idx1(jA): t + 64m + (m << CB)
+             : map == RD_B1 ? (m << CB)                            // idx1(jB)
+             : map == RD_B2 ? (m << CB) + ((m << CB) >> R)         // idx2(jB): 9m (N=1024), 4m + (m>>2) (N=2048)
+                            : m;                                   // idx2(jC)
+    }
 };
 
 // -------------------------------------------------------------- butterflies
@@ -159,8 +168,34 @@ struct WaveFFT {
     using G = Geom<LOGN>;
     static constexpr int PPL = G::PPL;
 
-    // one wave-wide transpose through LDS: write with map widx, read with map ridx
-    template <class WIdx, class RIdx>
+#if defined(TFHE_LDS_READ_ASM) && !defined(TFHE_EMU)
+    // Eight ds_read_b64 from one address register with immediate offsets, then the wait -- in ONE
+    // asm statement, so no result is consumed before it has landed.  Exists because hipcc pairs
+    // adjacent 8-byte LDS reads into ds_read2_b64, which the LDS serves at half the ds_read_b64 rate
+    // (MI355X_MICROARCH.md, LDS table).  Opt-in build (build.py --asm-lds) until measured.
+    template <int MAP, int M0>
+    TFHE_DEVICE static void read8(double (&x)[PPL], uint32_t addr) {
+        asm volatile(
+            "ds_read_b64 %0, %8 offset:%9\n\t"
+            "ds_read_b64 %1, %8 offset:%10\n\t"
+            "ds_read_b64 %2, %8 offset:%11\n\t"
+            "ds_read_b64 %3, %8 offset:%12\n\t"
+            "ds_read_b64 %4, %8 offset:%13\n\t"
+            "ds_read_b64 %5, %8 offset:%14\n\t"
+            "ds_read_b64 %6, %8 offset:%15\n\t"
+            "ds_read_b64 %7, %8 offset:%16\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(x[M0 + 0]), "=&v"(x[M0 + 1]), "=&v"(x[M0 + 2]), "=&v"(x[M0 + 3]), "=&v"(x[M0 + 4]),
+              "=&v"(x[M0 + 5]), "=&v"(x[M0 + 6]), "=&v"(x[M0 + 7])
+            : "v"(addr), "i"(8 * G::roff(MAP, M0 + 0)), "i"(8 * G::roff(MAP, M0 + 1)), "i"(8 * G::roff(MAP, M0 + 2)),
+              "i"(8 * G::roff(MAP, M0 + 3)), "i"(8 * G::roff(MAP, M0 + 4)), "i"(8 * G::roff(MAP, M0 + 5)),
+              "i"(8 * G::roff(MAP, M0 + 6)), "i"(8 * G::roff(MAP, M0 + 7))
+            : "memory");
+    }
+#endif
+
+    // one wave-wide transpose through LDS: write with map widx, read with map ridx (= read map MAP)
+    template <int MAP, class WIdx, class RIdx>
     TFHE_DEVICE static void transpose(double (&x)[PPL], double *xch, WIdx widx, RIdx ridx) {
 #ifdef TFHE_ABLATE
         if (TFHE_ABL(ABL_NO_TRANSPOSES)) return;
@@ -168,8 +203,15 @@ struct WaveFFT {
 #pragma unroll
         for (int m = 0; m < PPL; m++) xch[widx(m)] = x[m];
         TFHE_WAVE_FENCE();
+#if defined(TFHE_LDS_READ_ASM) && !defined(TFHE_EMU)
+        // low 32 bits of a flat pointer into LDS = its LDS byte offset
+        const uint32_t addr = (uint32_t)(uintptr_t)(xch + ridx(0));
+        read8<MAP, 0>(x, addr);
+        if (PPL == 16) read8<MAP, (PPL == 16 ? 8 : 0)>(x, addr);
+#else
 #pragma unroll
         for (int m = 0; m < PPL; m++) x[m] = xch[ridx(m)];
+#endif
         TFHE_WAVE_FENCE();
     }
 
@@ -204,8 +246,8 @@ struct WaveFFT {
         auto rB = [&](int m) { return G::idx1(G::jB(t, m)); };
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            transpose(xr[p], xch, wA, rB);
-            transpose(xi[p], xch, wA, rB);
+            transpose<G::RD_B1>(xr[p], xch, wA, rB);
+            transpose<G::RD_B1>(xi[p], xch, wA, rB);
         }
         // pass B: strides s<<CB
 #pragma unroll
@@ -222,8 +264,8 @@ struct WaveFFT {
         auto rC = [&](int m) { return G::idx2(G::jC(t, m)); };
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            transpose(xr[p], xch, wB, rC);
-            transpose(xi[p], xch, wB, rC);
+            transpose<G::RD_C2>(xr[p], xch, wB, rC);
+            transpose<G::RD_C2>(xi[p], xch, wB, rC);
         }
         // pass C: (N=1024 only) stride 4 general stage, then size-4 and size-2 steps
         if (G::CB == 3) {
@@ -303,8 +345,8 @@ struct WaveFFT {
         auto rB = [&](int m) { return G::idx2(G::jB(t, m)); };
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            transpose(xr[p], xch, wC, rB);
-            transpose(xi[p], xch, wC, rB);
+            transpose<G::RD_B2>(xr[p], xch, wC, rB);
+            transpose<G::RD_B2>(xi[p], xch, wC, rB);
         }
         const int c = t & ((1 << G::CB) - 1);
 #pragma unroll
@@ -325,8 +367,8 @@ struct WaveFFT {
         auto rA = [&](int m) { return G::idx1(G::jA(t, m)); };
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            transpose(xr[p], xch, wB, rA);
-            transpose(xi[p], xch, wB, rA);
+            transpose<G::RD_A1>(xr[p], xch, wB, rA);
+            transpose<G::RD_A1>(xi[p], xch, wB, rA);
         }
 #pragma unroll
         for (int s = 1; s <= PPL / 2; s <<= 1) {

@@ -14,6 +14,8 @@ import oracle_py as O  # noqa: E402
 
 O.lib()
 T = importlib.import_module("experimental-tfhe_amd")
+if os.environ.get("TFHE_AMD_TEST_LIB"):  # check an experiment build (e.g. build.py --asm-lds) instead
+    T.DEFAULT_LIB = os.path.abspath(os.environ["TFHE_AMD_TEST_LIB"])
 import parity_checks as P  # noqa: E402
 
 max_stage = int(sys.argv[1]) if len(sys.argv) > 1 else 99

@@ -37,6 +37,12 @@ except Exception as e:
 PY
 done
 
+echo "== experiment build: hand-placed ds_read_b64 in the transposes (parity first, then timing)" | tee -a "$OUT/log.txt"
+TFHE_AMD_TEST_LIB=experimental-tfhe_amd/libtfhe_amd_asmlds.so timeout 300 python3 tests/gpu_stage_check.py 4 2>&1 | tail -4 | tee -a "$OUT/log.txt"
+timeout 300 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --lib experimental-tfhe_amd/libtfhe_amd_asmlds.so \
+    > "$OUT/bench_asmlds.json" 2> "$OUT/bench_asmlds.err"
+tail -c 400 "$OUT/bench_asmlds.json" | tee -a "$OUT/log.txt"
+
 echo "== ablation table (diagnostic build, wrong results by design, times only)" | tee -a "$OUT/log.txt"
 timeout 600 python3 tools/ablate.py --reps 3 2> "$OUT/ablate.err" | tee "$OUT/ablate.txt" | tee -a "$OUT/log.txt"
 
