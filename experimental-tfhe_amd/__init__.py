@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
     "tfhe_amd_set_bootstrap_key", "tfhe_amd_load_keyswitch_key",
     "tfhe_amd_ifft_int32", "tfhe_amd_ifft_torus64", "tfhe_amd_fft_torus32", "tfhe_amd_fft_torus64",
-    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_mux_rotate",
+    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_mux_rotate", "tfhe_amd_cmux",
     "tfhe_amd_blind_rotate", "tfhe_amd_blind_rotate_extract", "tfhe_amd_bootstrap_woks",
     "tfhe_amd_keyswitch", "tfhe_amd_bootstrap", "tfhe_amd_bootstrap_streamed", "tfhe_amd_bootstrap_host",
     "tfhe_amd_cb_bootstrap_woks", "tfhe_amd_modswitch",
@@ -104,6 +104,7 @@ def load_library(path=None):
     lib.tfhe_amd_lagrange_addmul.argtypes = [vp, f64p, f64p, f64p, C.c_int, C.c_int]
     lib.tfhe_amd_extern_mul.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     lib.tfhe_amd_mux_rotate.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
+    lib.tfhe_amd_cmux.argtypes = [vp, vp, vp, i32p, vp, vp, C.c_int]
     lib.tfhe_amd_blind_rotate.argtypes = [vp, vp, i32p, C.c_int]
     lib.tfhe_amd_blind_rotate_extract.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
     lib.tfhe_amd_bootstrap_woks.argtypes = [vp, i32p, C.c_int32, i32p, C.c_int]
@@ -331,6 +332,18 @@ class Engine:
         d.free()
         r.free()
         return out
+
+    def cmux(self, g, sel, d0, d1):
+        d0 = np.ascontiguousarray(d0, self.torus).reshape(-1, 2, self.params.N)
+        d1 = np.ascontiguousarray(d1, self.torus).reshape(d0.shape)
+        a0, a1 = self.to_device(d0), self.to_device(d1)
+        out = self.alloc(d0.nbytes)
+        s = self.to_device(np.ascontiguousarray(sel, np.int32)) if sel is not None else None
+        self._chk(self.lib.tfhe_amd_cmux(self.ctx, out.ptr, g, s.ptr if s else None, a0.ptr, a1.ptr, d0.shape[0]))
+        res = out.download(self.torus, d0.shape)
+        for d in (a0, a1, out) + ((s,) if s else ()):
+            d.free()
+        return res
 
     def blind_rotate(self, acc, bara):
         acc = np.ascontiguousarray(acc, self.torus).reshape(-1, 2, self.params.N)

@@ -651,6 +651,35 @@ int tfhe_amd_mux_rotate(tfhe_amd_ctx *c, void *acc_d, const tfhe_amd_gsw *g, int
     return run_steps(c, acc_d, g, index, 1, barai_d, 1, batch, 0);
 }
 
+// CMux on data: out = gsw[sel] (x) (d1 - d0) + d0 -- one launch, subtraction and addition fused
+// into the kernel's load/store
+int tfhe_amd_cmux(tfhe_amd_ctx *c, void *out_d, const tfhe_amd_gsw *g, const int32_t *sel_d, const void *d0_d,
+                  const void *d1_d, int batch) {
+    if (!c || !out_d || !g || !d0_d || !d1_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    REQUIRE(c, g->ctx == c, "TGSW handle belongs to another context");
+    if (batch == 0) return TFHE_AMD_OK;
+    if (c->p.torus_bits == 32) {
+        BlindRotateArgs<int32_t> a;
+        fill_common(c, a, g, 0, 1, batch);
+        a.acc_io = (int32_t *)out_d;
+        a.cmux_d0 = (const int32_t *)d0_d;
+        a.cmux_d1 = (const int32_t *)d1_d;
+        a.gsw_sel = sel_d;
+        a.gsw_sample_stride = (long long)g->sample_complex;
+        a.flags = BR_NO_ROTATE | BR_CMUX_DATA;
+        return launch_br32(c, a);
+    }
+    BlindRotateArgs<int64_t> a;
+    fill_common(c, a, g, 0, 1, batch);
+    a.acc_io = (int64_t *)out_d;
+    a.cmux_d0 = (const int64_t *)d0_d;
+    a.cmux_d1 = (const int64_t *)d1_d;
+    a.gsw_sel = sel_d;
+    a.gsw_sample_stride = (long long)g->sample_complex;
+    a.flags = BR_NO_ROTATE | BR_CMUX_DATA;
+    return launch_br64(c, a);
+}
+
 // ---- L3
 int tfhe_amd_blind_rotate(tfhe_amd_ctx *c, void *acc_d, const int32_t *bara_d, int batch) {
     if (!c || !acc_d || !bara_d || batch < 0) return TFHE_AMD_ERR_PARAM;

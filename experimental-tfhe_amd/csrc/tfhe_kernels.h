@@ -679,6 +679,7 @@ enum : uint32_t {
     BR_TV_CONST = 1u << 3,      // test vector = tv_const everywhere (tfhe_bootstrap_woKS_FFT)
     BR_TV_HALF = 1u << 4,       // test vector = -tv_const for j<N/2, +tv_const above (poc:551-553)
     BR_NO_ROTATE = 1u << 5,     // plain external product steps (tGswFFTExternMulToTLwe): no X^a, no +acc
+    BR_CMUX_DATA = 1u << 6,     // CMux on data: acc = d1 - d0 on load, + d0 on store (d0 = cmux_d0, d1 = cmux_d1)
 };
 
 template <typename T>
@@ -688,6 +689,10 @@ struct BlindRotateArgs {
     const int32_t *rot;     // [batch][rot_stride]: rotations (or LWE a_i); entry n_steps = barb / b
     T *acc_io;              // [batch][2][N] (in and/or out)
     const T *tv;            // test vector(s) [N] (tv_stride 0) or [batch][N]
+    const T *cmux_d0;       // BR_CMUX_DATA: [batch][2][N]
+    const T *cmux_d1;       // BR_CMUX_DATA: [batch][2][N]
+    const int32_t *gsw_sel; // per-sample TGSW index into bk (null: 0)
+    long long gsw_sample_stride;  // complex elements per TGSW sample (for gsw_sel)
     T *lwe_out;             // [batch][N+1]
     long long tv_stride;
     long long bk_step_stride;  // complex elements between consecutive steps (0: same row every step)
@@ -772,17 +777,23 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             w.acc[j] = 0;
             w.acc[N + j] = (T)((idx & N) ? (U)(0 - v) : v);
         }
+    } else if (A.flags & BR_CMUX_DATA) {
+        const T *d0 = A.cmux_d0 + (size_t)ct * 2 * N, *d1 = A.cmux_d1 + (size_t)ct * 2 * N;
+#pragma unroll
+        for (int m = 0; m < 4 * PPL; m++) w.acc[t + 64 * m] = (T)((U)d1[t + 64 * m] - (U)d0[t + 64 * m]);
     } else {
         const T *src = A.acc_io + (size_t)ct * 2 * N;
 #pragma unroll
         for (int m = 0; m < 4 * PPL; m++) w.acc[t + 64 * m] = src[t + 64 * m];
     }
     TFHE_WAVE_FENCE();
+    const double2 *bk0 = A.bk;
+    if (A.gsw_sel) bk0 += (size_t)TFHE_UNIFORM(A.gsw_sel[ct]) * A.gsw_sample_stride;
 
     // ---- CMux loop (lwe_functions.cpp:337-361)
 #pragma unroll 1
     for (int i = 0; i < A.n_steps; i++) {
-        const double2 *bkrow = A.bk + (size_t)i * A.bk_step_stride;
+        const double2 *bkrow = bk0 + (size_t)i * A.bk_step_stride;
         int a = 0;
         const bool rotate = !(A.flags & BR_NO_ROTATE);
         if (rotate) {
@@ -803,6 +814,11 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             out[j] = (j == 0) ? w.acc[0] : (T)(0 - (U)w.acc[N - j]);
         }
         if (t == 0) out[N] = (T)((U)w.acc[N] + (U)A.out_b_add);
+    } else if (A.flags & BR_CMUX_DATA) {
+        const T *d0 = A.cmux_d0 + (size_t)ct * 2 * N;
+        T *dst = A.acc_io + (size_t)ct * 2 * N;
+#pragma unroll
+        for (int m = 0; m < 4 * PPL; m++) dst[t + 64 * m] = (T)((U)w.acc[t + 64 * m] + (U)d0[t + 64 * m]);
     } else {
         T *dst = A.acc_io + (size_t)ct * 2 * N;
 #pragma unroll

@@ -135,6 +135,13 @@ int tfhe_amd_extern_mul(tfhe_amd_ctx *ctx, void *acc_d, const tfhe_amd_gsw *gsw,
 int tfhe_amd_mux_rotate(tfhe_amd_ctx *ctx, void *acc_d, const tfhe_amd_gsw *gsw, int index,
                         const int32_t *barai_d, int batch);
 
+/* CMux on data, the consumer of a circuit bootstrap (stub `CMux` at poc:877-879; in library terms
+ * tGswFFTExternMulToTLwe applied to d1 - d0, plus d0): out[i] = gsw[sel[i]] (x) (d1[i] - d0[i]) + d0[i].
+ * sel_d: [batch] TGSW indices into `gsw` (NULL: index 0 for every sample); d0_d, d1_d, out_d:
+ * [batch][2][N] torus; out_d may alias d1_d.  One level of a vertical-packing / LUT tree. */
+int tfhe_amd_cmux(tfhe_amd_ctx *ctx, void *out_d, const tfhe_amd_gsw *gsw, const int32_t *sel_d, const void *d0_d,
+                  const void *d1_d, int batch);
+
 /* ---- L3: bootstrapping -------------------------------------------------------------- */
 /* tfhe_blindRotate_FFT (CB/lwe_functions.cpp:337-361): acc_d [batch][2][N] in place,
  * bara_d [batch][n] rotations in [0,2N) */

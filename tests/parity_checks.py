@@ -192,6 +192,47 @@ def check_torus64_path(lib_path, N, n, l, Bgbit, B, seed=31):
         e.close()
 
 
+# ------------------------------------------------------------------ CMux on data
+def check_cmux_data(lib_path, N=1024, l=2, Bgbit=8, B=11, seed=71):
+    """out = gsw[sel] (x) (d1 - d0) + d0 with a per-sample TGSW selector (one level of a
+    vertical-packing tree over circuit-bootstrap outputs, gadget l1=2, Bgbit1=8 as in poc:70-85),
+    against the oracle's external product, plus the functional property: TGSW(1) selects d1,
+    TGSW(0) selects d0."""
+    rs = np.random.RandomState(seed)
+    tkey = O.keygen_binary(N, SEED, 2)
+    bits = np.array([0, 1, 1, 0], np.int32)
+    gsw_lag = O.bk_create32(N, bits, tkey, l, Bgbit, 2.0 ** -30, SEED, 9000)   # TGSW encryptions of the bits
+    e = T.Engine(torus_bits=32, n=4, N=N, l=l, Bgbit=Bgbit, ks_t=0, lib_path=lib_path)
+    try:
+        g = e.gsw_from_fft(gsw_lag)
+        d0 = rs.randint(-2 ** 31, 2 ** 31, size=(B, 2, N)).astype(np.int32)
+        d1 = rs.randint(-2 ** 31, 2 ** 31, size=(B, 2, N)).astype(np.int32)
+        sel = rs.randint(0, 4, size=B).astype(np.int32)
+
+        def want_for(s_, a0, a1):
+            diff = ((a1.astype(np.int64) - a0) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+            prod = O.extprod32(N, diff, gsw_lag[s_], l, Bgbit).reshape(2, N)
+            return ((prod.astype(np.int64) + a0) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+
+        want = np.stack([want_for(sel[b], d0[b], d1[b]) for b in range(B)])
+        assert np.array_equal(e.cmux(g, sel, d0, d1), want), "CMux on data"
+        want0 = np.stack([want_for(0, d0[b], d1[b]) for b in range(B)])
+        assert np.array_equal(e.cmux(g, None, d0, d1), want0), "CMux on data, default selector"
+        # functional check on noiseless trivial TLWE samples (a = 0, b = message polynomial)
+        m0 = (rs.randint(-4, 4, size=(B, N)).astype(np.int64) << 28).astype(np.int32)
+        m1 = (rs.randint(-4, 4, size=(B, N)).astype(np.int64) << 28).astype(np.int32)
+        t0, t1 = np.zeros((B, 2, N), np.int32), np.zeros((B, 2, N), np.int32)
+        t0[:, 1], t1[:, 1] = m0, m1
+        out = e.cmux(g, sel, t0, t1)
+        for b in range(B):
+            ph = O.tlwe_phase32(out[b].ravel(), tkey).astype(np.int64)
+            chosen = (m1 if bits[sel[b]] else m0)[b].astype(np.int64)
+            err = ((ph - chosen + 2 ** 31) % 2 ** 32) - 2 ** 31
+            assert np.abs(err).max() < 2 ** 24, (b, np.abs(err).max())
+    finally:
+        e.close()
+
+
 # ------------------------------------------------------- rounding range extremes
 def check_rounding_extremes(lib_path, br_variant=0):
     """Torus32 rounding has a short sequence valid for |x| < 2^51 and an exact fallback (DESIGN.md,

@@ -45,6 +45,10 @@ def test_keyswitch_real_shapes_emu(emu_lib, n_out, t, bb, B):
     P.check_keyswitch_shapes(emu_lib, 1024, n_out, t, bb, B)
 
 
+def test_cmux_on_data_emu(emu_lib):
+    P.check_cmux_data(emu_lib, B=5)
+
+
 def test_circuit_bootstrap_emu(emu_lib):
     # N2 = 2048, l2 = 4, Bgbit2 = 9, privKS base 8 as in the PoC; short n0 / key-switch lengths
     P.check_circuit_bootstrap(emu_lib, n0=2, N1=1024, N2=2048, l1=2, bg1=8, l2=4, bg2=9, t10=3, bb10=2, t21=2,

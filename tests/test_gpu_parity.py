@@ -103,6 +103,12 @@ def test_circuit_bootstrap_blind_rotation_full(gpu_lib):
     P.check_torus64_path(gpu_lib, N=2048, n=500, l=4, Bgbit=9, B=4, seed=41)
 
 
+def test_cmux_on_data(gpu_lib):
+    """vertical-packing building block on TGSW selectors with the circuit-bootstrap output gadget"""
+    P.check_cmux_data(gpu_lib, B=37)
+    P.check_cmux_data(gpu_lib, N=2048, l=3, Bgbit=7, B=6, seed=72)
+
+
 def test_circuit_bootstrap_pipeline(gpu_lib):
     """BASELINE config 3: tfhe_CircuitBootstrapFFT with the PoC ring sizes and gadgets (N1=1024,
     N2=2048, l2=4, Bgbit2=9, l1=2, Bgbit1=8, preKS 6x2, privKS base 8); n0 and the privKS length are
