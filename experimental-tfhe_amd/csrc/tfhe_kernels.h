@@ -465,6 +465,18 @@ TFHE_DEVICE typename Torus<T>::U rot_minus_one(const T *p, int i, int a) {
     const U rot = (idx & N) ? (U)(0 - src) : src;
     return rot - (U)p[i];
 }
+// The same coefficient with the lane's rotation base hoisted: base = (t - a) mod 2N is computed once
+// per CMux, i = t + K with K a compile-time constant.  Bit LOGN of base+K is the sign of the wrapped
+// term (higher bits do not matter), its low LOGN bits the source index.
+template <typename T, int LOGN>
+TFHE_DEVICE typename Torus<T>::U rot_minus_one_hoisted(const T *p, int base, int K, int t) {
+    using U = typename Torus<T>::U;
+    constexpr int N = 1 << LOGN;
+    const int idx = base + K;
+    const U src = (U)p[idx & (N - 1)];
+    const U rot = (idx & N) ? (U)(0 - src) : src;
+    return rot - (U)p[t + K];
+}
 // one coefficient of X^a * p, a in [0, 2N)   (numeric_functions.cpp:327-347)
 template <typename T, int LOGN>
 TFHE_DEVICE T rot_only(const T *p, int i, int a) {
@@ -594,11 +606,11 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
 #else
         if (rotate) {
 #endif
+            const int base = (t - a) & (2 * N - 1);
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
-                const int j = G::jA(t, m);
-                lo[m] = (rot_minus_one<T, LOGN>(p, j, a) + offset) ^ flip;
-                hi[m] = (rot_minus_one<T, LOGN>(p, j + NC, a) + offset) ^ flip;
+                lo[m] = (rot_minus_one_hoisted<T, LOGN>(p, base, 64 * m, t) + offset) ^ flip;
+                hi[m] = (rot_minus_one_hoisted<T, LOGN>(p, base, 64 * m + NC, t) + offset) ^ flip;
             }
         } else {
 #pragma unroll
