@@ -26,10 +26,10 @@ ABI_SYMBOLS = [
     "tfhe_amd_set_stream", "tfhe_amd_sync", "tfhe_amd_set_option", "tfhe_amd_get_tables",
     "tfhe_amd_event_create", "tfhe_amd_event_record", "tfhe_amd_event_elapsed_ms", "tfhe_amd_event_destroy",
     "tfhe_amd_malloc", "tfhe_amd_free", "tfhe_amd_memcpy_h2d", "tfhe_amd_memcpy_d2h",
-    "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
+    "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_from_torus_d", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
     "tfhe_amd_set_bootstrap_key", "tfhe_amd_load_keyswitch_key",
     "tfhe_amd_ifft_int32", "tfhe_amd_ifft_torus64", "tfhe_amd_fft_torus32", "tfhe_amd_fft_torus64",
-    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_mux_rotate", "tfhe_amd_cmux",
+    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_mux_rotate", "tfhe_amd_cmux", "tfhe_amd_lut_eval",
     "tfhe_amd_blind_rotate", "tfhe_amd_blind_rotate_extract", "tfhe_amd_bootstrap_woks",
     "tfhe_amd_keyswitch", "tfhe_amd_bootstrap", "tfhe_amd_bootstrap_streamed", "tfhe_amd_bootstrap_host",
     "tfhe_amd_cb_bootstrap_woks", "tfhe_amd_modswitch",
@@ -92,6 +92,7 @@ def load_library(path=None):
     lib.tfhe_amd_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     lib.tfhe_amd_gsw_from_fft.argtypes = [vp, f64p, C.c_int, C.POINTER(vp)]
     lib.tfhe_amd_gsw_from_torus.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    lib.tfhe_amd_gsw_from_torus_d.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
     lib.tfhe_amd_gsw_free.argtypes = [vp]
     lib.tfhe_amd_gsw_free.restype = None
     lib.tfhe_amd_gsw_export_fft.argtypes = [vp, vp, C.c_int, f64p]
@@ -105,6 +106,7 @@ def load_library(path=None):
     lib.tfhe_amd_extern_mul.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     lib.tfhe_amd_mux_rotate.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
     lib.tfhe_amd_cmux.argtypes = [vp, vp, vp, i32p, vp, vp, C.c_int]
+    lib.tfhe_amd_lut_eval.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int]
     lib.tfhe_amd_blind_rotate.argtypes = [vp, vp, i32p, C.c_int]
     lib.tfhe_amd_blind_rotate_extract.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
     lib.tfhe_amd_bootstrap_woks.argtypes = [vp, i32p, C.c_int32, i32p, C.c_int]
@@ -267,6 +269,13 @@ class Engine:
         self._gsw.append(g)
         return g
 
+    def gsw_from_torus_d(self, dev_torus, count):
+        """tGswToFFTConvert of `count` TGSW samples already in device memory (DeviceBuffer or pointer)"""
+        g = C.c_void_p()
+        self._chk(self.lib.tfhe_amd_gsw_from_torus_d(self.ctx, getattr(dev_torus, "ptr", dev_torus), count, C.byref(g)))
+        self._gsw.append(g)
+        return g
+
     def gsw_export_fft(self, g, index):
         out = np.empty((2 * self.params.l, 2, self.params.N))
         self._chk(self.lib.tfhe_amd_gsw_export_fft(self.ctx, g, index, _np_ptr(out)))
@@ -345,6 +354,18 @@ class Engine:
             d.free()
         return res
 
+    def lut_eval(self, bits, d, lut, batch):
+        """LUT evaluation by vertical packing: `bits` = TGSW handle of batch*d samples (item b's bit i
+        at b*d + i), lut [max(1, 2^(d-log2 N))][N] plaintext torus polynomials -> [batch][N+1] LWE"""
+        N = self.params.N
+        lut = np.ascontiguousarray(lut, self.torus).reshape(-1, N)
+        t, out = self.to_device(lut), self.alloc(batch * (N + 1) * np.dtype(self.torus).itemsize)
+        self._chk(self.lib.tfhe_amd_lut_eval(self.ctx, out.ptr, bits, d, t.ptr, batch))
+        res = out.download(self.torus, (batch, N + 1))
+        t.free()
+        out.free()
+        return res
+
     def blind_rotate(self, acc, bara):
         acc = np.ascontiguousarray(acc, self.torus).reshape(-1, 2, self.params.N)
         bara = np.ascontiguousarray(bara, np.int32).reshape(acc.shape[0], self.params.n)
@@ -411,6 +432,7 @@ class CircuitBootstrap:
         if rc != OK:
             raise TfheAmdError(f"tfhe_amd_cb_create failed with status {rc}")
         self.ctx = C.c_void_p(self.lib.tfhe_amd_cb_ctx_lvl2(self.cb))  # memory helpers go through lvl2
+        self.ctx10 = C.c_void_p(self.lib.tfhe_amd_cb_ctx_lvl10(self.cb))  # Torus32, N1, gadget (l1, Bgbit1)
 
     def _chk(self, rc):
         if rc != OK:
@@ -475,6 +497,33 @@ class CircuitBootstrap:
         self._chk(self.lib.tfhe_amd_circuit_bootstrap(self.cb, d_o, d_x, B))
         self.lib.tfhe_amd_free(self.ctx, d_x)
         return self._out(d_o, np.int32, (B, 2, self.p.l1, 2, self.p.N1))
+
+
+    def circuit_bootstrap_lut(self, x, d, lut):
+        """BASELINE config 3's chain, entirely on the device: circuit-bootstrap B*d LWE-encrypted bits
+        (row b*d + i = bit i of item b), convert the TGSW32 outputs to Lagrange form, evaluate the
+        2^d-entry table by vertical packing.  Returns ([B*d][2][l1][2][N1] TGSW32, [B][N1+1] LWE)."""
+        p = self.p
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, p.N1 + 1)
+        B = x.shape[0] // d
+        assert B * d == x.shape[0]
+        lut = np.ascontiguousarray(lut, np.int32).reshape(-1, p.N1)
+        d_x, d_lut = self._dev(x), self._dev(lut)
+        d_g = self._dev(np.zeros((B * d, 2, p.l1, 2, p.N1), np.int32))
+        d_o = self._dev(np.zeros((B, p.N1 + 1), np.int32))
+        self._chk(self.lib.tfhe_amd_circuit_bootstrap(self.cb, d_g, d_x, B * d))
+        bits = C.c_void_p()
+        rc = self.lib.tfhe_amd_gsw_from_torus_d(self.ctx10, d_g, B * d, C.byref(bits))
+        if rc == OK:
+            rc = self.lib.tfhe_amd_lut_eval(self.ctx10, d_o, bits, d, d_lut, B)
+        if rc != OK:
+            raise TfheAmdError(f"status {rc}: {self.lib.tfhe_amd_last_error(self.ctx10).decode()}")
+        out = self._out(d_o, np.int32, (B, p.N1 + 1))
+        tgsw = self._out(d_g, np.int32, (B * d, 2, p.l1, 2, p.N1))
+        self.lib.tfhe_amd_gsw_free(bits)
+        self.lib.tfhe_amd_free(self.ctx, d_x)
+        self.lib.tfhe_amd_free(self.ctx, d_lut)
+        return tgsw, out
 
 
 # ---- harness wrappers (host side of the ABI; usable without a GPU) --------------------

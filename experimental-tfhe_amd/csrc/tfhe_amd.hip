@@ -41,6 +41,7 @@ struct tfhe_amd_ctx {
     size_t ws_lwe_bytes;
     void *ws_acc;
     size_t ws_acc_bytes;
+    int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     bool ks_force_gather;  // TFHE_AMD_OPT_KS_GATHER: per-sample gather kernel even when the tiled one applies
     int br_variant;        // TFHE_AMD_OPT_BR_VARIANT
     std::vector<const void *> lds_configured;  // kernels whose dynamic-LDS limit is raised on this device
@@ -172,13 +173,13 @@ int launch_br64(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
     return c->logn == 10 ? launch_br_t<int64_t, 10, 4, 2>(c, a) : launch_br_t<int64_t, 11, 3, 1>(c, a);
 }
 
-template <typename TIN, int LOGN>
+template <typename TIN, int LOGN, bool PACK = false>
 int launch_ifft_t(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
     constexpr int WAVES = 4;
     using Lds = FftLds<LOGN, WAVES>;
-    auto kernel = k_ifft_batch<TIN, LOGN, WAVES>;
+    auto kernel = k_ifft_batch<TIN, LOGN, WAVES, PACK>;
     if (int rc = set_lds(c, kernel, Lds::total)) return rc;
-    TFHE_LAUNCH((k_ifft_batch<TIN, LOGN, WAVES>), dim3((batch + WAVES - 1) / WAVES), dim3(WAVES * 64), Lds::total,
+    TFHE_LAUNCH((k_ifft_batch<TIN, LOGN, WAVES, PACK>), dim3((batch + WAVES - 1) / WAVES), dim3(WAVES * 64), Lds::total,
                 c->stream, out_d, in_d, (const double2 *)c->tw_d, batch);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
@@ -266,6 +267,92 @@ void fill_common(const tfhe_amd_ctx *c, BlindRotateArgs<T> &a, const tfhe_amd_gs
     a.n_steps = steps;
     a.batch = batch;
 }
+int launch_br(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) { return launch_br32(c, a); }
+int launch_br(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) { return launch_br64(c, a); }
+
+template <typename T>
+int cmux_t(tfhe_amd_ctx *c, void *out_d, const tfhe_amd_gsw *g, const int32_t *sel_d, const void *d0_d, const void *d1_d,
+           int batch) {
+    BlindRotateArgs<T> a;
+    fill_common(c, a, g, 0, 1, batch);
+    a.acc_io = (T *)out_d;
+    a.cmux_d0 = (const T *)d0_d;
+    a.cmux_d1 = (const T *)d1_d;
+    a.gsw_sel = sel_d;
+    a.gsw_sample_stride = (long long)g->sample_complex;
+    a.cmux_stride = 2ll * c->p.N;
+    a.flags = BR_NO_ROTATE | BR_CMUX_DATA;
+    return launch_br(c, a);
+}
+
+// LUT evaluation by vertical packing (see tfhe_amd.h).  items = batch, TGSW sample b*d + i = bit i of item b.
+//   tree:   level j (bit logN + j) halves the table: new[p] = CMux(bit, cur[2p], cur[2p+1]);
+//           level 0 reads the shared plaintext table, later levels the previous level's TLWE samples
+//   rotate: acc <- CMux(bit i, acc, X^{-2^i} acc), i < min(d, logN)  == a blind rotation whose "key" is
+//           the item's own TGSW samples and whose rotations are the constants 2N - 2^i; extraction fused
+template <typename T>
+int lut_eval_t(tfhe_amd_ctx *c, void *lwe_out_d, const tfhe_amd_gsw *bits, int d, const void *lut_d, int batch) {
+    const int N = c->p.N, logn = c->logn;
+    const int low = d < logn ? d : logn, levels = d - low;
+    if (!c->vp_rot_d) {
+        // row r = the rotations of an r-bit selection, (2N - 2^i)_{i<r}, then 0 in the slot the
+        // test-vector initialisation reads as "barb"
+        int32_t rot[12 * 16] = {0};
+        for (int r = 0; r <= logn; r++)
+            for (int i = 0; i < r; i++) rot[r * 16 + i] = 2 * N - (1 << i);
+        HIPCHECK(c, hipMalloc((void **)&c->vp_rot_d, sizeof(rot)));
+        HIPCHECK(c, hipMemcpyAsync(c->vp_rot_d, rot, sizeof(rot), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));  // `rot` is a stack array
+    }
+    BlindRotateArgs<T> a;
+    const T *cur = nullptr;
+    if (levels > 0) {
+        // two ping-pong buffers: level 0 writes batch * 2^(levels-1) samples, level 1 half of that, ...
+        const size_t sample = (size_t)2 * N * sizeof(T), first = ((size_t)batch << (levels - 1)) * sample;
+        if (int rc = grow(c, &c->ws_acc, &c->ws_acc_bytes, first + first / 2)) return rc;
+        T *buf[2] = {(T *)c->ws_acc, (T *)((char *)c->ws_acc + first)};
+        for (int j = 0; j < levels; j++) {
+            const int pairs = 1 << (levels - 1 - j);
+            if ((long long)batch * pairs > 0x7fffffffLL) return fail(c, TFHE_AMD_ERR_PARAM, "LUT tree level too large");
+            fill_common(c, a, bits, 0, 1, batch * pairs);
+            a.acc_io = buf[j & 1];
+            a.gsw_sample_stride = (long long)bits->sample_complex;
+            a.sel_div = pairs;
+            a.sel_mul = d;
+            a.sel_add = low + j;
+            a.flags = BR_NO_ROTATE | BR_CMUX_DATA;
+            if (j == 0) {  // shared plaintext table: item (b, p) reads polynomials 2p and 2p + 1
+                a.cmux_d0 = (const T *)lut_d;
+                a.cmux_d1 = (const T *)lut_d + N;
+                a.cmux_stride = 2ll * N;
+                a.cmux_period = pairs;
+                a.flags |= BR_CMUX_TRIVIAL;
+            } else {       // previous level: item (b, p) reads samples (b, 2p) and (b, 2p + 1)
+                a.cmux_d0 = cur;
+                a.cmux_d1 = cur + 2 * N;
+                a.cmux_stride = 4ll * N;
+            }
+            if (int rc = launch_br(c, a)) return rc;
+            cur = buf[j & 1];
+        }
+    }
+    fill_common(c, a, bits, 0, low, batch);
+    a.gsw_sample_stride = (long long)bits->sample_complex;
+    a.sel_div = 1;
+    a.sel_mul = d;
+    a.rot = c->vp_rot_d + low * 16;
+    a.rot_stride = 0;
+    a.lwe_out = (T *)lwe_out_d;
+    a.flags = BR_EXTRACT;
+    if (levels > 0) {
+        a.acc_io = const_cast<T *>(cur);
+    } else {  // d <= logN: the table is one polynomial, the accumulator starts as its trivial sample
+        a.tv = (const T *)lut_d;
+        a.tv_stride = 0;
+        a.flags |= BR_INIT_TESTVEC;
+    }
+    return launch_br(c, a);
+}
 
 }  // namespace
 
@@ -300,6 +387,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") != nullptr;
     c->br_variant = getenv("TFHE_AMD_BR_VARIANT") ? atoi(getenv("TFHE_AMD_BR_VARIANT")) : 0;
     c->ws_lwe = c->ws_acc = nullptr;
+    c->vp_rot_d = nullptr;
     c->ws_lwe_bytes = c->ws_acc_bytes = 0;
     if (hipSetDevice(device) != hipSuccess) {
         delete c;
@@ -349,6 +437,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     if (c->ksd_d) (void)hipFree(c->ksd_d);
     if (c->ws_lwe) (void)hipFree(c->ws_lwe);
     if (c->ws_acc) (void)hipFree(c->ws_acc);
+    if (c->vp_rot_d) (void)hipFree(c->vp_rot_d);
 #ifndef TFHE_EMU
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
 #endif
@@ -493,40 +582,42 @@ int tfhe_amd_gsw_from_fft(tfhe_amd_ctx *c, const double *gsw_fft, int count, tfh
     return TFHE_AMD_OK;
 }
 
-int tfhe_amd_gsw_from_torus(tfhe_amd_ctx *c, const void *gsw_torus, int count, tfhe_amd_gsw **out) {
-    if (!c || !gsw_torus || !out || count < 1) return TFHE_AMD_ERR_PARAM;
+// tGswToFFTConvert on device-resident coefficients: every polynomial through
+// execute_reverse_torus32/64, written directly in the key layout (k_ifft_batch<PACK>)
+int tfhe_amd_gsw_from_torus_d(tfhe_amd_ctx *c, const void *gsw_torus_d, int count, tfhe_amd_gsw **out) {
+    if (!c || !gsw_torus_d || !out || count < 1) return TFHE_AMD_ERR_PARAM;
     const long long rows = (long long)count * 2 * c->p.l * 2;
-    const size_t tbytes = (size_t)rows * c->p.N * torus_bytes(c);
-    const size_t dbytes = (size_t)rows * c->p.N * sizeof(double);
-    void *tor = nullptr;
-    double *lag = nullptr;
-    HIPCHECK(c, hipMalloc(&tor, tbytes));
-    if (hipMalloc((void **)&lag, dbytes) != hipSuccess) {
-        (void)hipFree(tor);
-        return fail(c, TFHE_AMD_ERR_ALLOC, "hipMalloc(lagrange tmp)");
-    }
-    int rc = TFHE_AMD_OK;
+    REQUIRE(c, rows <= 0x7fffffffLL, "too many TGSW samples for one conversion");
     tfhe_amd_gsw *g = nullptr;
-    if (hipMemcpyAsync(tor, gsw_torus, tbytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
-        rc = fail(c, TFHE_AMD_ERR_DEVICE, "upload gsw");
-    // tGswToFFTConvert: every polynomial through execute_reverse_torus32/64
-    if (!rc) {
-        if (c->p.torus_bits == 32)
-            rc = tfhe_amd_ifft_int32(c, lag, (const int32_t *)tor, (int)rows);
-        else
-            rc = tfhe_amd_ifft_torus64(c, lag, (const int64_t *)tor, (int)rows);
-    }
-    if (!rc) rc = gsw_alloc(c, count, &g);
-    if (!rc) rc = pack_rows(c, g->data_d, lag, rows);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(tor);
-    (void)hipFree(lag);
+    int rc = gsw_alloc(c, count, &g);
+    if (rc) return rc;
+    double *dst = reinterpret_cast<double *>(g->data_d);
+    if (c->p.torus_bits == 32)
+        rc = c->logn == 10 ? launch_ifft_t<int32_t, 10, true>(c, dst, (const int32_t *)gsw_torus_d, (int)rows)
+                           : launch_ifft_t<int32_t, 11, true>(c, dst, (const int32_t *)gsw_torus_d, (int)rows);
+    else
+        rc = c->logn == 10 ? launch_ifft_t<int64_t, 10, true>(c, dst, (const int64_t *)gsw_torus_d, (int)rows)
+                           : launch_ifft_t<int64_t, 11, true>(c, dst, (const int64_t *)gsw_torus_d, (int)rows);
     if (rc) {
-        if (g) tfhe_amd_gsw_free(g);
+        tfhe_amd_gsw_free(g);
         return rc;
     }
     *out = g;
     return TFHE_AMD_OK;
+}
+
+int tfhe_amd_gsw_from_torus(tfhe_amd_ctx *c, const void *gsw_torus, int count, tfhe_amd_gsw **out) {
+    if (!c || !gsw_torus || !out || count < 1) return TFHE_AMD_ERR_PARAM;
+    const size_t tbytes = (size_t)count * 2 * c->p.l * 2 * c->p.N * torus_bytes(c);
+    void *tor = nullptr;
+    HIPCHECK(c, hipMalloc(&tor, tbytes));
+    int rc = TFHE_AMD_OK;
+    if (hipMemcpyAsync(tor, gsw_torus, tbytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        rc = fail(c, TFHE_AMD_ERR_DEVICE, "upload gsw");
+    if (!rc) rc = tfhe_amd_gsw_from_torus_d(c, tor, count, out);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(tor);
+    return rc;
 }
 
 void tfhe_amd_gsw_free(tfhe_amd_gsw *g) {
@@ -658,26 +749,18 @@ int tfhe_amd_cmux(tfhe_amd_ctx *c, void *out_d, const tfhe_amd_gsw *g, const int
     if (!c || !out_d || !g || !d0_d || !d1_d || batch < 0) return TFHE_AMD_ERR_PARAM;
     REQUIRE(c, g->ctx == c, "TGSW handle belongs to another context");
     if (batch == 0) return TFHE_AMD_OK;
-    if (c->p.torus_bits == 32) {
-        BlindRotateArgs<int32_t> a;
-        fill_common(c, a, g, 0, 1, batch);
-        a.acc_io = (int32_t *)out_d;
-        a.cmux_d0 = (const int32_t *)d0_d;
-        a.cmux_d1 = (const int32_t *)d1_d;
-        a.gsw_sel = sel_d;
-        a.gsw_sample_stride = (long long)g->sample_complex;
-        a.flags = BR_NO_ROTATE | BR_CMUX_DATA;
-        return launch_br32(c, a);
-    }
-    BlindRotateArgs<int64_t> a;
-    fill_common(c, a, g, 0, 1, batch);
-    a.acc_io = (int64_t *)out_d;
-    a.cmux_d0 = (const int64_t *)d0_d;
-    a.cmux_d1 = (const int64_t *)d1_d;
-    a.gsw_sel = sel_d;
-    a.gsw_sample_stride = (long long)g->sample_complex;
-    a.flags = BR_NO_ROTATE | BR_CMUX_DATA;
-    return launch_br64(c, a);
+    return c->p.torus_bits == 32 ? cmux_t<int32_t>(c, out_d, g, sel_d, d0_d, d1_d, batch)
+                                 : cmux_t<int64_t>(c, out_d, g, sel_d, d0_d, d1_d, batch);
+}
+
+int tfhe_amd_lut_eval(tfhe_amd_ctx *c, void *lwe_out_d, const tfhe_amd_gsw *bits, int d, const void *lut_d, int batch) {
+    if (!c || !lwe_out_d || !bits || !lut_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    REQUIRE(c, bits->ctx == c, "TGSW handle belongs to another context");
+    REQUIRE(c, c->p.torus_bits == 32, "LUT evaluation consumes TGSW32 samples (circuit-bootstrap outputs)");
+    REQUIRE(c, d >= 1 && d <= c->logn + 20, "LUT evaluation: 1 <= d <= log2(N) + 20");
+    REQUIRE(c, (long long)batch * d <= bits->count, "LUT evaluation needs batch * d TGSW samples (bit i of item b at b*d + i)");
+    if (batch == 0) return TFHE_AMD_OK;
+    return lut_eval_t<int32_t>(c, lwe_out_d, bits, d, lut_d, batch);
 }
 
 // ---- L3

@@ -692,6 +692,7 @@ enum : uint32_t {
     BR_TV_HALF = 1u << 4,       // test vector = -tv_const for j<N/2, +tv_const above (poc:551-553)
     BR_NO_ROTATE = 1u << 5,     // plain external product steps (tGswFFTExternMulToTLwe): no X^a, no +acc
     BR_CMUX_DATA = 1u << 6,     // CMux on data: acc = d1 - d0 on load, + d0 on store (d0 = cmux_d0, d1 = cmux_d1)
+    BR_CMUX_TRIVIAL = 1u << 7,  // with BR_CMUX_DATA: d0/d1 are plaintext polynomials [N] = noiseless trivial TLWE (0, d)
 };
 
 template <typename T>
@@ -703,8 +704,11 @@ struct BlindRotateArgs {
     const T *tv;            // test vector(s) [N] (tv_stride 0) or [batch][N]
     const T *cmux_d0;       // BR_CMUX_DATA: [batch][2][N]
     const T *cmux_d1;       // BR_CMUX_DATA: [batch][2][N]
-    const int32_t *gsw_sel; // per-sample TGSW index into bk (null: 0)
-    long long gsw_sample_stride;  // complex elements per TGSW sample (for gsw_sel)
+    const int32_t *gsw_sel; // per-sample TGSW index into bk (null: computed, see sel_div)
+    long long gsw_sample_stride;  // complex elements per TGSW sample (for gsw_sel / sel_div)
+    long long cmux_stride;  // BR_CMUX_DATA: elements between the d0 (and d1) of consecutive items
+    int32_t cmux_period;    // BR_CMUX_DATA: item index taken modulo this (0: no wrap) -- shared plaintext table
+    int32_t sel_div, sel_mul, sel_add;  // gsw_sel == null, sel_div > 0: TGSW sample (ct / sel_div) * sel_mul + sel_add
     T *lwe_out;             // [batch][N+1]
     long long tv_stride;
     long long bk_step_stride;  // complex elements between consecutive steps (0: same row every step)
@@ -790,9 +794,18 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             w.acc[N + j] = (T)((idx & N) ? (U)(0 - v) : v);
         }
     } else if (A.flags & BR_CMUX_DATA) {
-        const T *d0 = A.cmux_d0 + (size_t)ct * 2 * N, *d1 = A.cmux_d1 + (size_t)ct * 2 * N;
+        const size_t item = A.cmux_period ? (size_t)(ct % A.cmux_period) : (size_t)ct;
+        const T *d0 = A.cmux_d0 + item * A.cmux_stride, *d1 = A.cmux_d1 + item * A.cmux_stride;
+        if (A.flags & BR_CMUX_TRIVIAL) {
 #pragma unroll
-        for (int m = 0; m < 4 * PPL; m++) w.acc[t + 64 * m] = (T)((U)d1[t + 64 * m] - (U)d0[t + 64 * m]);
+            for (int m = 0; m < 2 * PPL; m++) {
+                w.acc[t + 64 * m] = 0;
+                w.acc[N + t + 64 * m] = (T)((U)d1[t + 64 * m] - (U)d0[t + 64 * m]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4 * PPL; m++) w.acc[t + 64 * m] = (T)((U)d1[t + 64 * m] - (U)d0[t + 64 * m]);
+        }
     } else {
         const T *src = A.acc_io + (size_t)ct * 2 * N;
 #pragma unroll
@@ -800,7 +813,10 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
     }
     TFHE_WAVE_FENCE();
     const double2 *bk0 = A.bk;
-    if (A.gsw_sel) bk0 += (size_t)TFHE_UNIFORM(A.gsw_sel[ct]) * A.gsw_sample_stride;
+    if (A.gsw_sel)
+        bk0 += (size_t)TFHE_UNIFORM(A.gsw_sel[ct]) * A.gsw_sample_stride;
+    else if (A.sel_div > 0)
+        bk0 += (size_t)((ct / A.sel_div) * A.sel_mul + A.sel_add) * A.gsw_sample_stride;
 
     // ---- CMux loop (lwe_functions.cpp:337-361)
 #pragma unroll 1
@@ -827,10 +843,19 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
         }
         if (t == 0) out[N] = (T)((U)w.acc[N] + (U)A.out_b_add);
     } else if (A.flags & BR_CMUX_DATA) {
-        const T *d0 = A.cmux_d0 + (size_t)ct * 2 * N;
+        const size_t item = A.cmux_period ? (size_t)(ct % A.cmux_period) : (size_t)ct;
+        const T *d0 = A.cmux_d0 + item * A.cmux_stride;
         T *dst = A.acc_io + (size_t)ct * 2 * N;
+        if (A.flags & BR_CMUX_TRIVIAL) {
 #pragma unroll
-        for (int m = 0; m < 4 * PPL; m++) dst[t + 64 * m] = (T)((U)w.acc[t + 64 * m] + (U)d0[t + 64 * m]);
+            for (int m = 0; m < 2 * PPL; m++) {
+                dst[t + 64 * m] = w.acc[t + 64 * m];
+                dst[N + t + 64 * m] = (T)((U)w.acc[N + t + 64 * m] + (U)d0[t + 64 * m]);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4 * PPL; m++) dst[t + 64 * m] = (T)((U)w.acc[t + 64 * m] + (U)d0[t + 64 * m]);
+        }
     } else {
         T *dst = A.acc_io + (size_t)ct * 2 * N;
 #pragma unroll
@@ -848,8 +873,11 @@ struct FftLds {
     static constexpr size_t total = tw_bytes + WAVES * wave_bytes;
 };
 
-// execute_reverse_int / _torus32 / _torus64: torus or int coefficients -> LagrangeHalfC
-template <typename TIN, int LOGN, int WAVES>
+// execute_reverse_int / _torus32 / _torus64: torus or int coefficients -> LagrangeHalfC.
+// PACK: write the key layout of the blind-rotation kernel instead ([row][PPL][64] complex, scaled by
+// 2/N -- what k_pack_gsw makes of the reference layout), i.e. tGswToFFTConvert straight into a
+// device-resident key without the intermediate LagrangeHalfC array.
+template <typename TIN, int LOGN, int WAVES, bool PACK = false>
 TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     k_ifft_batch(double *__restrict__ out, const TIN *__restrict__ in, const double2 *__restrict__ twg, int batch) {
     using G = Geom<LOGN>;
@@ -872,6 +900,13 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     }
     const TwLds<LOGN> twp{tw, t};
     WaveFFT<LOGN>::template ifft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
+    if (PACK) {
+        double2 *o = reinterpret_cast<double2 *>(out) + (size_t)b * NC;
+        const double scale = 2.0 / (double)N;  // exact: a power of two
+#pragma unroll
+        for (int m = 0; m < PPL; m++) o[64 * m + t] = make_double2(xr[0][m] * scale, xi[0][m] * scale);
+        return;
+    }
     double *o = out + (size_t)b * N;
 #pragma unroll
     for (int m = 0; m < PPL; m++) {

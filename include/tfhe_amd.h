@@ -103,6 +103,10 @@ int tfhe_amd_gsw_from_fft(tfhe_amd_ctx *ctx, const double *gsw_fft, int count, t
 /* TGSW samples in coefficient form, host layout [count][(k+1)l][k+1][N] torus values
  * (int32_t or int64_t per params.torus_bits); converted on the GPU = tGswToFFTConvert. */
 int tfhe_amd_gsw_from_torus(tfhe_amd_ctx *ctx, const void *gsw_torus, int count, tfhe_amd_gsw **out);
+/* the same from DEVICE memory (asynchronous on the context's stream): turns the TGSW32 outputs of
+ * tfhe_amd_circuit_bootstrap ([B][2][l1][2][N1], i.e. B samples in this layout) into selectors for
+ * tfhe_amd_cmux / tfhe_amd_lut_eval without leaving the GPU */
+int tfhe_amd_gsw_from_torus_d(tfhe_amd_ctx *ctx, const void *gsw_torus_d, int count, tfhe_amd_gsw **out);
 void tfhe_amd_gsw_free(tfhe_amd_gsw *gsw);
 /* read back sample `index` in the reference's Lagrange layout [(k+1)l][k+1][N] (unscaled) */
 int tfhe_amd_gsw_export_fft(tfhe_amd_ctx *ctx, const tfhe_amd_gsw *gsw, int index, double *out);
@@ -141,6 +145,22 @@ int tfhe_amd_mux_rotate(tfhe_amd_ctx *ctx, void *acc_d, const tfhe_amd_gsw *gsw,
  * [batch][2][N] torus; out_d may alias d1_d.  One level of a vertical-packing / LUT tree. */
 int tfhe_amd_cmux(tfhe_amd_ctx *ctx, void *out_d, const tfhe_amd_gsw *gsw, const int32_t *sel_d, const void *d0_d,
                   const void *d1_d, int batch);
+
+/* LUT evaluation by vertical packing over TGSW-encrypted bits -- what BASELINE config 3 names after
+ * the circuit bootstrap.  The reference stops at the CMux stub (poc:877-879); the algorithm is the
+ * published one (Chillotti-Gama-Georgieva-Izabachene, "Faster packed homomorphic operations and
+ * efficient circuit bootstrapping for TFHE", vertical packing), built from the two reference
+ * operations above: for f: {0,1}^d -> Torus with table polynomials
+ *     lut[p] = sum_{i<N} f(p*N + i) X^i,   p < npoly = max(1, 2^(d - log2 N)),
+ * and x = sum_i x_i 2^i given as TGSW samples (item b's bit i = sample b*d + i of `bits`):
+ *   1. d - log2 N tree levels of tfhe_amd_cmux: level j keeps cur[2p + x_{log2 N + j}] (level 0 reads
+ *      the shared plaintext table as noiseless trivial samples, tLweNoiselessTrivial);
+ *   2. min(d, log2 N) steps of tfhe_MuxRotate_FFT with the constant rotations 2N - 2^i (X^{-2^i}) and
+ *      the item's own bit i as the selector;
+ *   3. tLweExtractLweSampleIndex at index 0.
+ * lut_d: [npoly][N] Torus32 (plaintext, shared by the batch); lwe_out_d: [batch][N+1].  Torus32 contexts
+ * (the circuit bootstrap emits TGSW32), 1 <= d <= log2 N + 20. */
+int tfhe_amd_lut_eval(tfhe_amd_ctx *ctx, void *lwe_out_d, const tfhe_amd_gsw *bits, int d, const void *lut_d, int batch);
 
 /* ---- L3: bootstrapping -------------------------------------------------------------- */
 /* tfhe_blindRotate_FFT (CB/lwe_functions.cpp:337-361): acc_d [batch][2][N] in place,

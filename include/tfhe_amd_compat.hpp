@@ -15,7 +15,7 @@
 //       class FFT_Processor_AMD  (same five execute_* methods as FFT_Processor_Spqlios),
 //       LagrangeHalfCPolynomialAddMulASM-compatible AddMul
 //   PoC form (CB/poc_CircuitBootstrapping.cpp, types of CB/poc_types.h): class template
-//       PocEngine<Globals>: tfhe_CircuitBootstrapFFT :823-873, circuitBootstrapWoKS :530-659,
+//       PocEngine<Globals>: tfhe_CircuitBootstrapFFT :823-873, CMux :877-879, circuitBootstrapWoKS :530-659,
 //       circuitPrivKS :667-698, preKeySwitch :437-465, preModSwitch :472-484.  It is a template
 //       so it compiles against the reference's own poc_types.h (include that first) or against
 //       any structs with the same members.
@@ -478,6 +478,30 @@ class PocEngine {
         check(tfhe_amd_memcpy_h2d(c2_, d_a_, x->a, sizeof(int32_t) * (size_t)(p_.n0 + 1)), c2_, "h2d");
         check(tfhe_amd_modswitch(c2_, (int32_t *)d_b_, (const int32_t *)d_a_, 1), c2_, "modswitch");
         check(tfhe_amd_memcpy_d2h(c2_, result, d_b_, sizeof(int) * (size_t)(p_.n0 + 1)), c2_, "d2h");
+    }
+    // CMux(TLweSample32* out, const TGswSample32* c, const TLweSample32* in0, const TLweSample32* in1, env)
+    // -- declared but left empty by the reference (poc:877-879).  out = c ? in1 : in0, i.e.
+    // c (x) (in1 - in0) + in0 with c converted to Lagrange form on the device (tGswToFFTConvert).
+    template <class TLweSample32T, class TGswSample32T>
+    void CMux(TLweSample32T *out, const TGswSample32T *c, const TLweSample32T *in0, const TLweSample32T *in1) {
+        const size_t N1 = (size_t)p_.N1, rows = (size_t)2 * p_.l1;
+        std::vector<int32_t> g(rows * 2 * N1), d(4 * N1);
+        for (int u = 0; u < 2; u++)
+            for (int w = 0; w < p_.l1; w++)
+                for (int q = 0; q < 2; q++)
+                    std::memcpy(&g[(((size_t)u * p_.l1 + w) * 2 + q) * N1], c->samples[u][w].a[q].coefs, sizeof(int32_t) * N1);
+        for (int q = 0; q < 2; q++) {
+            std::memcpy(&d[(size_t)q * N1], in0->a[q].coefs, sizeof(int32_t) * N1);
+            std::memcpy(&d[(2 + (size_t)q) * N1], in1->a[q].coefs, sizeof(int32_t) * N1);
+        }
+        tfhe_amd_gsw *sel = nullptr;
+        check(tfhe_amd_gsw_from_torus(c10_, g.data(), 1, &sel), c10_, "gsw_from_torus");
+        check(tfhe_amd_memcpy_h2d(c10_, d_a_, d.data(), sizeof(int32_t) * d.size()), c10_, "h2d");
+        int32_t *dd = (int32_t *)d_a_;
+        check(tfhe_amd_cmux(c10_, d_b_, sel, nullptr, dd, dd + 2 * N1, 1), c10_, "cmux");
+        check(tfhe_amd_memcpy_d2h(c10_, d.data(), d_b_, sizeof(int32_t) * 2 * N1), c10_, "d2h");
+        tfhe_amd_gsw_free(sel);
+        for (int q = 0; q < 2; q++) std::memcpy(out->a[q].coefs, &d[(size_t)q * N1], sizeof(int32_t) * N1);
     }
     tfhe_amd_cb *handle() { return cb_; }
 

@@ -408,6 +408,47 @@ void orc_blind_rotate_extract32(const orc_tables *t, int32_t *lwe, const int32_t
     free(acc);
 }
 
+/* ---- CMux on data and LUT evaluation by vertical packing --------------------------------------
+ * The reference ends at the stub `CMux(out, c, in0, in1, env)` (poc:877-879).  Restated from the two
+ * reference operations it would be built from: tGswFFTExternMulToTLwe (tgsw_functions.cpp:424-449)
+ * and tfhe_MuxRotate_FFT (lwe_functions.cpp:328-333); the tree/rotate/extract composition is the
+ * published vertical-packing algorithm (no reference code: "parity unpinned" beyond the primitives). */
+void orc_cmux32(const orc_tables *t, int32_t *out, const double *gsw, const int32_t *d0, const int32_t *d1,
+                int l, int Bgbit) {
+    const int N = t->N;
+    for (int j = 0; j < 2 * N; j++) out[j] = (int32_t)((uint32_t)d1[j] - (uint32_t)d0[j]);
+    orc_extprod32(t, out, gsw, l, Bgbit);
+    for (int j = 0; j < 2 * N; j++) out[j] = (int32_t)((uint32_t)out[j] + (uint32_t)d0[j]);
+}
+
+void orc_lut_eval32(const orc_tables *t, int32_t *lwe, const double *bits /* [d][2l][2][N] */, int d,
+                    const int32_t *lut /* [max(1, 2^(d-logN))][N] */, int l, int Bgbit) {
+    const int N = t->N;
+    int logn = 0;
+    while ((1 << logn) < N) logn++;
+    const int low = d < logn ? d : logn, levels = d - low;
+    const size_t row = (size_t)2 * l * 2 * N, S = (size_t)2 * N;
+    size_t cnt = (size_t)1 << levels;
+    int32_t *cur = (int32_t *)calloc(cnt * S, sizeof(int32_t));
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * S);
+    for (size_t p = 0; p < cnt; p++) /* tLweNoiselessTrivial (tlwe_functions.cpp:146-152): a = 0, b = table */
+        memcpy(cur + p * S + N, lut + p * N, sizeof(int32_t) * (size_t)N);
+    for (int j = 0; j < levels; j++) { /* bit logN + j halves the table */
+        cnt >>= 1;
+        for (size_t p = 0; p < cnt; p++) {
+            orc_cmux32(t, tmp, bits + row * (size_t)(low + j), cur + (2 * p) * S, cur + (2 * p + 1) * S, l, Bgbit);
+            memcpy(cur + p * S, tmp, sizeof(int32_t) * S);
+        }
+    }
+    for (int i = 0; i < low; i++) { /* X^{-2^i} when bit i is set */
+        orc_mux_rotate32(t, tmp, cur, bits + row * (size_t)i, 2 * N - (1 << i), l, Bgbit);
+        memcpy(cur, tmp, sizeof(int32_t) * S);
+    }
+    orc_sample_extract32(lwe, cur, N);
+    free(cur);
+    free(tmp);
+}
+
 int32_t orc_modswitch32(int32_t phase, int Msize) {
     const uint64_t interv = ((UINT64_C(1) << 63) / (uint64_t)Msize) * 2;
     const uint64_t half = interv / 2;

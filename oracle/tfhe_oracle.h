@@ -114,6 +114,13 @@ void orc_blind_rotate_extract32(const orc_tables *t, int32_t *lwe /* N+1 */, con
                                 const double *bkfft, int barb, const int32_t *bara, int n,
                                 int l, int Bgbit);
 
+/* CMux on data and LUT evaluation by vertical packing (stub CMux poc:877-879; composition of
+ * tgsw_functions.cpp:424-449 and lwe_functions.cpp:328-333, see the .c file) */
+void orc_cmux32(const orc_tables *t, int32_t *out /* 2N */, const double *gsw, const int32_t *d0,
+                const int32_t *d1, int l, int Bgbit);
+void orc_lut_eval32(const orc_tables *t, int32_t *lwe /* N+1 */, const double *bits /* [d][2l][2][N] */,
+                    int d, const int32_t *lut /* [max(1,2^(d-logN))][N] */, int l, int Bgbit);
+
 /* modSwitchFromTorus32, CB/numeric_functions.cpp:54-60 */
 int32_t orc_modswitch32(int32_t phase, int Msize);
 

@@ -251,6 +251,13 @@ static int run_poc(const char *inp, const char *outp) {
         PTGsw32 tg{rs.data(), rr.data()};
         eng.tfhe_CircuitBootstrapFFT(&tg, &x);
         out.put(res.data(), 4 * res.size());
+        // CMux (stub at poc:877-879) with the circuit bootstrap's TGSW32 output as the selector and
+        // two of its own TLWE rows as data
+        std::vector<int32_t> mx((size_t)2 * N1);
+        PPoly32 mp[2] = {{mx.data()}, {mx.data() + N1}};
+        PTLwe32 mux{mp, mp + 1};
+        eng.CMux(&mux, &tg, &rr[0], &rr[2 * l1 - 1]);
+        out.put(mx.data(), 4 * mx.size());
     }
     out.save(outp);
     return 0;

@@ -218,6 +218,21 @@ def extprod32(N, acc, gsw, l, Bgbit):
     return acc
 
 
+def cmux32(N, gsw, d0, d1, l, Bgbit):
+    out = np.empty(2 * N, np.int32)
+    d0, d1, gsw = i32(d0), i32(d1), f64(gsw)
+    lib().orc_cmux32(tables(N), _p(out, C.c_int32), _p(gsw, C.c_double), _p(d0, C.c_int32), _p(d1, C.c_int32), l, Bgbit)
+    return out
+
+
+def lut_eval32(N, bits, d, lut, l, Bgbit):
+    """bits [d][2l][2][N] Lagrange TGSW samples of one item, lut [max(1,2^(d-logN))][N] -> LWE [N+1]"""
+    out = np.empty(N + 1, np.int32)
+    bits, lut = f64(bits), i32(lut)
+    lib().orc_lut_eval32(tables(N), _p(out, C.c_int32), _p(bits, C.c_double), d, _p(lut, C.c_int32), l, Bgbit)
+    return out
+
+
 def extprod64(N, acc, gsw, l, Bgbit):
     acc = i64(acc).copy()
     gsw = f64(gsw)

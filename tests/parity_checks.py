@@ -233,6 +233,37 @@ def check_cmux_data(lib_path, N=1024, l=2, Bgbit=8, B=11, seed=71):
         e.close()
 
 
+def check_lut_eval(lib_path, N=1024, l=3, Bgbit=8, d=12, B=3, seed=81, decrypt_tol=2 ** 25):
+    """LUT evaluation by vertical packing (tfhe_amd_lut_eval): d TGSW-encrypted bits per item select
+    f(x) out of a 2^d-entry table.  Bit-compared with the oracle's composition of the reference's
+    external product / MuxRotate / sample extraction, and decrypt-checked: the phase of the result
+    is the table entry of the item's bits.  The library's Torus32 decomposition truncates (offset
+    without a rounding bit, tgsw_functions.cpp:24-36), so every CMux adds a bias of about
+    N/2 * 2^(32 - l*Bgbit - 1) to the phase: with the PoC's l1=2, Bgbit1=8 that is 2^24 per level and
+    the decrypt check is only meaningful at l=3 (pass decrypt_tol=None to bit-compare only)."""
+    rs = np.random.RandomState(seed)
+    logn = N.bit_length() - 1
+    tkey = O.keygen_binary(N, SEED, 2)
+    x = rs.randint(0, 1 << d, size=B)
+    x[0] = (1 << d) - 1  # all bits set: every level takes the "1" branch, every rotation applies
+    bits = np.array([[(int(v) >> i) & 1 for i in range(d)] for v in x], np.int32)
+    gsw_lag = O.bk_create32(N, bits.ravel(), tkey, l, Bgbit, 2.0 ** -30, SEED, 9100)  # [B*d][2l][2][N]
+    npoly = 1 << max(0, d - logn)
+    table = (rs.randint(-4, 4, size=npoly * N).astype(np.int64) << 28).astype(np.int32)  # f(x), x < npoly*N
+    e = T.Engine(torus_bits=32, n=1, N=N, l=l, Bgbit=Bgbit, ks_t=0, lib_path=lib_path)
+    try:
+        g = e.gsw_from_fft(gsw_lag)
+        got = e.lut_eval(g, d, table.reshape(npoly, N), B)
+        per_item = gsw_lag.reshape(B, d, 2 * l, 2, N)
+        want = np.stack([O.lut_eval32(N, per_item[b], d, table, l, Bgbit) for b in range(B)])
+        assert np.array_equal(got, want), f"LUT evaluation d={d}"
+        for b in range(B if decrypt_tol else 0):
+            err = (O.lwe_phase32(got[b], tkey) - int(table[x[b]]) + 2 ** 31) % 2 ** 32 - 2 ** 31
+            assert abs(err) < decrypt_tol, (b, x[b], err)
+    finally:
+        e.close()
+
+
 # ------------------------------------------------------- rounding range extremes
 def check_rounding_extremes(lib_path, br_variant=0):
     """Torus32 rounding has a short sequence valid for |x| < 2^51 and an exact fallback (DESIGN.md,
@@ -292,6 +323,14 @@ def check_circuit_bootstrap(lib_path, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t
         want = np.stack([O.circuit_bootstrap(x[b], preks, bk, privks, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10,
                                              t21, bb21) for b in range(B)])
         assert np.array_equal(cb.circuit_bootstrap(x), want), "tfhe_CircuitBootstrapFFT"
+        # the chain of BASELINE config 3, device-resident end to end: the TGSW32 outputs become the
+        # selectors of a LUT evaluation (d = 2 items x ... bits taken from the same inputs)
+        d = min(B, 11)
+        table = O.fill32(77, (1 << max(0, d - (N1.bit_length() - 1))) * N1)
+        tgsw, lwe = cb.circuit_bootstrap_lut(x[:d], d, table)
+        assert np.array_equal(tgsw, want[:d]), "circuit bootstrap inside the chain"
+        sel = O.execute_reverse_int(N1, want[:d].reshape(-1, N1)).reshape(d, 2 * l1, 2, N1)
+        assert np.array_equal(lwe[0], O.lut_eval32(N1, sel, d, table, l1, bg1)), "circuit bootstrap -> LUT evaluation"
     finally:
         cb.close()
 

@@ -109,6 +109,9 @@ def run_poc_form(driver, tmp_path, n0=3, N1=1024, N2=1024, l1=2, bg1=8, l2=3, bg
         assert np.array_equal(take(np.int32, 2 * N1), O.privks(privks[1], x64[c], N2, N1, t21, bb21)), "circuitPrivKS"
         want = O.circuit_bootstrap(x[c], preks, bk, privks, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21)
         assert np.array_equal(take(np.int32, 2 * l1 * 2 * N1), want.ravel()), "tfhe_CircuitBootstrapFFT"
+        rows = np.asarray(want, np.int32).reshape(2 * l1, 2 * N1)
+        sel = O.execute_reverse_int(N1, rows.reshape(-1, N1))
+        assert np.array_equal(take(np.int32, 2 * N1), O.cmux32(N1, sel, rows[0], rows[-1], l1, bg1)), "CMux"
     assert pos == len(raw)
 
 

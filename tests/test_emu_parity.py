@@ -49,6 +49,17 @@ def test_cmux_on_data_emu(emu_lib):
     P.check_cmux_data(emu_lib, B=5)
 
 
+@pytest.mark.parametrize("d,B", [(3, 2), (10, 2), (12, 3)])
+def test_lut_eval_emu(emu_lib, d, B):
+    """vertical packing: fewer bits than log2 N (rotation only), exactly log2 N, and a 2-level CMux tree"""
+    P.check_lut_eval(emu_lib, d=d, B=B)
+
+
+def test_lut_eval_poc_gadget_emu(emu_lib):
+    """the circuit bootstrap's output gadget (l1=2, Bgbit1=8, poc:70-85): bit-compare only"""
+    P.check_lut_eval(emu_lib, l=2, Bgbit=8, d=11, B=2, decrypt_tol=None)
+
+
 def test_circuit_bootstrap_emu(emu_lib):
     # N2 = 2048, l2 = 4, Bgbit2 = 9, privKS base 8 as in the PoC; short n0 / key-switch lengths
     P.check_circuit_bootstrap(emu_lib, n0=2, N1=1024, N2=2048, l1=2, bg1=8, l2=4, bg2=9, t10=3, bb10=2, t21=2,

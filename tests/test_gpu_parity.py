@@ -109,6 +109,15 @@ def test_cmux_on_data(gpu_lib):
     P.check_cmux_data(gpu_lib, N=2048, l=3, Bgbit=7, B=6, seed=72)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,B", [(3, 5), (10, 9), (13, 17)])
+def test_lut_eval_gpu(gpu_lib, d, B):
+    """LUT evaluation by vertical packing (BASELINE config 3's consumer of the circuit bootstrap)"""
+    P.check_lut_eval(gpu_lib, d=d, B=B)
+    if d == 13:  # the circuit bootstrap's output gadget (l1=2, Bgbit1=8): bit-compare only
+        P.check_lut_eval(gpu_lib, l=2, Bgbit=8, d=d, B=B, decrypt_tol=None)
+
+
 def test_circuit_bootstrap_pipeline(gpu_lib):
     """BASELINE config 3: tfhe_CircuitBootstrapFFT with the PoC ring sizes and gadgets (N1=1024,
     N2=2048, l2=4, Bgbit2=9, l1=2, Bgbit1=8, preKS 6x2, privKS base 8); n0 and the privKS length are

@@ -115,3 +115,28 @@ def test_circuit_bootstrap_small():
             want0 = -bit * h * key1.astype(np.int64)
             err = ((ph0 - want0 + 2 ** 31) % 2 ** 32) - 2 ** 31
             assert np.abs(err).max() < h // 4, (bit, w, np.abs(err).max(), h)
+
+
+def test_circuit_bootstrap_feeds_lut_small():
+    """The chain BASELINE config 3 names: LWE-encrypted bits -> tfhe_CircuitBootstrapFFT -> TGSW32
+    -> LUT evaluation by vertical packing -> LWE of f(bits).  Reduced rings as above (N1 = 64, so 8
+    bits = 6 rotation steps + a 2-level CMux tree); decrypts to the table entry for every input."""
+    n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21 = 8, 64, 128, 2, 8, 4, 9, 6, 2, 10, 3
+    d = 8
+    key0, key1 = O.keygen_binary(n0, SEED, 21), O.keygen_binary(N1, SEED, 22)
+    key2 = O.keygen_binary(N2, SEED, 23)
+    bk = O.bk_create64(N2, key0, key2, l2, bg2, 2.0 ** -44, SEED, 3000)
+    preks = O.ks_create32(key1, key0, t10, bb10, 2.0 ** -20, SEED, 4000)
+    privks = O.privks_create(key2, key1, t21, bb21, 2.0 ** -31, SEED, 5000)
+    rs = np.random.RandomState(5)
+    table = (rs.randint(-4, 4, size=1 << d).astype(np.int64) << 28).astype(np.int32)
+    for x in (0, (1 << d) - 1, 0b10110010):
+        sel = []
+        for i in range(d):
+            bit = (x >> i) & 1
+            ct = O.lwe_encrypt32(bit << 31, 2.0 ** -20, key1, O.rng(SEED, 700 + 16 * x + i))
+            tgsw = O.circuit_bootstrap(ct, preks, bk, privks, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21)
+            sel.append(O.execute_reverse_int(N1, np.asarray(tgsw, np.int32).reshape(-1, N1)))  # tGswToFFTConvert
+        out = O.lut_eval32(N1, np.stack(sel), d, table, l1, bg1)
+        err = (O.lwe_phase32(out, key1) - int(table[x]) + 2 ** 31) % 2 ** 32 - 2 ** 31
+        assert abs(err) < 2 ** 26, (x, err)
