@@ -66,4 +66,10 @@ if max_stage >= 8:
     P.check_circuit_bootstrap(T.DEFAULT_LIB, n0=6, N1=1024, N2=2048, l1=2, bg1=8, l2=4, bg2=9, t10=6, bb10=2, t21=2,
                               bb21=3, B=5)
     say("   ok")
+if max_stage >= 9:
+    say("stage 9: CMux on data + LUT evaluation by vertical packing (d = 3, 10, 13)")
+    P.check_cmux_data(T.DEFAULT_LIB, B=9)
+    for d in (3, 10, 13):
+        P.check_lut_eval(T.DEFAULT_LIB, d=d, B=4)
+    say("   ok")
 say("done")
