@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Timings for the BASELINE configs that are NOT the bench.py line (run on the GPU box):
+
+    python tools/bench_configs.py fft   [--batch 8192] [--reps 5]     BASELINE config 4
+    python tools/bench_configs.py cb    [--batch 256]  [--reps 3]     BASELINE config 3
+    python tools/bench_configs.py all
+
+fft  batched N=2048 transforms through the FFT-plugin entry points: 8,192
+     polynomials (256 MiB working set = Infinity Cache size) and 4x that, each of
+     execute_reverse_torus64 / execute_reverse_int / execute_direct_torus64 / execute_direct_torus32(N=1024);
+     reported as polynomials/s and as algorithmic GB/s (bytes in + bytes out) against 8 TB/s -- these
+     kernels ARE HBM-bound (1.6 flop/B), unlike the blind rotation.
+cb   circuit bootstrap at the PoC parameters (poc:70-85: n0=500, N1=1024, N2=2048, l2=4, Bgbit2=9,
+     l1=2, Bgbit1=8, preKS 6x2, privKS 10x3 = 2.69 GB) on synthetic keys, stage by stage
+     (preKeySwitch, preModSwitch, l1 Torus64 blind rotations, 2*l1 private key switches), then the
+     whole tfhe_amd_circuit_bootstrap call, then a 16-bit LUT evaluation over its outputs.
+
+One JSON object per line.  No torch, no child processes; HIP events through the engine's C ABI.
+Synthetic keys are uniformly random tables: throughput does not depend on key contents.
+`--small` shrinks every size (for the CPU emulator build: --lib tests/emu/_build/libtfhe_amd_emu.so)."""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+HBM_PEAK = 8.0e12
+
+
+class Events:
+    """HIP events of a raw context handle (same three methods as Engine)"""
+
+    def __init__(self, lib, ctx):
+        self.lib, self.ctx = lib, ctx
+
+    def event(self):
+        e = C.c_void_p()
+        assert self.lib.tfhe_amd_event_create(self.ctx, C.byref(e)) == 0
+        return e
+
+    def record(self, e):
+        assert self.lib.tfhe_amd_event_record(self.ctx, e) == 0
+
+    def elapsed_ms(self, e0, e1):
+        ms = C.c_float()
+        assert self.lib.tfhe_amd_event_elapsed_ms(self.ctx, e0, e1, C.byref(ms)) == 0
+        return float(ms.value)
+
+
+def timed(eng, reps, fn):
+    """min and mean HIP-event time (ms) of fn() over `reps` runs after one warm-up"""
+    e0, e1 = eng.event(), eng.event()
+    fn()
+    ts = []
+    for _ in range(reps):
+        eng.record(e0)
+        fn()
+        eng.record(e1)
+        ts.append(eng.elapsed_ms(e0, e1))
+    return min(ts), float(np.mean(ts))
+
+
+def rand_bits(rs, shape, dtype):
+    """uniform values of the full integer range (any bit pattern is a valid torus element)"""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    return np.frombuffer(rs.bytes(nbytes), dtype=dtype).reshape(shape)
+
+
+def bench_fft(T, a):
+    rs = np.random.RandomState(4)
+    lines = []
+    for N, batch in ((2048, a.batch), (2048, 4 * a.batch), (1024, 4 * a.batch)):
+        if a.small:
+            batch = 8
+        eng = T.Engine(torus_bits=64 if N == 2048 else 32, n=1, N=N, l=2, Bgbit=8, ks_t=0, lib_path=a.lib)
+        lib = eng.lib
+        i64 = eng.to_device(rand_bits(rs, (batch, N), np.int64))
+        i32 = eng.to_device(rs.randint(-256, 256, size=(batch, N)).astype(np.int32))      # digits in [-256, 256)
+        lag = eng.alloc(batch * N * 8)
+        o64, o32 = eng.alloc(batch * N * 8), eng.alloc(batch * N * 4)
+        eng._chk(lib.tfhe_amd_ifft_int32(eng.ctx, lag.ptr, i32.ptr, batch))                # Lagrange doubles to transform back
+        cases = [("execute_reverse_int", 4 + 8, lambda: eng._chk(lib.tfhe_amd_ifft_int32(eng.ctx, lag.ptr, i32.ptr, batch))),
+                 ("execute_reverse_torus64", 8 + 8, lambda: eng._chk(lib.tfhe_amd_ifft_torus64(eng.ctx, lag.ptr, i64.ptr, batch))),
+                 ("execute_direct_torus64", 8 + 8, lambda: eng._chk(lib.tfhe_amd_fft_torus64(eng.ctx, o64.ptr, lag.ptr, batch))),
+                 ("execute_direct_torus32", 8 + 4, lambda: eng._chk(lib.tfhe_amd_fft_torus32(eng.ctx, o32.ptr, lag.ptr, batch)))]
+        for name, bytes_per_coef, fn in cases:
+            if name == "execute_direct_torus64":
+                eng._chk(lib.tfhe_amd_ifft_int32(eng.ctx, lag.ptr, i32.ptr, batch))
+            best, mean = timed(eng, a.reps, fn)
+            algo = batch * N * bytes_per_coef
+            lines.append({"workload": f"{name} N={N} batch={batch}", "ms_min": best, "ms_mean": mean,
+                          "polynomials_per_s": batch / (best * 1e-3),
+                          "roofline": {"bound": "hbm", "achieved": algo / (best * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                                       "unit": "GB/s", "frac": algo / (best * 1e-3) / HBM_PEAK,
+                                       "algorithmic_bytes_per_launch": algo,
+                                       "working_set_MiB": algo / 2 ** 20}})
+            print(json.dumps(lines[-1]), flush=True)
+        eng.close()
+    return lines
+
+
+def bench_cb(T, a):
+    rs = np.random.RandomState(5)
+    if a.small:
+        n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, B, d = 3, 1024, 2048, 2, 8, 4, 9, 2, 2, 2, 3, 4, 4
+    else:
+        n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, B, d = 500, 1024, 2048, 2, 8, 4, 9, 6, 2, 10, 3, a.cb_batch, 16
+    B -= B % d
+    cb = T.CircuitBootstrap(n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, lib_path=a.lib)
+    lib = cb.lib
+    cb.load_preks(rand_bits(rs, (N1, t10, 1 << bb10, n0 + 1), np.int32))
+    cb.load_bk_torus(rand_bits(rs, (n0, 2 * l2, 2, N2), np.int64))        # tGswToFFTConvert on the GPU
+    for u in range(2):                                                    # one 1.35 GB plane at a time
+        plane = rand_bits(rs, ((N2 + 1) * t21 * (1 << bb21) * 2 * N1,), np.int32)
+        cb._chk(lib.tfhe_amd_cb_load_privks_plane(cb.cb, u, T._np_ptr(plane)))
+        del plane
+    x = rand_bits(rs, (B, N1 + 1), np.int32)
+    d_x = cb._dev(x)
+    d_out = cb._dev(np.zeros((B, 2, l1, 2, N1), np.int32))
+
+    ev = Events(lib, cb.ctx)  # all of cb shares one stream; events go through the level-2 context
+    whole_min, whole_mean = timed(ev, a.reps, lambda: cb._chk(lib.tfhe_amd_circuit_bootstrap(cb.cb, d_out, d_x, B)))
+    line = {"workload": f"tfhe_CircuitBootstrapFFT n0={n0} N1={N1} N2={N2} l2={l2} Bgbit2={bg2} l1={l1} Bgbit1={bg1} "
+                        f"preKS {t10}x{bb10} privKS {t21}x{bb21}, batch {B}, synthetic keys",
+            "ms_min": whole_min, "ms_mean": whole_mean, "circuit_bootstraps_per_s": B / (whole_min * 1e-3)}
+    # stages, timed separately through the same entry points the pipeline composes
+    c10, c2 = cb.ctx10, cb.ctx
+    d_pre = cb._dev(np.zeros((B, n0 + 1), np.int32))
+    d_abar = cb._dev(np.zeros((B, n0 + 1), np.int32))
+    d_boot = cb._dev(np.zeros((B, N2 + 1), np.int64))
+    d_row = cb._dev(np.zeros((B, 2, N1), np.int32))
+    stages = {
+        "preKeySwitch": lambda: cb._chk(lib.tfhe_amd_keyswitch(c10, d_pre, d_x, B)),
+        "preModSwitch": lambda: cb._chk(lib.tfhe_amd_modswitch(c2, d_abar, d_pre, B)),
+        "circuitBootstrapWoKS (one of l1)": lambda: cb._chk(lib.tfhe_amd_cb_bootstrap_woks(c2, d_boot, 1 << 55, d_abar, B)),
+        "circuitPrivKS (one of 2*l1)": lambda: cb._chk(lib.tfhe_amd_privks(cb.cb, d_row, 0, d_boot, B)),
+    }
+    line["stages_ms"] = {k: timed(ev, a.reps, f)[0] for k, f in stages.items()}
+    plane_bytes = (N2 + 1) * t21 * (1 << bb21) * 2 * N1 * 4
+    t_priv = line["stages_ms"]["circuitPrivKS (one of 2*l1)"] * 1e-3
+    line["privks_hbm"] = {"note": "batch-major: one launch streams one table plane once (SURVEY 8a a19: 2.69 GB in two planes)",
+                          "algorithmic_bytes_per_launch": plane_bytes, "achieved_GBps": plane_bytes / t_priv / 1e9,
+                          "peak_GBps": HBM_PEAK / 1e9, "frac": plane_bytes / t_priv / HBM_PEAK}
+    print(json.dumps(line), flush=True)
+    # LUT evaluation over the circuit bootstrap's outputs (d bits per item)
+    items = B // d
+    table = rand_bits(rs, (max(1, (1 << d) // N1), N1), np.int32)
+    d_tab, d_lwe = cb._dev(table), cb._dev(np.zeros((items, N1 + 1), np.int32))
+    bits = C.c_void_p()
+    cb._chk(lib.tfhe_amd_gsw_from_torus_d(c10, d_out, B, C.byref(bits)))
+    t_min, t_mean = timed(ev, a.reps, lambda: cb._chk(lib.tfhe_amd_lut_eval(c10, d_lwe, bits, d, d_tab, items)))
+    cmux_count = items * ((max(1, (1 << d) // N1) - 1) + min(d, 10))
+    l2line = {"workload": f"LUT evaluation by vertical packing, d={d} bits, {items} items (TGSW32 from the circuit bootstrap)",
+              "ms_min": t_min, "ms_mean": t_mean, "lut_evaluations_per_s": items / (t_min * 1e-3),
+              "cmux_per_s": cmux_count / (t_min * 1e-3)}
+    print(json.dumps(l2line), flush=True)
+    lib.tfhe_amd_gsw_free(bits)
+    cb.close()
+    return [line, l2line]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["fft", "cb", "all"])
+    ap.add_argument("--batch", type=int, default=8192, help="polynomials per launch (fft)")
+    ap.add_argument("--cb-batch", type=int, default=256, help="LWE inputs per circuit-bootstrap launch")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--small", action="store_true")
+    a = ap.parse_args()
+    T = importlib.import_module("experimental-tfhe_amd")
+    if a.lib is None and not os.path.exists(T.DEFAULT_LIB):
+        importlib.import_module("experimental-tfhe_amd.build").build()  # child process before any GPU use
+    if a.what in ("fft", "all"):
+        bench_fft(T, a)
+    if a.what in ("cb", "all"):
+        bench_cb(T, a)
+
+
+if __name__ == "__main__":
+    main()

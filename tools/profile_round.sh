@@ -46,6 +46,10 @@ tail -c 400 "$OUT/bench_asmlds.json" | tee -a "$OUT/log.txt"
 echo "== ablation table (diagnostic build, wrong results by design, times only)" | tee -a "$OUT/log.txt"
 timeout 600 python3 tools/ablate.py --reps 3 2> "$OUT/ablate.err" | tee "$OUT/ablate.txt" | tee -a "$OUT/log.txt"
 
+echo "== BASELINE configs 3 and 4 (circuit bootstrap + LUT evaluation, batched N=2048 transforms)" | tee -a "$OUT/log.txt"
+timeout 900 python3 tools/bench_configs.py all > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
+cut -c1-300 "$OUT/configs.jsonl" | tee -a "$OUT/log.txt"
+
 echo "== rocprofv3 kernel trace + stats" | tee -a "$OUT/log.txt"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
     python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
