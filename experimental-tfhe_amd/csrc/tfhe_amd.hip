@@ -44,6 +44,7 @@ struct tfhe_amd_ctx {
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     bool ks_force_gather;  // TFHE_AMD_OPT_KS_GATHER: per-sample gather kernel even when the tiled one applies
     int br_variant;        // TFHE_AMD_OPT_BR_VARIANT
+    int fft_waves;         // TFHE_AMD_OPT_FFT_WAVES
     std::vector<const void *> lds_configured;  // kernels whose dynamic-LDS limit is raised on this device
 };
 
@@ -173,9 +174,8 @@ int launch_br64(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
     return c->logn == 10 ? launch_br_t<int64_t, 10, 4, 2>(c, a) : launch_br_t<int64_t, 11, 3, 1>(c, a);
 }
 
-template <typename TIN, int LOGN, bool PACK = false>
-int launch_ifft_t(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
-    constexpr int WAVES = 4;
+template <typename TIN, int LOGN, bool PACK, int WAVES>
+int launch_ifft_w(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
     using Lds = FftLds<LOGN, WAVES>;
     auto kernel = k_ifft_batch<TIN, LOGN, WAVES, PACK>;
     if (int rc = set_lds(c, kernel, Lds::total)) return rc;
@@ -184,9 +184,18 @@ int launch_ifft_t(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
-template <typename TOUT, int LOGN>
-int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
-    constexpr int WAVES = 4;
+// waves per workgroup of the standalone transforms (TFHE_AMD_OPT_FFT_WAVES): the twiddle table is
+// staged once per workgroup, so more waves amortise it and raise the resident-wave count per CU
+template <typename TIN, int LOGN, bool PACK = false>
+int launch_ifft_t(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
+    switch (c->fft_waves) {
+        case 8: return launch_ifft_w<TIN, LOGN, PACK, 8>(c, out_d, in_d, batch);
+        case 12: return launch_ifft_w<TIN, LOGN, PACK, 12>(c, out_d, in_d, batch);
+        default: return launch_ifft_w<TIN, LOGN, PACK, 4>(c, out_d, in_d, batch);
+    }
+}
+template <typename TOUT, int LOGN, int WAVES>
+int launch_fft_w(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
     using Lds = FftLds<LOGN, WAVES>;
     auto kernel = k_fft_batch<TOUT, LOGN, WAVES>;
     if (int rc = set_lds(c, kernel, Lds::total)) return rc;
@@ -194,6 +203,14 @@ int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
                 c->stream, out_d, in_d, (const double2 *)c->tw_d, batch);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
+}
+template <typename TOUT, int LOGN>
+int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
+    switch (c->fft_waves) {
+        case 8: return launch_fft_w<TOUT, LOGN, 8>(c, out_d, in_d, batch);
+        case 12: return launch_fft_w<TOUT, LOGN, 12>(c, out_d, in_d, batch);
+        default: return launch_fft_w<TOUT, LOGN, 4>(c, out_d, in_d, batch);
+    }
 }
 
 int grow(tfhe_amd_ctx *c, void **buf, size_t *have, size_t need) {
@@ -386,6 +403,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->ksd_d = nullptr;
     c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") != nullptr;
     c->br_variant = getenv("TFHE_AMD_BR_VARIANT") ? atoi(getenv("TFHE_AMD_BR_VARIANT")) : 0;
+    c->fft_waves = 4;
     c->ws_lwe = c->ws_acc = nullptr;
     c->vp_rot_d = nullptr;
     c->ws_lwe_bytes = c->ws_acc_bytes = 0;
@@ -475,6 +493,10 @@ int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_KS_GATHER:
             c->ks_force_gather = value != 0;
+            return TFHE_AMD_OK;
+        case TFHE_AMD_OPT_FFT_WAVES:
+            REQUIRE(c, value == 4 || value == 8 || value == 12, "transform kernels are built for 4, 8 or 12 waves per workgroup");
+            c->fft_waves = value;
             return TFHE_AMD_OK;
         default:
             return fail(c, TFHE_AMD_ERR_PARAM, "unknown option");

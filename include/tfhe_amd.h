@@ -75,8 +75,9 @@ int tfhe_amd_sync(tfhe_amd_ctx *ctx);
  *        0 (default) 8 waves per workgroup (2 per SIMD), twiddles in LDS, gadget digits in pairs
  *        1           4 waves per workgroup (1 per SIMD), twiddles held in registers, digits in pairs
  *        2           8 waves per workgroup, twiddles in LDS, digits one at a time
- *   TFHE_AMD_OPT_KS_GATHER   != 0: per-sample gather key switch instead of the batch-tiled kernel */
-enum { TFHE_AMD_OPT_BR_VARIANT = 1, TFHE_AMD_OPT_KS_GATHER = 2 };
+ *   TFHE_AMD_OPT_KS_GATHER   != 0: per-sample gather key switch instead of the batch-tiled kernel
+ *   TFHE_AMD_OPT_FFT_WAVES   waves (= polynomials) per workgroup of the standalone transforms: 4 (default), 8, 12 */
+enum { TFHE_AMD_OPT_BR_VARIANT = 1, TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_FFT_WAVES = 3 };
 int tfhe_amd_set_option(tfhe_amd_ctx *ctx, int option, int value);
 /* HIP events on the context's stream, for timing kernels without a HIP binding in the host
  * language: create, record (asynchronous), elapsed milliseconds between two recorded events

@@ -12,6 +12,12 @@ def test_fft_plugin_emu(emu_lib, N):
     P.check_fft_plugin(emu_lib, N, count=3)
 
 
+@pytest.mark.parametrize("N,waves", [(1024, 8), (2048, 12)])
+def test_fft_plugin_wider_workgroups_emu(emu_lib, N, waves):
+    """TFHE_AMD_OPT_FFT_WAVES: more polynomials per workgroup, ragged last workgroup (count % waves != 0)"""
+    P.check_fft_plugin(emu_lib, N, count=waves + 1, fft_waves=waves)
+
+
 def test_gate_path_emu_n1024(emu_lib):
     P.check_gate_path(emu_lib, N=1024, n=6, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=3)
 

@@ -49,6 +49,10 @@ timeout 600 python3 tools/ablate.py --reps 3 2> "$OUT/ablate.err" | tee "$OUT/ab
 echo "== BASELINE configs 3 and 4 (circuit bootstrap + LUT evaluation, batched N=2048 transforms)" | tee -a "$OUT/log.txt"
 timeout 900 python3 tools/bench_configs.py all > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
 cut -c1-300 "$OUT/configs.jsonl" | tee -a "$OUT/log.txt"
+for w in 8 12; do
+  timeout 300 python3 tools/bench_configs.py fft --fft-waves $w > "$OUT/configs_fftwaves$w.jsonl" 2>> "$OUT/configs.err"
+  cut -c1-200 "$OUT/configs_fftwaves$w.jsonl" | tee -a "$OUT/log.txt"
+done
 
 echo "== rocprofv3 kernel trace + stats" | tee -a "$OUT/log.txt"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
