@@ -45,6 +45,17 @@ struct tfhe_amd_ctx {
     bool ks_force_gather;  // TFHE_AMD_OPT_KS_GATHER: per-sample gather kernel even when the tiled one applies
     int br_variant;        // TFHE_AMD_OPT_BR_VARIANT
     int fft_waves;         // TFHE_AMD_OPT_FFT_WAVES
+    // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
+    // hipGraph and replayed while the call's arguments stay the same
+    bool streamed_graph;
+    unsigned streamed_warm;  // bit v: schedule variant v has run uncaptured once
+    struct {
+        void *exec;  // hipGraphExec_t
+        const void *x, *out;
+        int32_t mu;
+        int batch, variant;
+        bool ks_gather;
+    } sg;
     std::vector<const void *> lds_configured;  // kernels whose dynamic-LDS limit is raised on this device
 };
 
@@ -213,8 +224,17 @@ int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
     }
 }
 
+void drop_streamed_graph(tfhe_amd_ctx *c) {
+#ifndef TFHE_EMU
+    if (c->sg.exec) (void)hipGraphExecDestroy((hipGraphExec_t)c->sg.exec);
+#endif
+    c->sg.exec = nullptr;
+}
+
+// workspaces only grow; a captured streamed-schedule graph holds their addresses and dies with them
 int grow(tfhe_amd_ctx *c, void **buf, size_t *have, size_t need) {
     if (*have >= need) return TFHE_AMD_OK;
+    drop_streamed_graph(c);
     if (*buf) {
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         HIPCHECK(c, hipFree(*buf));
@@ -404,6 +424,9 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") != nullptr;
     c->br_variant = getenv("TFHE_AMD_BR_VARIANT") ? atoi(getenv("TFHE_AMD_BR_VARIANT")) : 0;
     c->fft_waves = 4;
+    c->streamed_graph = false;
+    c->streamed_warm = 0;
+    memset(&c->sg, 0, sizeof(c->sg));
     c->ws_lwe = c->ws_acc = nullptr;
     c->vp_rot_d = nullptr;
     c->ws_lwe_bytes = c->ws_acc_bytes = 0;
@@ -456,6 +479,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     if (c->ws_lwe) (void)hipFree(c->ws_lwe);
     if (c->ws_acc) (void)hipFree(c->ws_acc);
     if (c->vp_rot_d) (void)hipFree(c->vp_rot_d);
+    drop_streamed_graph(c);
 #ifndef TFHE_EMU
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
 #endif
@@ -493,6 +517,9 @@ int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_KS_GATHER:
             c->ks_force_gather = value != 0;
+            return TFHE_AMD_OK;
+        case TFHE_AMD_OPT_STREAMED_GRAPH:
+            c->streamed_graph = value != 0;
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_FFT_WAVES:
             REQUIRE(c, value == 4 || value == 8 || value == 12, "transform kernels are built for 4, 8 or 12 waves per workgroup");
@@ -644,7 +671,10 @@ int tfhe_amd_gsw_from_torus(tfhe_amd_ctx *c, const void *gsw_torus, int count, t
 
 void tfhe_amd_gsw_free(tfhe_amd_gsw *g) {
     if (!g) return;
-    if (g->ctx && g->ctx->bk == g) g->ctx->bk = nullptr;
+    if (g->ctx && g->ctx->bk == g) {
+        g->ctx->bk = nullptr;
+        drop_streamed_graph(g->ctx);
+    }
     if (g->data_d) {
         (void)hipStreamSynchronize(g->ctx->stream);
         (void)hipFree(g->data_d);
@@ -675,12 +705,14 @@ int tfhe_amd_set_bootstrap_key(tfhe_amd_ctx *c, const tfhe_amd_gsw *bk) {
     if (!c) return TFHE_AMD_ERR_PARAM;
     REQUIRE(c, bk && bk->ctx == c && bk->count == c->p.n, "bootstrap key must hold exactly n TGSW samples of this context");
     c->bk = bk;
+    drop_streamed_graph(c);
     return TFHE_AMD_OK;
 }
 
 int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *c, const int32_t *ks) {
     if (!c || !ks) return TFHE_AMD_ERR_PARAM;
     REQUIRE(c, c->p.ks_t > 0, "context has no key-switch parameters");
+    drop_streamed_graph(c);
     const size_t bytes = (size_t)c->p.N * c->p.ks_t * ((size_t)1 << c->p.ks_basebit) * (c->p.ks_n_out + 1) * 4;
     if (!c->ks_d) HIPCHECK(c, hipMalloc((void **)&c->ks_d, bytes));
     HIPCHECK(c, hipMemcpyAsync(c->ks_d, ks, bytes, hipMemcpyHostToDevice, c->stream));
@@ -857,11 +889,7 @@ int tfhe_amd_bootstrap(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, const int32_
     return tfhe_amd_keyswitch(c, out_d, (const int32_t *)c->ws_lwe, batch);
 }
 
-int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, const int32_t *x_d, int batch) {
-    if (!c || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
-    REQUIRE(c, c->p.torus_bits == 32, "Torus32 operation");
-    if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
-    if (batch == 0) return TFHE_AMD_OK;
+static int streamed_plain(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, const int32_t *x_d, int batch) {
     const int n = c->p.n, N = c->p.N;
     int rc = grow(c, &c->ws_lwe, &c->ws_lwe_bytes, (size_t)batch * (N + 1) * 4);
     if (rc) return rc;
@@ -896,6 +924,55 @@ int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, con
     rc = launch_br32(c, a);
     if (rc) return rc;
     return tfhe_amd_keyswitch(c, out_d, (const int32_t *)c->ws_lwe, batch);
+}
+
+int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, const int32_t *x_d, int batch) {
+    if (!c || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    REQUIRE(c, c->p.torus_bits == 32, "Torus32 operation");
+    if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
+    if (!c->ks_d) return fail(c, TFHE_AMD_ERR_STATE, "no key-switch key");
+    if (batch == 0) return TFHE_AMD_OK;
+#ifndef TFHE_EMU
+    if (c->streamed_graph) {
+        // workspace growth and per-kernel LDS attributes must not happen inside a capture: grow now,
+        // and let the first call of each schedule variant run as plain launches
+        if (int rc = grow(c, &c->ws_lwe, &c->ws_lwe_bytes, (size_t)batch * (c->p.N + 1) * 4)) return rc;
+        if (int rc = grow(c, &c->ws_acc, &c->ws_acc_bytes, (size_t)batch * 2 * c->p.N * 4)) return rc;
+        const unsigned vbit = 1u << (c->br_variant + (c->ks_force_gather ? 8 : 0));
+        if (!(c->streamed_warm & vbit)) {
+            c->streamed_warm |= vbit;
+            return streamed_plain(c, out_d, mu, x_d, batch);
+        }
+        const bool hit = c->sg.exec && c->sg.x == x_d && c->sg.out == out_d && c->sg.mu == mu && c->sg.batch == batch &&
+                         c->sg.variant == c->br_variant && c->sg.ks_gather == c->ks_force_gather;
+        if (!hit) {
+            drop_streamed_graph(c);
+            hipGraph_t graph = nullptr;
+            HIPCHECK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = streamed_plain(c, out_d, mu, x_d, batch);
+            const hipError_t e = hipStreamEndCapture(c->stream, &graph);  // always end the capture
+            if (rc) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            HIPCHECK(c, e);
+            hipGraphExec_t exec = nullptr;
+            const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            HIPCHECK(c, ei);
+            c->sg.exec = exec;
+            c->sg.x = x_d;
+            c->sg.out = out_d;
+            c->sg.mu = mu;
+            c->sg.batch = batch;
+            c->sg.variant = c->br_variant;
+            c->sg.ks_gather = c->ks_force_gather;
+        }
+        HIPCHECK(c, hipGraphLaunch((hipGraphExec_t)c->sg.exec, c->stream));
+        return TFHE_AMD_OK;
+    }
+#endif
+    return streamed_plain(c, out_d, mu, x_d, batch);
 }
 
 int tfhe_amd_bootstrap_host(tfhe_amd_ctx *c, int32_t *out, int32_t mu, const int32_t *x, int batch) {
