@@ -33,3 +33,15 @@ def test_bench_line_on_emulator(emu_lib):
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "bootstraps/s"
     assert d["decrypt_check"] is True
     assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_smoke_logic_on_emulator(emu_lib, monkeypatch):
+    """__graft_entry__.smoke() with the engine library swapped for the emulator build: the same
+    calls, keys and oracle comparison the driver runs on cuda:0"""
+    import importlib
+    T = importlib.import_module("experimental-tfhe_amd")
+    orig = T.load_library
+    monkeypatch.setattr(T, "load_library", lambda path=None: orig(emu_lib))
+    sys.path.insert(0, ROOT)
+    G = importlib.import_module("__graft_entry__")
+    G.smoke()
