@@ -433,15 +433,17 @@ struct Torus<int64_t> {
     // fft_processor_spqlios.cpp:131-142: mantissa shifted by (exponent-1075), truncation,
     // modulo 2^64; shifts of 64 or more (|x| < 2^-11: undefined in the reference) give 0.
     TFHE_DEVICE static int64_t from_double(double x) {
+        // Branch-free: a right shift of 53..63 already gives 0 (mant < 2^53), so the count is clamped
+        // instead of tested; the sign is applied as (v ^ s) - s with s = 0 or ~0.
         const uint64_t bits = (uint64_t)__builtin_bit_cast(int64_t, x);
         const uint64_t mant = (bits & 0x000FFFFFFFFFFFFFull) | 0x0010000000000000ull;
         const int trans = (int)((bits >> 52) & 0x7FF) - 1075;
-        uint64_t v;
-        if (trans > 0)
-            v = trans >= 64 ? 0 : (mant << trans);
-        else
-            v = (-trans) >= 64 ? 0 : (mant >> (-trans));
-        return (int64_t)((bits >> 63) ? (0 - v) : v);
+        const int rsh = -trans < 63 ? -trans : 63;
+        const uint64_t left = trans > 63 ? 0 : (mant << (trans & 63));
+        const uint64_t right = mant >> (rsh & 63);
+        const uint64_t v = trans > 0 ? left : right;
+        const uint64_t s = (uint64_t)(__builtin_bit_cast(int64_t, x) >> 63);
+        return (int64_t)((v ^ s) - s);
     }
     TFHE_DEVICE static double to_double(int64_t v) { return (double)v; }  // round to nearest even
 };

@@ -78,6 +78,10 @@ def check_fft_plugin(lib_path, N, count=4, seed=11, fft_waves=4):
         lag64 = O.lagrange_addmul(N, np.zeros((count, N)), O.execute_reverse_int(N, dig),
                                   O.execute_reverse_torus64(N, a64))
         assert np.array_equal(e.fft_torus64(lag64), O.execute_direct_torus64(N, lag64)), "execute_direct_torus64"
+        # execute_direct_torus64's shift ranges: results far below 1 (right shifts up to and beyond 63),
+        # around 2^64 (wrap) and far above (left shifts of 64 or more: defined as 0)
+        for sc in (2.0 ** -70, 2.0 ** -52, 2.0 ** 12, 2.0 ** 30, 2.0 ** 70):
+            assert np.array_equal(e.fft_torus64(lag64 * sc), O.execute_direct_torus64(N, lag64 * sc)), f"direct_torus64 x {sc}"
         assert np.array_equal(e.fft_torus32(np.zeros((1, N))), np.zeros((1, N), np.int32))
         assert np.array_equal(e.fft_torus64(np.zeros((1, N))), np.zeros((1, N), np.int64))
         got = e.lagrange_addmul(lag32, O.execute_reverse_int(N, dig), O.execute_reverse_int(N, a32))
