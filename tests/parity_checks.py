@@ -269,6 +269,36 @@ def check_lut_eval(lib_path, N=1024, l=3, Bgbit=8, d=12, B=3, seed=81, decrypt_t
         e.close()
 
 
+def check_streamed_graph(lib_path, N=1024, n=12, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=5, seed=91):
+    """tfhe_amd_bootstrap_streamed under TFHE_AMD_OPT_STREAMED_GRAPH: call 1 runs plain launches, call 2
+    captures the n+3 launches into a hipGraph, call 3 replays it; new data written into the SAME device
+    buffers must be picked up by the replay; a different batch size must re-capture.  (On the CPU
+    emulator build the option is accepted and ignored.)"""
+    s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb)
+    rs = np.random.RandomState(seed)
+    e = s.eng
+    try:
+        e.set_option(T.OPT_STREAMED_GRAPH, 1)
+        mu = 1 << 29
+        xa = rs.randint(-2 ** 31, 2 ** 31, size=(B, n + 1)).astype(np.int32)
+        xb = rs.randint(-2 ** 31, 2 ** 31, size=(B, n + 1)).astype(np.int32)
+        want_a, want_b = e.bootstrap(mu, xa), e.bootstrap(mu, xb)   # persistent kernel (parity-checked elsewhere)
+        assert np.array_equal(want_a[0], O.bootstrap32(N, s.bk, s.ks, mu, xa[0], l, Bgbit, ks_t, ks_bb))
+        x_d, out_d = e.to_device(xa), e.alloc(xa.nbytes)
+        for call in range(3):
+            e._chk(e.lib.tfhe_amd_bootstrap_streamed(e.ctx, out_d.ptr, mu, x_d.ptr, B))
+            assert np.array_equal(out_d.download(np.int32, xa.shape), want_a), f"streamed call {call}"
+        x_d.upload(xb)
+        e._chk(e.lib.tfhe_amd_bootstrap_streamed(e.ctx, out_d.ptr, mu, x_d.ptr, B))
+        assert np.array_equal(out_d.download(np.int32, xb.shape), want_b), "replay on new data in the same buffers"
+        e._chk(e.lib.tfhe_amd_bootstrap_streamed(e.ctx, out_d.ptr, mu, x_d.ptr, B - 2))   # other batch: re-capture
+        assert np.array_equal(out_d.download(np.int32, xb.shape)[:B - 2], want_b[:B - 2]), "re-captured for a smaller batch"
+        e._chk(e.lib.tfhe_amd_bootstrap_streamed(e.ctx, out_d.ptr, -mu, x_d.ptr, B - 2))  # other mu: re-capture
+        assert np.array_equal(out_d.download(np.int32, xb.shape)[:B - 2], e.bootstrap(-mu, xb[:B - 2])), "re-captured for another mu"
+    finally:
+        s.close()
+
+
 # ------------------------------------------------------- rounding range extremes
 def check_rounding_extremes(lib_path, br_variant=0):
     """Torus32 rounding has a short sequence valid for |x| < 2^51 and an exact fallback (DESIGN.md,

@@ -51,6 +51,10 @@ def test_keyswitch_real_shapes_emu(emu_lib, n_out, t, bb, B):
     P.check_keyswitch_shapes(emu_lib, 1024, n_out, t, bb, B)
 
 
+def test_streamed_schedule_fixed_buffers_emu(emu_lib):
+    P.check_streamed_graph(emu_lib, n=4, B=3)
+
+
 def test_cmux_on_data_emu(emu_lib):
     P.check_cmux_data(emu_lib, B=5)
 

@@ -111,6 +111,11 @@ def test_cmux_on_data(gpu_lib):
     P.check_cmux_data(gpu_lib, N=2048, l=3, Bgbit=7, B=6, seed=72)
 
 
+def test_streamed_schedule_hipgraph(gpu_lib):
+    """TFHE_AMD_OPT_STREAMED_GRAPH: capture, replay, replay on new data, re-capture"""
+    P.check_streamed_graph(gpu_lib, n=40, B=33)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("d,B", [(3, 5), (10, 9), (13, 17)])
 def test_lut_eval_gpu(gpu_lib, d, B):
