@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_from_torus_d", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
     "tfhe_amd_set_bootstrap_key", "tfhe_amd_load_keyswitch_key",
     "tfhe_amd_ifft_int32", "tfhe_amd_ifft_torus64", "tfhe_amd_fft_torus32", "tfhe_amd_fft_torus64",
-    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_mux_rotate", "tfhe_amd_cmux", "tfhe_amd_lut_eval",
+    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_mux_rotate", "tfhe_amd_extern_mul_exact", "tfhe_amd_cmux", "tfhe_amd_lut_eval",
     "tfhe_amd_blind_rotate", "tfhe_amd_blind_rotate_extract", "tfhe_amd_bootstrap_woks",
     "tfhe_amd_keyswitch", "tfhe_amd_bootstrap", "tfhe_amd_bootstrap_streamed", "tfhe_amd_bootstrap_host",
     "tfhe_amd_cb_bootstrap_woks", "tfhe_amd_modswitch",
@@ -106,6 +106,7 @@ def load_library(path=None):
     lib.tfhe_amd_extern_mul.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     lib.tfhe_amd_mux_rotate.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
     lib.tfhe_amd_cmux.argtypes = [vp, vp, vp, i32p, vp, vp, C.c_int]
+    lib.tfhe_amd_extern_mul_exact.argtypes = [vp, vp, vp, C.c_int]
     lib.tfhe_amd_lut_eval.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int]
     lib.tfhe_amd_blind_rotate.argtypes = [vp, vp, i32p, C.c_int]
     lib.tfhe_amd_blind_rotate_extract.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
@@ -331,6 +332,16 @@ class Engine:
         self._chk(self.lib.tfhe_amd_extern_mul(self.ctx, d.ptr, g, index, acc.shape[0]))
         out = d.download(self.torus, acc.shape)
         d.free()
+        return out
+
+    def extern_mul_exact(self, acc, gsw_torus):
+        """FFT-free external product: gsw_torus = one TGSW sample in coefficient form [2l][2][N]"""
+        acc = np.ascontiguousarray(acc, self.torus).reshape(-1, 2, self.params.N)
+        d, g = self.to_device(acc), self.to_device(np.ascontiguousarray(gsw_torus, self.torus))
+        self._chk(self.lib.tfhe_amd_extern_mul_exact(self.ctx, d.ptr, g.ptr, acc.shape[0]))
+        out = d.download(self.torus, acc.shape)
+        d.free()
+        g.free()
         return out
 
     def mux_rotate(self, acc, g, index, barai):

@@ -304,6 +304,17 @@ void fill_common(const tfhe_amd_ctx *c, BlindRotateArgs<T> &a, const tfhe_amd_gs
     a.n_steps = steps;
     a.batch = batch;
 }
+template <typename T, int LOGN>
+int launch_exact_t(tfhe_amd_ctx *c, void *acc_d, const void *gsw_torus_d, int batch) {
+    const size_t lds = ExactLds<T, LOGN>::total(c->p.l);
+    if (lds > 160 * 1024) return fail(c, TFHE_AMD_ERR_PARAM, "exact external product: the digits of this gadget do not fit the LDS");
+    auto kernel = k_extprod_exact<T, LOGN>;
+    if (int rc = set_lds(c, kernel, lds)) return rc;
+    TFHE_LAUNCH((k_extprod_exact<T, LOGN>), dim3(batch), dim3(256), lds, c->stream, (T *)acc_d, (const T *)gsw_torus_d,
+                c->gd, batch);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
 int launch_br(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) { return launch_br32(c, a); }
 int launch_br(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) { return launch_br64(c, a); }
 
@@ -1021,6 +1032,17 @@ int tfhe_amd_modswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *x_d, int 
         TFHE_LAUNCH_FLAT((k_modswitch<11>), dim3(blocks), dim3(256), c->stream, out_d, x_d, total);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
+}
+
+// exact external product: the reference's FFT-free backend (poc:285-316, CB/poc_karatsuba.cpp)
+int tfhe_amd_extern_mul_exact(tfhe_amd_ctx *c, void *acc_d, const void *gsw_torus_d, int batch) {
+    if (!c || !acc_d || !gsw_torus_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    if (c->p.torus_bits == 32)
+        return c->logn == 10 ? launch_exact_t<int32_t, 10>(c, acc_d, gsw_torus_d, batch)
+                             : launch_exact_t<int32_t, 11>(c, acc_d, gsw_torus_d, batch);
+    return c->logn == 10 ? launch_exact_t<int64_t, 10>(c, acc_d, gsw_torus_d, batch)
+                         : launch_exact_t<int64_t, 11>(c, acc_d, gsw_torus_d, batch);
 }
 
 }  // extern "C"

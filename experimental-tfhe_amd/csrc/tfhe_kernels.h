@@ -991,6 +991,68 @@ TFHE_GLOBAL void k_modswitch(int32_t *__restrict__ out, const int32_t *__restric
     if (gid < total) out[gid] = modswitch_2N<LOGN>(in[gid]);
 }
 
+// ------------------------------------------- exact (FFT-free) external product
+// The reference's `#ifndef USE_FFT` backend (poc:285-316): the same external product with every
+// polynomial product computed exactly in Z_{2^W}[X]/(X^N+1) (torus{32,64}PolynomialMultAddKaratsuba,
+// CB/poc_karatsuba.cpp; here the plain negacyclic convolution -- same ring element, no rounding).
+// A verification backend: what the fp64 path approximates.  One workgroup per sample; the digits of
+// the sample stay in LDS, each key polynomial is staged in LDS as its negacyclic extension
+// [g | -g] so that coefficient (i - j) mod 2N needs no sign logic.
+template <typename T, int LOGN>
+struct ExactLds {
+    static constexpr int N = 1 << LOGN;
+    static constexpr size_t dig_bytes(int l) { return sizeof(int32_t) * 2 * (size_t)l * N; }
+    static constexpr size_t total(int l) { return dig_bytes(l) + sizeof(T) * 2 * N; }
+};
+template <typename T, int LOGN>
+TFHE_GLOBAL void __launch_bounds__(256)
+    k_extprod_exact(T *__restrict__ acc_io, const T *__restrict__ gsw, Gadget gd, int batch) {
+    using U = typename Torus<T>::U;
+    constexpr int N = 1 << LOGN, R = N / 256, BITS = Torus<T>::BITS;
+    TFHE_DYN_LDS(smem);
+    int32_t *dig = reinterpret_cast<int32_t *>(smem);                                    // [2l][N]
+    U *gext = reinterpret_cast<U *>(smem + ExactLds<T, LOGN>::dig_bytes(gd.l));            // [2N]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= batch) return;
+    T *acc = acc_io + (size_t)b * 2 * N;
+    // gadget decomposition (tgsw_functions.cpp:224-337 / poc:492-515; offset from the host)
+    const U mask = ((U)1 << gd.Bgbit) - 1;
+    const int32_t halfBg = 1 << (gd.Bgbit - 1);
+    for (int e = tid; e < 2 * N; e += 256) {
+        const U v = (U)acc[e] + (U)gd.offset;
+        const int poly = e >> LOGN, c = e & (N - 1);
+        for (int p = 0; p < gd.l; p++)
+            dig[(poly * gd.l + p) * N + c] = (int32_t)((v >> (BITS - (p + 1) * gd.Bgbit)) & mask) - halfBg;
+    }
+    U res[2][R];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < R; r++) res[q][r] = 0;
+    for (int p = 0; p < 2 * gd.l; p++) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            __syncthreads();  // digits written / previous polynomial consumed
+            const T *g = gsw + ((size_t)p * 2 + q) * N;
+            for (int e = tid; e < N; e += 256) {
+                gext[e] = (U)g[e];
+                gext[N + e] = (U)0 - (U)g[e];
+            }
+            __syncthreads();
+            const int32_t *dp = dig + p * N;
+            for (int j = 0; j < N; j++) {
+                const U d = (U)(T)dp[j];  // sign-extended digit, wave-uniform (LDS broadcast)
+#pragma unroll
+                for (int r = 0; r < R; r++) res[q][r] += d * gext[(tid + 256 * r - j) & (2 * N - 1)];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[q * N + tid + 256 * r] = (T)res[q][r];
+}
+
 // ----------------------------------------------------------- LWE key switch
 // lweKeySwitch (lwe_functions.cpp:136-171) / preKeySwitch (poc:437-465), one workgroup per
 // sample, threads over the n_out+1 output coefficients.  ks: [n_in][t][base][n_out+1].

@@ -142,6 +142,13 @@ int tfhe_amd_extern_mul(tfhe_amd_ctx *ctx, void *acc_d, const tfhe_amd_gsw *gsw,
 int tfhe_amd_mux_rotate(tfhe_amd_ctx *ctx, void *acc_d, const tfhe_amd_gsw *gsw, int index,
                         const int32_t *barai_d, int batch);
 
+/* The same external product with exact polynomial products in Z_{2^W}[X]/(X^N+1) -- the reference's
+ * FFT-free backend (`#ifndef USE_FFT`, poc:285-316, built on torus{32,64}PolynomialMultAddKaratsuba_lvl{1,2},
+ * CB/poc_karatsuba.cpp:80-95,188-203).  gsw_torus_d: ONE TGSW sample in coefficient form, device memory,
+ * [(k+1)l][k+1][N] torus values.  A verification backend: tfhe_amd_extern_mul approximates this result
+ * to within the fp64 rounding of the transforms. */
+int tfhe_amd_extern_mul_exact(tfhe_amd_ctx *ctx, void *acc_d, const void *gsw_torus_d, int batch);
+
 /* CMux on data, the consumer of a circuit bootstrap (stub `CMux` at poc:877-879; in library terms
  * tGswFFTExternMulToTLwe applied to d1 - d0, plus d0): out[i] = gsw[sel[i]] (x) (d1[i] - d0[i]) + d0[i].
  * sel_d: [batch] TGSW indices into `gsw` (NULL: index 0 for every sample); d0_d, d1_d, out_d:

@@ -408,6 +408,40 @@ void orc_blind_rotate_extract32(const orc_tables *t, int32_t *lwe, const int32_t
     free(acc);
 }
 
+/* exact external product: the reference's FFT-free backend (`#ifndef USE_FFT`, poc:285-316): the
+ * accumulation loops of tgsw_functions.cpp:441-443 with torus{32,64}PolynomialMultAddKaratsuba
+ * (CB/poc_karatsuba.cpp:80-95,188-203) as the product -- restated with the plain negacyclic
+ * convolution, which is the same ring element (pinned against the reference's Karatsuba objects
+ * by tests/test_oracle_golden.py).  gsw: coefficient form [2l][2][N]. */
+void orc_extprod_exact32(int32_t *acc, const int32_t *gsw, int N, int l, int Bgbit) {
+    const int kpl = 2 * l;
+    int32_t *deca = (int32_t *)malloc(sizeof(int32_t) * (size_t)kpl * N);
+    int32_t *prod = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
+    for (int i = 0; i <= 1; i++) orc_decomp32(deca + i * l * N, acc + i * N, N, l, Bgbit);
+    memset(acc, 0, sizeof(int32_t) * (size_t)2 * N);
+    for (int p = 0; p < kpl; p++)
+        for (int q = 0; q <= 1; q++) {
+            orc_negacyclic_mul32(prod, deca + p * N, gsw + ((size_t)p * 2 + q) * N, N);
+            for (int j = 0; j < N; j++) acc[q * N + j] = (int32_t)((uint32_t)acc[q * N + j] + (uint32_t)prod[j]);
+        }
+    free(deca);
+    free(prod);
+}
+void orc_extprod_exact64(int64_t *acc, const int64_t *gsw, int N, int l, int Bgbit) {
+    const int kpl = 2 * l;
+    int32_t *deca = (int32_t *)malloc(sizeof(int32_t) * (size_t)kpl * N);
+    int64_t *prod = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
+    for (int i = 0; i <= 1; i++) orc_decomp64(deca + i * l * N, acc + i * N, N, l, Bgbit);
+    memset(acc, 0, sizeof(int64_t) * (size_t)2 * N);
+    for (int p = 0; p < kpl; p++)
+        for (int q = 0; q <= 1; q++) {
+            orc_negacyclic_mul64(prod, deca + p * N, gsw + ((size_t)p * 2 + q) * N, N);
+            for (int j = 0; j < N; j++) acc[q * N + j] = (int64_t)((uint64_t)acc[q * N + j] + (uint64_t)prod[j]);
+        }
+    free(deca);
+    free(prod);
+}
+
 /* ---- CMux on data and LUT evaluation by vertical packing --------------------------------------
  * The reference ends at the stub `CMux(out, c, in0, in1, env)` (poc:877-879).  Restated from the two
  * reference operations it would be built from: tGswFFTExternMulToTLwe (tgsw_functions.cpp:424-449)

@@ -114,6 +114,11 @@ void orc_blind_rotate_extract32(const orc_tables *t, int32_t *lwe /* N+1 */, con
                                 const double *bkfft, int barb, const int32_t *bara, int n,
                                 int l, int Bgbit);
 
+/* exact (FFT-free) external product, `#ifndef USE_FFT` backend poc:285-316 + CB/poc_karatsuba.cpp:80-95,188-203;
+ * gsw in coefficient form [2l][2][N] */
+void orc_extprod_exact32(int32_t *acc /* 2N */, const int32_t *gsw, int N, int l, int Bgbit);
+void orc_extprod_exact64(int64_t *acc /* 2N */, const int64_t *gsw, int N, int l, int Bgbit);
+
 /* CMux on data and LUT evaluation by vertical packing (stub CMux poc:877-879; composition of
  * tgsw_functions.cpp:424-449 and lwe_functions.cpp:328-333, see the .c file) */
 void orc_cmux32(const orc_tables *t, int32_t *out /* 2N */, const double *gsw, const int32_t *d0,

@@ -78,4 +78,8 @@ if max_stage >= 10:
         P.check_fft_plugin(T.DEFAULT_LIB, N, count=w + 3, fft_waves=w)
     P.check_streamed_graph(T.DEFAULT_LIB, n=24, B=9)
     say("   ok")
+if max_stage >= 11:
+    say("stage 11: exact (FFT-free) external product, Torus32 N=1024 and Torus64 N=2048")
+    say("   fp64 vs exact, worst difference:", P.check_exact_extprod(T.DEFAULT_LIB, 32, 1024, 2, 10, B=5, fft_bound=4),
+        P.check_exact_extprod(T.DEFAULT_LIB, 64, 2048, 4, 9, B=5, fft_bound=2 ** 32))
 say("done")

@@ -218,6 +218,18 @@ def extprod32(N, acc, gsw, l, Bgbit):
     return acc
 
 
+def extprod_exact32(N, acc, gsw_torus, l, Bgbit):
+    acc, g = i32(acc).copy(), i32(gsw_torus)
+    lib().orc_extprod_exact32(_p(acc, C.c_int32), _p(g, C.c_int32), N, l, Bgbit)
+    return acc
+
+
+def extprod_exact64(N, acc, gsw_torus, l, Bgbit):
+    acc, g = i64(acc).copy(), i64(gsw_torus)
+    lib().orc_extprod_exact64(_p(acc, C.c_int64), _p(g, C.c_int64), N, l, Bgbit)
+    return acc
+
+
 def cmux32(N, gsw, d0, d1, l, Bgbit):
     out = np.empty(2 * N, np.int32)
     d0, d1, gsw = i32(d0), i32(d1), f64(gsw)

@@ -299,6 +299,34 @@ def check_streamed_graph(lib_path, N=1024, n=12, l=2, Bgbit=10, ks_t=8, ks_bb=2,
         s.close()
 
 
+def check_exact_extprod(lib_path, torus_bits=32, N=1024, l=2, Bgbit=10, B=3, seed=95, fft_bound=None):
+    """tfhe_amd_extern_mul_exact (the reference's FFT-free backend, poc:285-316) against the oracle's exact
+    negacyclic products, bit for bit; and the fp64 external product against it: the difference is the
+    rounding noise of the transforms, bounded by `fft_bound` torus units."""
+    rs = np.random.RandomState(seed)
+    tkey = O.keygen_binary(N, SEED, 2)
+    stdev = 2.0 ** -25 if torus_bits == 32 else 2.0 ** -44
+    gsw_t = T.keygen_bk_torus(torus_bits, np.array([1], np.int32), tkey, l, Bgbit, stdev, SEED, 9500, lib_path=lib_path)[0]
+    e = T.Engine(torus_bits=torus_bits, n=1, N=N, l=l, Bgbit=Bgbit, ks_t=0, lib_path=lib_path)
+    try:
+        if torus_bits == 32:
+            acc = rs.randint(-2 ** 31, 2 ** 31, size=(B, 2, N)).astype(np.int32)
+            want = np.stack([O.extprod_exact32(N, acc[b].ravel(), gsw_t, l, Bgbit) for b in range(B)]).reshape(B, 2, N)
+        else:
+            acc = rs.randint(-2 ** 63, 2 ** 63 - 1, size=(B, 2, N), dtype=np.int64)
+            want = np.stack([O.extprod_exact64(N, acc[b].ravel(), gsw_t, l, Bgbit) for b in range(B)]).reshape(B, 2, N)
+        got = e.extern_mul_exact(acc, gsw_t)
+        assert np.array_equal(got, want), "exact external product"
+        approx = e.extern_mul(acc, e.gsw_from_torus(gsw_t[None]), 0)
+        diff = (approx.astype(object) - got.astype(object) + 2 ** (torus_bits - 1)) % 2 ** torus_bits - 2 ** (torus_bits - 1)
+        worst = max(abs(int(v)) for v in diff.ravel())
+        if fft_bound is not None:
+            assert worst <= fft_bound, f"fp64 external product is {worst} torus units from the exact one (bound {fft_bound})"
+        return worst
+    finally:
+        e.close()
+
+
 # ------------------------------------------------------- rounding range extremes
 def check_rounding_extremes(lib_path, br_variant=0):
     """Torus32 rounding has a short sequence valid for |x| < 2^51 and an exact fallback (DESIGN.md,

@@ -55,6 +55,12 @@ def test_streamed_schedule_fixed_buffers_emu(emu_lib):
     P.check_streamed_graph(emu_lib, n=4, B=3)
 
 
+@pytest.mark.parametrize("bits,N,l,Bgbit,bound", [(32, 1024, 2, 10, 4), (64, 2048, 4, 9, 2 ** 32)])
+def test_exact_external_product_emu(emu_lib, bits, N, l, Bgbit, bound):
+    """FFT-free backend (poc:285-316) bit-exact vs the oracle; fp64 path within `bound` units of it"""
+    P.check_exact_extprod(emu_lib, bits, N, l, Bgbit, B=2, fft_bound=bound)
+
+
 def test_cmux_on_data_emu(emu_lib):
     P.check_cmux_data(emu_lib, B=5)
 

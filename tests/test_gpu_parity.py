@@ -111,6 +111,14 @@ def test_cmux_on_data(gpu_lib):
     P.check_cmux_data(gpu_lib, N=2048, l=3, Bgbit=7, B=6, seed=72)
 
 
+@pytest.mark.parametrize("bits,N,l,Bgbit,bound", [(32, 1024, 2, 10, 4), (32, 1024, 2, 8, 4), (64, 2048, 4, 9, 2 ** 32),
+                                                  (64, 1024, 3, 10, 2 ** 32)])
+def test_exact_external_product(gpu_lib, bits, N, l, Bgbit, bound):
+    """the reference's FFT-free backend on the GPU, bit-exact vs the oracle's exact products; and the
+    fp64 external product within the transforms' rounding noise of it"""
+    P.check_exact_extprod(gpu_lib, bits, N, l, Bgbit, B=7, fft_bound=bound)
+
+
 def test_streamed_schedule_hipgraph(gpu_lib):
     """TFHE_AMD_OPT_STREAMED_GRAPH: capture, replay, replay on new data, re-capture"""
     P.check_streamed_graph(gpu_lib, n=40, B=33)
