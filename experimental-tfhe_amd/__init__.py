@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_from_torus_d", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
     "tfhe_amd_set_bootstrap_key", "tfhe_amd_load_keyswitch_key",
     "tfhe_amd_ifft_int32", "tfhe_amd_ifft_torus64", "tfhe_amd_fft_torus32", "tfhe_amd_fft_torus64",
-    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_mux_rotate", "tfhe_amd_extern_mul_exact", "tfhe_amd_cmux", "tfhe_amd_lut_eval",
+    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_hp_twiddles", "tfhe_amd_hp_ifft", "tfhe_amd_hp_fft",
+    "tfhe_amd_mux_rotate", "tfhe_amd_extern_mul_exact", "tfhe_amd_cmux", "tfhe_amd_lut_eval",
     "tfhe_amd_blind_rotate", "tfhe_amd_blind_rotate_extract", "tfhe_amd_bootstrap_woks",
     "tfhe_amd_keyswitch", "tfhe_amd_bootstrap", "tfhe_amd_bootstrap_streamed", "tfhe_amd_bootstrap_host",
     "tfhe_amd_cb_bootstrap_woks", "tfhe_amd_modswitch",
@@ -107,6 +108,9 @@ def load_library(path=None):
     lib.tfhe_amd_mux_rotate.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
     lib.tfhe_amd_cmux.argtypes = [vp, vp, vp, i32p, vp, vp, C.c_int]
     lib.tfhe_amd_extern_mul_exact.argtypes = [vp, vp, vp, C.c_int]
+    lib.tfhe_amd_hp_twiddles.argtypes = [C.c_int, vp, vp]
+    lib.tfhe_amd_hp_ifft.argtypes = [vp, vp, vp, C.c_int]
+    lib.tfhe_amd_hp_fft.argtypes = [vp, vp, vp, C.c_int]
     lib.tfhe_amd_lut_eval.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int]
     lib.tfhe_amd_blind_rotate.argtypes = [vp, vp, i32p, C.c_int]
     lib.tfhe_amd_blind_rotate_extract.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
@@ -333,6 +337,18 @@ class Engine:
         out = d.download(self.torus, acc.shape)
         d.free()
         return out
+
+    def hp_ifft(self, x):
+        """Real96 iFFT: [B][N] Torus64 -> [B][N/2][4] uint64 (re.lo, re.hi, im.lo, im.hi)"""
+        N = self.params.N
+        x = np.ascontiguousarray(x, np.int64).reshape(-1, N)
+        return self._roundtrip(self.lib.tfhe_amd_hp_ifft, x, np.uint64, (x.shape[0], N // 2, 4), x.shape[0])
+
+    def hp_fft(self, spec):
+        """Real96 FFT: [B][N/2][4] uint64 -> [B][N] Torus64 (divided by N/2)"""
+        N = self.params.N
+        spec = np.ascontiguousarray(spec, np.uint64).reshape(-1, N // 2, 4)
+        return self._roundtrip(self.lib.tfhe_amd_hp_fft, spec, np.int64, (spec.shape[0], N), spec.shape[0])
 
     def extern_mul_exact(self, acc, gsw_torus):
         """FFT-free external product: gsw_torus = one TGSW sample in coefficient form [2l][2][N]"""
@@ -577,3 +593,11 @@ def keygen_ks32(in_key, out_key, t, basebit, stdev, seed, stream, lib_path=None)
     assert lib.tfhe_amd_keygen_ks32(_np_ptr(ks), _np_ptr(in_key), in_key.size, _np_ptr(out_key), out_key.size, t,
                                     basebit, float(stdev), seed, stream) == OK
     return ks
+
+
+def hp_twiddles(n, lib_path=None):
+    """Real96 twiddle tables of tfhe_amd_hp_twiddles: (powomega, powombar), each [n][4] uint64"""
+    lib = load_library(lib_path)
+    a, b = np.empty((n, 4), np.uint64), np.empty((n, 4), np.uint64)
+    assert lib.tfhe_amd_hp_twiddles(n, _np_ptr(a), _np_ptr(b)) == OK
+    return a, b

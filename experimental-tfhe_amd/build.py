@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtfhe_amd.so")
 OUT_ABLATE = os.path.join(HERE, "libtfhe_amd_ablate.so")  # diagnostic build (tools/ablate.py), never loaded by default
 OUT_ASMLDS = os.path.join(HERE, "libtfhe_amd_asmlds.so")  # experiment build (--asm-lds), never loaded by default
-SOURCES = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp")]
+SOURCES = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp"), os.path.join(CSRC, "hp_twiddles.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "devport.h"),
                   os.path.join(os.path.dirname(HERE), "include", "tfhe_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",

@@ -42,6 +42,7 @@ struct tfhe_amd_ctx {
     void *ws_acc;
     size_t ws_acc_bytes;
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
+    void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
     bool ks_force_gather;  // TFHE_AMD_OPT_KS_GATHER: per-sample gather kernel even when the tiled one applies
     int br_variant;        // TFHE_AMD_OPT_BR_VARIANT
     int fft_waves;         // TFHE_AMD_OPT_FFT_WAVES
@@ -440,6 +441,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     memset(&c->sg, 0, sizeof(c->sg));
     c->ws_lwe = c->ws_acc = nullptr;
     c->vp_rot_d = nullptr;
+    c->hp_tw_d = nullptr;
     c->ws_lwe_bytes = c->ws_acc_bytes = 0;
     if (hipSetDevice(device) != hipSuccess) {
         delete c;
@@ -490,6 +492,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     if (c->ws_lwe) (void)hipFree(c->ws_lwe);
     if (c->ws_acc) (void)hipFree(c->ws_acc);
     if (c->vp_rot_d) (void)hipFree(c->vp_rot_d);
+    if (c->hp_tw_d) (void)hipFree(c->hp_tw_d);
     drop_streamed_graph(c);
 #ifndef TFHE_EMU
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1043,6 +1046,43 @@ int tfhe_amd_extern_mul_exact(tfhe_amd_ctx *c, void *acc_d, const void *gsw_toru
                              : launch_exact_t<int32_t, 11>(c, acc_d, gsw_torus_d, batch);
     return c->logn == 10 ? launch_exact_t<int64_t, 10>(c, acc_d, gsw_torus_d, batch)
                          : launch_exact_t<int64_t, 11>(c, acc_d, gsw_torus_d, batch);
+}
+
+// ---- Real96 high-precision anticyclic transforms (high-precision-anticyclic-fft/src/code.cpp)
+static int hp_prepare(tfhe_amd_ctx *c) {
+    if (c->hp_tw_d) return TFHE_AMD_OK;
+    const int n = 2 * c->p.N;
+    std::vector<uint64_t> tw((size_t)2 * n * 4);
+    if (tfhe_amd_hp_twiddles(n, tw.data(), tw.data() + (size_t)n * 4) != TFHE_AMD_OK)
+        return fail(c, TFHE_AMD_ERR_PARAM, "Real96 twiddle tables");
+    HIPCHECK(c, hipMalloc(&c->hp_tw_d, tw.size() * 8));
+    HIPCHECK(c, hipMemcpyAsync(c->hp_tw_d, tw.data(), tw.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_hp_ifft(tfhe_amd_ctx *c, uint64_t *out_d, const int64_t *in_d, int batch) {
+    if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    if (int rc = hp_prepare(c)) return rc;
+    const HpCplx *pw = (const HpCplx *)c->hp_tw_d;
+    if (c->logn == 10)
+        TFHE_LAUNCH((k_hp_ifft<10>), dim3(batch), dim3(256), HpGeom<10>::lds_bytes, c->stream, (HpCplx *)out_d, in_d, pw, batch);
+    else
+        TFHE_LAUNCH((k_hp_ifft<11>), dim3(batch), dim3(256), HpGeom<11>::lds_bytes, c->stream, (HpCplx *)out_d, in_d, pw, batch);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_hp_fft(tfhe_amd_ctx *c, int64_t *out_d, const uint64_t *in_d, int batch) {
+    if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (batch == 0) return TFHE_AMD_OK;
+    if (int rc = hp_prepare(c)) return rc;
+    const HpCplx *pwbar = (const HpCplx *)c->hp_tw_d + 2 * c->p.N;
+    if (c->logn == 10)
+        TFHE_LAUNCH((k_hp_fft<10>), dim3(batch), dim3(256), HpGeom<10>::lds_bytes, c->stream, out_d, (const HpCplx *)in_d, pwbar, batch);
+    else
+        TFHE_LAUNCH((k_hp_fft<11>), dim3(batch), dim3(256), HpGeom<11>::lds_bytes, c->stream, out_d, (const HpCplx *)in_d, pwbar, batch);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
 }
 
 }  // extern "C"

@@ -1053,6 +1053,110 @@ TFHE_GLOBAL void __launch_bounds__(256)
         for (int r = 0; r < R; r++) acc[q * N + tid + 256 * r] = (T)res[q][r];
 }
 
+// ------------------------------------- Real96 high-precision anticyclic transforms
+// high-precision-anticyclic-fft/src/code.cpp ("HP"): the same radix-2 structure as spqlios, on
+// 128-bit fixed point (a Real96 is a two's-complement integer v standing for v / 2^64, HP:17-40),
+// n = 2N, N/2 complex points.  One 256-thread workgroup per polynomial, points in LDS (32 B each:
+// 32 KB at N = 2048), one workgroup barrier per stage, twiddles read from the [n] table in global
+// memory (128 KB at n = 4096: L2-resident).  Integer arithmetic: results are exact functions of
+// the inputs, so parity with the CPU restatement is equality.
+typedef unsigned __int128 u128;
+struct HpCplx {
+    u128 re, im;
+};
+// intmul (HP:79-95 = :148-169): (a * b) >> 64 for a twiddle b in [-1, 1) with sign-extended high word
+TFHE_DEVICE u128 hp_intmul(u128 a, u128 b) {
+    const uint64_t alo = (uint64_t)a, ahi = (uint64_t)(a >> 64), blo = (uint64_t)b, bhi = (uint64_t)(b >> 64);
+    u128 tab = (u128)blo * ahi;
+    const u128 tcd = (((u128)blo * alo) >> 64) | ((u128)((uint64_t)((int64_t)ahi >> 63) & (0 - blo)) << 64);
+    tab += tcd;
+    if (bhi >> 63) tab -= a;
+    return tab;
+}
+// std::complex<Real96> product: data on the left, twiddle on the right
+TFHE_DEVICE HpCplx hp_cmul(const HpCplx &a, const HpCplx &w) {
+    HpCplx r;
+    r.re = hp_intmul(a.re, w.re) - hp_intmul(a.im, w.im);
+    r.im = hp_intmul(a.re, w.im) + hp_intmul(a.im, w.re);
+    return r;
+}
+template <int LOGN>
+struct HpGeom {
+    static constexpr int N = 1 << LOGN, NS4 = N / 2, n = 2 * N;
+    static constexpr size_t lds_bytes = sizeof(HpCplx) * NS4;
+};
+// iFFT (HP:391-444): Torus64 coefficients -> N/2 complex Real96 values
+template <int LOGN>
+TFHE_GLOBAL void __launch_bounds__(256)
+    k_hp_ifft(HpCplx *__restrict__ out, const int64_t *__restrict__ in, const HpCplx *__restrict__ pw, int batch) {
+    using G = HpGeom<LOGN>;
+    constexpr int NS4 = G::NS4;
+    TFHE_DYN_LDS(smem);
+    HpCplx *buf = reinterpret_cast<HpCplx *>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= batch) return;
+    const int64_t *p = in + (size_t)b * G::N;
+    for (int j = tid; j < NS4; j += 256) {
+        HpCplx v;
+        v.re = (u128)(__int128)p[j];  // t64tor96, HP:184-189
+        v.im = (u128)(__int128)p[j + NS4];
+        buf[j] = hp_cmul(v, pw[j]);
+    }
+    __syncthreads();
+    for (int nn = NS4; nn >= 2; nn >>= 1) {
+        const int halfnn = nn >> 1, step = 2 * (NS4 / halfnn);
+        for (int bf = tid; bf < NS4 / 2; bf += 256) {
+            const int off = bf & (halfnn - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + halfnn;
+            const HpCplx t1 = buf[i1], t2 = buf[i2];
+            HpCplx sum, dif;
+            sum.re = t1.re + t2.re;
+            sum.im = t1.im + t2.im;
+            dif.re = t1.re - t2.re;
+            dif.im = t1.im - t2.im;
+            buf[i1] = sum;
+            buf[i2] = hp_cmul(dif, pw[step * off]);
+        }
+        __syncthreads();
+    }
+    HpCplx *o = out + (size_t)b * NS4;
+    for (int j = tid; j < NS4; j += 256) o[j] = buf[j];
+}
+// FFT (HP:446-512): N/2 complex Real96 values -> Torus64 coefficients, divided by N/2 (">> 10", HP:499-500)
+template <int LOGN>
+TFHE_GLOBAL void __launch_bounds__(256)
+    k_hp_fft(int64_t *__restrict__ out, const HpCplx *__restrict__ in, const HpCplx *__restrict__ pwbar, int batch) {
+    using G = HpGeom<LOGN>;
+    constexpr int NS4 = G::NS4;
+    TFHE_DYN_LDS(smem);
+    HpCplx *buf = reinterpret_cast<HpCplx *>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= batch) return;
+    const HpCplx *p = in + (size_t)b * NS4;
+    for (int j = tid; j < NS4; j += 256) buf[j] = p[j];
+    __syncthreads();
+    for (int nn = 2; nn <= NS4; nn <<= 1) {
+        const int halfnn = nn >> 1, step = 2 * (NS4 / halfnn);
+        for (int bf = tid; bf < NS4 / 2; bf += 256) {
+            const int off = bf & (halfnn - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + halfnn;
+            const HpCplx t1 = buf[i1], t2 = hp_cmul(buf[i2], pwbar[step * off]);
+            HpCplx sum, dif;
+            sum.re = t1.re + t2.re;
+            sum.im = t1.im + t2.im;
+            dif.re = t1.re - t2.re;
+            dif.im = t1.im - t2.im;
+            buf[i1] = sum;
+            buf[i2] = dif;
+        }
+        __syncthreads();
+    }
+    int64_t *o = out + (size_t)b * G::N;
+    for (int j = tid; j < NS4; j += 256) {
+        const HpCplx v = hp_cmul(buf[j], pwbar[j]);
+        o[j] = (int64_t)(uint64_t)(v.re >> (LOGN - 1));
+        o[j + NS4] = (int64_t)(uint64_t)(v.im >> (LOGN - 1));
+    }
+}
+
 // ----------------------------------------------------------- LWE key switch
 // lweKeySwitch (lwe_functions.cpp:136-171) / preKeySwitch (poc:437-465), one workgroup per
 // sample, threads over the n_out+1 output coefficients.  ks: [n_in][t][base][n_out+1].

@@ -133,6 +133,19 @@ int tfhe_amd_fft_torus64(tfhe_amd_ctx *ctx, int64_t *out_d, const double *in_d, 
 int tfhe_amd_lagrange_addmul(tfhe_amd_ctx *ctx, double *res_d, const double *a_d, const double *b_d,
                              int batch, int b_shared);
 
+/* ---- Real96 high-precision anticyclic transforms (high-precision-anticyclic-fft/src/code.cpp = HP) --
+ * 128-bit fixed point: a Real96 is a two's-complement integer v standing for v / 2^64, stored here as
+ * two little-endian uint64 (lo, hi); a complex value is (re, im) = 4 uint64 (HP:17-40, 236).
+ * Any context of ring degree N serves (the torus width is not used); the reference runs N = 2048. */
+/* twiddle tables, host: powomega[i] = (cos, sin)(2 pi i / n), powombar[i] = (cos(i), sin(n - i)), 2^64-scaled
+ * and rounded to nearest, +1 stored as 2^64 - 1 (accurate_cos/accurate_sin HP:246-278, precomp_* HP:378-389).
+ * n = 2N; each table [n][4] uint64; either pointer may be NULL */
+int tfhe_amd_hp_twiddles(int n, uint64_t *powomega, uint64_t *powombar);
+/* iFFT (HP:391-444): in_d [batch][N] Torus64 -> out_d [batch][N/2][4] uint64 */
+int tfhe_amd_hp_ifft(tfhe_amd_ctx *ctx, uint64_t *out_d, const int64_t *in_d, int batch);
+/* FFT (HP:446-512): in_d [batch][N/2][4] uint64 (not modified) -> out_d [batch][N] Torus64, divided by N/2 */
+int tfhe_amd_hp_fft(tfhe_amd_ctx *ctx, int64_t *out_d, const uint64_t *in_d, int batch);
+
 /* ---- L2: ring / TGSW ---------------------------------------------------------------- */
 /* tGswFFTExternMulToTLwe (CB/tgsw_functions.cpp:424-449; PoC inline poc:609-620):
  * acc[i] <- gsw[index] (x) acc[i], acc_d: [batch][2][N] torus */

@@ -825,3 +825,102 @@ void orc_privks_create(int32_t *privks, const int32_t *key2, int n2, const int32
                 }
         }
 }
+
+/* ---- Real96 high-precision anticyclic FFT (high-precision-anticyclic-fft/src/code.cpp = "HP") ----
+ * 128-bit fixed point: a Real96 is a two's-complement integer v standing for v / 2^64 (HP:17-40).
+ * PARITY UNPINNED by reference object code: HP/code.cpp needs NTL (absent here), so this restatement
+ * is checked by properties only (round trip, unit circle, agreement of two independent twiddle
+ * builders); see tests/test_hp_fft.py. */
+typedef unsigned __int128 u128;
+
+/* intmul_best == intmul_ref, HP:79-95,148-169: (a * b) >> 64 for a twiddle b in [-1, 1) whose high
+ * word is its sign extension */
+static u128 hp_intmul(u128 a, u128 b) {
+    const uint64_t alo = (uint64_t)a, ahi = (uint64_t)(a >> 64), blo = (uint64_t)b, bhi = (uint64_t)(b >> 64);
+    u128 tab = (u128)blo * ahi;
+    const u128 tcd = (((u128)blo * alo) >> 64) | ((u128)((uint64_t)((int64_t)ahi >> 63) & (0 - blo)) << 64);
+    tab += tcd;
+    if (bhi >> 63) tab -= a;
+    return tab;
+}
+/* std::complex<Real96> product as libstdc++ instantiates it for a class type:
+ * re = a.re*b.re - a.im*b.im; im = a.re*b.im + a.im*b.re (data on the left, twiddle on the right) */
+static void hp_cmul(u128 *re, u128 *im, u128 are, u128 aim, u128 bre, u128 bim) {
+    const u128 r = hp_intmul(are, bre) - hp_intmul(aim, bim);
+    const u128 i = hp_intmul(are, bim) + hp_intmul(aim, bre);
+    *re = r;
+    *im = i;
+}
+
+/* accurate_cos / accurate_sin, HP:246-278 (NTL RR there; libquadmath here), tables HP:378-389.
+ * out: [n][2] (re, im) */
+#include <quadmath.h>
+static u128 hp_round64(__float128 x) { /* RoundToZZ(x * 2^64) in Real96 encoding */
+    const __float128 r = rintq(ldexpq(x, 64));
+    return (u128)(__int128)r;
+}
+void orc_hp_twiddles(int n, unsigned __int128 *powomega, unsigned __int128 *powombar) {
+    for (int i = 0; i < n; i++) {
+        const __float128 ang = 2 * M_PIq * (__float128)i / (__float128)n;
+        const int ib = (n - i) % n;
+        const __float128 angb = 2 * M_PIq * (__float128)ib / (__float128)n;
+        const u128 c = (i == 0) ? (u128)UINT64_MAX : hp_round64(cosq(ang));
+        const u128 s = (i == n / 4) ? (u128)UINT64_MAX : hp_round64(sinq(ang));
+        const u128 sb = (ib == n / 4) ? (u128)UINT64_MAX : hp_round64(sinq(angb));
+        if (powomega) {
+            powomega[2 * i] = c;
+            powomega[2 * i + 1] = s;
+        }
+        if (powombar) {
+            powombar[2 * i] = c;
+            powombar[2 * i + 1] = sb;
+        }
+    }
+}
+
+/* iFFT, HP:391-444: P -> P(omega).  in: N Torus64, out: [N/2][2], n = 2N */
+void orc_hp_ifft(unsigned __int128 *out, const int64_t *in, int N, const unsigned __int128 *powomega) {
+    const int n = 2 * N, ns4 = n / 4;
+    for (int j = 0; j < ns4; j++)
+        hp_cmul(&out[2 * j], &out[2 * j + 1], (u128)(__int128)in[j], (u128)(__int128)in[j + ns4], powomega[2 * j],
+                powomega[2 * j + 1]);
+    for (int nn = ns4; nn >= 2; nn /= 2) {
+        const int halfnn = nn / 2;
+        for (int block = 0; block < ns4; block += nn)
+            for (int off = 0; off < halfnn; off++) {
+                u128 *p1 = out + 2 * (block + off), *p2 = out + 2 * (block + off + halfnn);
+                const u128 t1r = p1[0], t1i = p1[1], t2r = p2[0], t2i = p2[1];
+                const int w = (2 * (ns4 / halfnn) * off) % n;
+                p1[0] = t1r + t2r;
+                p1[1] = t1i + t2i;
+                hp_cmul(&p2[0], &p2[1], t1r - t2r, t1i - t2i, powomega[2 * w], powomega[2 * w + 1]);
+            }
+    }
+}
+/* FFT, HP:446-512: P(omega) -> P, destroys `in`; the final ">> 10" is the reference's hard-coded
+ * division by N/2 for N = 2048 (HP:499-500), kept as log2(N/2) */
+void orc_hp_fft(int64_t *out, unsigned __int128 *in, int N, const unsigned __int128 *powombar) {
+    const int n = 2 * N, ns4 = n / 4;
+    int shift = 0;
+    while ((1 << shift) < ns4) shift++;
+    for (int nn = 2; nn <= ns4; nn *= 2) {
+        const int halfnn = nn / 2;
+        for (int block = 0; block < ns4; block += nn)
+            for (int off = 0; off < halfnn; off++) {
+                u128 *p1 = in + 2 * (block + off), *p2 = in + 2 * (block + off + halfnn);
+                const int w = (2 * (ns4 / halfnn) * off) % n;
+                u128 t2r, t2i;
+                hp_cmul(&t2r, &t2i, p2[0], p2[1], powombar[2 * w], powombar[2 * w + 1]);
+                const u128 t1r = p1[0], t1i = p1[1];
+                p1[0] = t1r + t2r;
+                p1[1] = t1i + t2i;
+                p2[0] = t1r - t2r;
+                p2[1] = t1i - t2i;
+            }
+    }
+    for (int j = 0; j < ns4; j++) {
+        hp_cmul(&in[2 * j], &in[2 * j + 1], in[2 * j], in[2 * j + 1], powombar[2 * j], powombar[2 * j + 1]);
+        out[j] = (int64_t)(uint64_t)(in[2 * j] >> shift);
+        out[j + ns4] = (int64_t)(uint64_t)(in[2 * j + 1] >> shift);
+    }
+}

@@ -227,4 +227,13 @@ void orc_privks_create(int32_t *privks /* [2][n2+1][t][base][2][N1] */, const in
 #ifdef __cplusplus
 }
 #endif
+/* Real96 high-precision anticyclic FFT (high-precision-anticyclic-fft/src/code.cpp): twiddle tables
+ * (:246-278,378-389; [n][2] re, im), iFFT (:391-444), FFT (:446-512).  PARITY UNPINNED: the reference
+ * needs NTL, which this image lacks; checked by properties (tests/test_hp_fft.py). */
+void orc_hp_twiddles(int n, unsigned __int128 *powomega, unsigned __int128 *powombar);
+void orc_hp_ifft(unsigned __int128 *out /* [N/2][2] */, const int64_t *in /* N */, int N,
+                 const unsigned __int128 *powomega /* [2N][2] */);
+void orc_hp_fft(int64_t *out /* N */, unsigned __int128 *in /* [N/2][2], destroyed */, int N,
+                const unsigned __int128 *powombar /* [2N][2] */);
+
 #endif

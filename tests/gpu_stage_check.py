@@ -82,4 +82,9 @@ if max_stage >= 11:
     say("stage 11: exact (FFT-free) external product, Torus32 N=1024 and Torus64 N=2048")
     say("   fp64 vs exact, worst difference:", P.check_exact_extprod(T.DEFAULT_LIB, 32, 1024, 2, 10, B=5, fft_bound=4),
         P.check_exact_extprod(T.DEFAULT_LIB, 64, 2048, 4, 9, B=5, fft_bound=2 ** 32))
+if max_stage >= 12:
+    say("stage 12: Real96 high-precision transforms, N=2048")
+    import test_hp_fft
+    test_hp_fft.check_hp_kernels(T.DEFAULT_LIB, 2048, B=5)
+    say("   ok")
 say("done")

@@ -218,6 +218,31 @@ def extprod32(N, acc, gsw, l, Bgbit):
     return acc
 
 
+def hp_twiddles(n):
+    """Real96 twiddles of the oracle (libquadmath): (powomega, powombar), each [n][4] uint64 = (re.lo, re.hi, im.lo, im.hi)"""
+    a, b = np.empty((n, 4), np.uint64), np.empty((n, 4), np.uint64)
+    lib().orc_hp_twiddles(n, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
+    return a, b
+
+
+def hp_ifft(x, powomega):
+    x = i64(x)
+    N = x.size
+    out = np.empty((N // 2, 4), np.uint64)
+    pw = np.ascontiguousarray(powomega, np.uint64)
+    lib().orc_hp_ifft(out.ctypes.data_as(C.c_void_p), _p(x, C.c_int64), N, pw.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def hp_fft(spec, powombar):
+    spec = np.ascontiguousarray(spec, np.uint64).copy()
+    N = spec.shape[0] * 2
+    out = np.empty(N, np.int64)
+    pw = np.ascontiguousarray(powombar, np.uint64)
+    lib().orc_hp_fft(_p(out, C.c_int64), spec.ctypes.data_as(C.c_void_p), N, pw.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def extprod_exact32(N, acc, gsw_torus, l, Bgbit):
     acc, g = i32(acc).copy(), i32(gsw_torus)
     lib().orc_extprod_exact32(_p(acc, C.c_int32), _p(g, C.c_int32), N, l, Bgbit)

@@ -101,6 +101,17 @@ def bench_fft(T, a):
                                        "algorithmic_bytes_per_launch": algo,
                                        "working_set_MiB": algo / 2 ** 20}})
             print(json.dumps(lines[-1]), flush=True)
+        if N == 2048:  # the Real96 (128-bit fixed point) transforms of the same size: integer-VALU bound
+            spec = eng.alloc(batch * (N // 2) * 32)
+            for name, bytes_per_poly, fn in (
+                    ("Real96 iFFT", N * 8 + N * 16, lambda: eng._chk(lib.tfhe_amd_hp_ifft(eng.ctx, spec.ptr, i64.ptr, batch))),
+                    ("Real96 FFT", N * 16 + N * 8, lambda: eng._chk(lib.tfhe_amd_hp_fft(eng.ctx, o64.ptr, spec.ptr, batch)))):
+                best, mean = timed(eng, a.reps, fn)
+                algo = batch * bytes_per_poly
+                lines.append({"workload": f"{name} N={N} batch={batch}", "ms_min": best, "ms_mean": mean,
+                              "polynomials_per_s": batch / (best * 1e-3),
+                              "hbm": {"achieved_GBps": algo / (best * 1e-3) / 1e9, "frac": algo / (best * 1e-3) / HBM_PEAK}})
+                print(json.dumps(lines[-1]), flush=True)
         eng.close()
     return lines
 
