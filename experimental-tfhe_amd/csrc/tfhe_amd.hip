@@ -72,6 +72,9 @@ int fail(tfhe_amd_ctx *c, int code, const std::string &msg) {
         if (e_ != hipSuccess)                                                                 \
             return fail((c), TFHE_AMD_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+// every entry point that allocates or launches starts here: a process may hold contexts on several
+// GPUs, and HIP allocates on / launches from the calling thread's current device
+#define ENTER(c) HIPCHECK((c), hipSetDevice((c)->device))
 #define REQUIRE(c, cond, msg) \
     do {                      \
         if (!(cond)) return fail((c), TFHE_AMD_ERR_PARAM, msg); \
@@ -552,6 +555,7 @@ int tfhe_amd_sync(tfhe_amd_ctx *c) {
 
 int tfhe_amd_event_create(tfhe_amd_ctx *c, void **event) {
     if (!c || !event) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     hipEvent_t e;
     HIPCHECK(c, hipEventCreate(&e));
     *event = (void *)e;
@@ -589,6 +593,7 @@ int tfhe_amd_malloc(tfhe_amd_ctx *c, void **dptr, size_t bytes) {
 }
 int tfhe_amd_free(tfhe_amd_ctx *c, void *dptr) {
     if (!c) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (dptr) {
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         HIPCHECK(c, hipFree(dptr));
@@ -597,12 +602,14 @@ int tfhe_amd_free(tfhe_amd_ctx *c, void *dptr) {
 }
 int tfhe_amd_memcpy_h2d(tfhe_amd_ctx *c, void *dst_d, const void *src, size_t bytes) {
     if (!c || (!dst_d && bytes) || (!src && bytes)) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     HIPCHECK(c, hipMemcpyAsync(dst_d, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     return TFHE_AMD_OK;
 }
 int tfhe_amd_memcpy_d2h(tfhe_amd_ctx *c, void *dst, const void *src_d, size_t bytes) {
     if (!c || (!dst && bytes) || (!src_d && bytes)) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     HIPCHECK(c, hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     return TFHE_AMD_OK;
@@ -625,6 +632,7 @@ static int gsw_alloc(tfhe_amd_ctx *c, int count, tfhe_amd_gsw **out) {
 
 int tfhe_amd_gsw_from_fft(tfhe_amd_ctx *c, const double *gsw_fft, int count, tfhe_amd_gsw **out) {
     if (!c || !gsw_fft || !out || count < 1) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     const long long rows = (long long)count * 2 * c->p.l * 2;
     const size_t bytes = (size_t)rows * c->p.N * sizeof(double);
     double *tmp = nullptr;
@@ -649,6 +657,7 @@ int tfhe_amd_gsw_from_fft(tfhe_amd_ctx *c, const double *gsw_fft, int count, tfh
 // execute_reverse_torus32/64, written directly in the key layout (k_ifft_batch<PACK>)
 int tfhe_amd_gsw_from_torus_d(tfhe_amd_ctx *c, const void *gsw_torus_d, int count, tfhe_amd_gsw **out) {
     if (!c || !gsw_torus_d || !out || count < 1) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     const long long rows = (long long)count * 2 * c->p.l * 2;
     REQUIRE(c, rows <= 0x7fffffffLL, "too many TGSW samples for one conversion");
     tfhe_amd_gsw *g = nullptr;
@@ -671,6 +680,7 @@ int tfhe_amd_gsw_from_torus_d(tfhe_amd_ctx *c, const void *gsw_torus_d, int coun
 
 int tfhe_amd_gsw_from_torus(tfhe_amd_ctx *c, const void *gsw_torus, int count, tfhe_amd_gsw **out) {
     if (!c || !gsw_torus || !out || count < 1) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     const size_t tbytes = (size_t)count * 2 * c->p.l * 2 * c->p.N * torus_bytes(c);
     void *tor = nullptr;
     HIPCHECK(c, hipMalloc(&tor, tbytes));
@@ -698,6 +708,7 @@ void tfhe_amd_gsw_free(tfhe_amd_gsw *g) {
 
 int tfhe_amd_gsw_export_fft(tfhe_amd_ctx *c, const tfhe_amd_gsw *g, int index, double *out) {
     if (!c || !g || !out || index < 0 || index >= g->count) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     const int N = c->p.N, NC = N / 2, PPL = NC / 64;
     std::vector<double2> h(g->sample_complex);
     HIPCHECK(c, hipMemcpyAsync(h.data(), g->data_d + (size_t)index * g->sample_complex,
@@ -725,6 +736,7 @@ int tfhe_amd_set_bootstrap_key(tfhe_amd_ctx *c, const tfhe_amd_gsw *bk) {
 
 int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *c, const int32_t *ks) {
     if (!c || !ks) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     REQUIRE(c, c->p.ks_t > 0, "context has no key-switch parameters");
     drop_streamed_graph(c);
     const size_t bytes = (size_t)c->p.N * c->p.ks_t * ((size_t)1 << c->p.ks_basebit) * (c->p.ks_n_out + 1) * 4;
@@ -747,26 +759,31 @@ int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *c, const int32_t *ks) {
 // ---- L1
 int tfhe_amd_ifft_int32(tfhe_amd_ctx *c, double *out_d, const int32_t *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     return c->logn == 10 ? launch_ifft_t<int32_t, 10>(c, out_d, in_d, batch) : launch_ifft_t<int32_t, 11>(c, out_d, in_d, batch);
 }
 int tfhe_amd_ifft_torus64(tfhe_amd_ctx *c, double *out_d, const int64_t *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     return c->logn == 10 ? launch_ifft_t<int64_t, 10>(c, out_d, in_d, batch) : launch_ifft_t<int64_t, 11>(c, out_d, in_d, batch);
 }
 int tfhe_amd_fft_torus32(tfhe_amd_ctx *c, int32_t *out_d, const double *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     return c->logn == 10 ? launch_fft_t<int32_t, 10>(c, out_d, in_d, batch) : launch_fft_t<int32_t, 11>(c, out_d, in_d, batch);
 }
 int tfhe_amd_fft_torus64(tfhe_amd_ctx *c, int64_t *out_d, const double *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     return c->logn == 10 ? launch_fft_t<int64_t, 10>(c, out_d, in_d, batch) : launch_fft_t<int64_t, 11>(c, out_d, in_d, batch);
 }
 int tfhe_amd_lagrange_addmul(tfhe_amd_ctx *c, double *res_d, const double *a_d, const double *b_d, int batch, int b_shared) {
     if (!c || !res_d || !a_d || !b_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     const int Ns2 = c->p.N / 2;
     const long long total = (long long)batch * Ns2;
@@ -799,12 +816,14 @@ static int run_steps(tfhe_amd_ctx *c, void *acc_d, const tfhe_amd_gsw *g, int in
 
 int tfhe_amd_extern_mul(tfhe_amd_ctx *c, void *acc_d, const tfhe_amd_gsw *g, int index, int batch) {
     if (!c || !acc_d || !g || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     REQUIRE(c, g->ctx == c && index >= 0 && index < g->count, "bad TGSW handle/index");
     if (batch == 0) return TFHE_AMD_OK;
     return run_steps(c, acc_d, g, index, 1, nullptr, 0, batch, BR_NO_ROTATE);
 }
 int tfhe_amd_mux_rotate(tfhe_amd_ctx *c, void *acc_d, const tfhe_amd_gsw *g, int index, const int32_t *barai_d, int batch) {
     if (!c || !acc_d || !g || !barai_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     REQUIRE(c, g->ctx == c && index >= 0 && index < g->count, "bad TGSW handle/index");
     if (batch == 0) return TFHE_AMD_OK;
     return run_steps(c, acc_d, g, index, 1, barai_d, 1, batch, 0);
@@ -815,6 +834,7 @@ int tfhe_amd_mux_rotate(tfhe_amd_ctx *c, void *acc_d, const tfhe_amd_gsw *g, int
 int tfhe_amd_cmux(tfhe_amd_ctx *c, void *out_d, const tfhe_amd_gsw *g, const int32_t *sel_d, const void *d0_d,
                   const void *d1_d, int batch) {
     if (!c || !out_d || !g || !d0_d || !d1_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     REQUIRE(c, g->ctx == c, "TGSW handle belongs to another context");
     if (batch == 0) return TFHE_AMD_OK;
     return c->p.torus_bits == 32 ? cmux_t<int32_t>(c, out_d, g, sel_d, d0_d, d1_d, batch)
@@ -823,6 +843,7 @@ int tfhe_amd_cmux(tfhe_amd_ctx *c, void *out_d, const tfhe_amd_gsw *g, const int
 
 int tfhe_amd_lut_eval(tfhe_amd_ctx *c, void *lwe_out_d, const tfhe_amd_gsw *bits, int d, const void *lut_d, int batch) {
     if (!c || !lwe_out_d || !bits || !lut_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     REQUIRE(c, bits->ctx == c, "TGSW handle belongs to another context");
     REQUIRE(c, c->p.torus_bits == 32, "LUT evaluation consumes TGSW32 samples (circuit-bootstrap outputs)");
     REQUIRE(c, d >= 1 && d <= c->logn + 20, "LUT evaluation: 1 <= d <= log2(N) + 20");
@@ -834,6 +855,7 @@ int tfhe_amd_lut_eval(tfhe_amd_ctx *c, void *lwe_out_d, const tfhe_amd_gsw *bits
 // ---- L3
 int tfhe_amd_blind_rotate(tfhe_amd_ctx *c, void *acc_d, const int32_t *bara_d, int batch) {
     if (!c || !acc_d || !bara_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
     if (batch == 0) return TFHE_AMD_OK;
     return run_steps(c, acc_d, c->bk, 0, c->p.n, bara_d, c->p.n, batch, 0);
@@ -842,6 +864,7 @@ int tfhe_amd_blind_rotate(tfhe_amd_ctx *c, void *acc_d, const int32_t *bara_d, i
 int tfhe_amd_blind_rotate_extract(tfhe_amd_ctx *c, void *lwe_out_d, const void *v_d, int v_per_sample,
                                   const int32_t *rot_d, int batch) {
     if (!c || !lwe_out_d || !v_d || !rot_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
     if (batch == 0) return TFHE_AMD_OK;
     const uint32_t flags = BR_INIT_TESTVEC | BR_EXTRACT;
@@ -869,6 +892,7 @@ int tfhe_amd_blind_rotate_extract(tfhe_amd_ctx *c, void *lwe_out_d, const void *
 
 int tfhe_amd_bootstrap_woks(tfhe_amd_ctx *c, int32_t *lwe_out_d, int32_t mu, const int32_t *x_d, int batch) {
     if (!c || !lwe_out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     REQUIRE(c, c->p.torus_bits == 32, "tfhe_bootstrap_woKS_FFT is a Torus32 operation");
     if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
     if (batch == 0) return TFHE_AMD_OK;
@@ -884,6 +908,7 @@ int tfhe_amd_bootstrap_woks(tfhe_amd_ctx *c, int32_t *lwe_out_d, int32_t mu, con
 
 int tfhe_amd_keyswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (!c->ks_d) return fail(c, TFHE_AMD_ERR_STATE, "no key-switch key");
     if (batch == 0) return TFHE_AMD_OK;
     if (c->ksd_d && !c->ks_force_gather) return launch_ks_tiled(c, out_d, in_d, batch);
@@ -895,6 +920,7 @@ int tfhe_amd_keyswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int
 
 int tfhe_amd_bootstrap(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, const int32_t *x_d, int batch) {
     if (!c || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     int rc = grow(c, &c->ws_lwe, &c->ws_lwe_bytes, (size_t)batch * (c->p.N + 1) * 4);
     if (rc) return rc;
@@ -942,6 +968,7 @@ static int streamed_plain(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, const int
 
 int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, const int32_t *x_d, int batch) {
     if (!c || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     REQUIRE(c, c->p.torus_bits == 32, "Torus32 operation");
     if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
     if (!c->ks_d) return fail(c, TFHE_AMD_ERR_STATE, "no key-switch key");
@@ -991,6 +1018,7 @@ int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, con
 
 int tfhe_amd_bootstrap_host(tfhe_amd_ctx *c, int32_t *out, int32_t mu, const int32_t *x, int batch) {
     if (!c || !out || !x || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     const size_t bytes = (size_t)batch * (c->p.n + 1) * 4;
     void *in_d = nullptr, *out_d = nullptr;
@@ -1010,6 +1038,7 @@ int tfhe_amd_bootstrap_host(tfhe_amd_ctx *c, int32_t *out, int32_t mu, const int
 
 int tfhe_amd_cb_bootstrap_woks(tfhe_amd_ctx *c, int64_t *lwe_out_d, int64_t mu, const int32_t *abar_d, int batch) {
     if (!c || !lwe_out_d || !abar_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     REQUIRE(c, c->p.torus_bits == 64, "circuitBootstrapWoKS works on Torus64");
     if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
     if (batch == 0) return TFHE_AMD_OK;
@@ -1026,6 +1055,7 @@ int tfhe_amd_cb_bootstrap_woks(tfhe_amd_ctx *c, int64_t *lwe_out_d, int64_t mu, 
 
 int tfhe_amd_modswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *x_d, int batch) {
     if (!c || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     const long long total = (long long)batch * (c->p.n + 1);
     const unsigned blocks = (unsigned)((total + 255) / 256);
@@ -1040,6 +1070,7 @@ int tfhe_amd_modswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *x_d, int 
 // exact external product: the reference's FFT-free backend (poc:285-316, CB/poc_karatsuba.cpp)
 int tfhe_amd_extern_mul_exact(tfhe_amd_ctx *c, void *acc_d, const void *gsw_torus_d, int batch) {
     if (!c || !acc_d || !gsw_torus_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     if (c->p.torus_bits == 32)
         return c->logn == 10 ? launch_exact_t<int32_t, 10>(c, acc_d, gsw_torus_d, batch)
@@ -1062,6 +1093,7 @@ static int hp_prepare(tfhe_amd_ctx *c) {
 }
 int tfhe_amd_hp_ifft(tfhe_amd_ctx *c, uint64_t *out_d, const int64_t *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     if (int rc = hp_prepare(c)) return rc;
     const HpCplx *pw = (const HpCplx *)c->hp_tw_d;
@@ -1074,6 +1106,7 @@ int tfhe_amd_hp_ifft(tfhe_amd_ctx *c, uint64_t *out_d, const int64_t *in_d, int 
 }
 int tfhe_amd_hp_fft(tfhe_amd_ctx *c, int64_t *out_d, const uint64_t *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
     if (int rc = hp_prepare(c)) return rc;
     const HpCplx *pwbar = (const HpCplx *)c->hp_tw_d + 2 * c->p.N;
@@ -1227,6 +1260,7 @@ int tfhe_amd_cb_load_bk_fft(tfhe_amd_cb *cb, const double *bkfft) {
 }
 int tfhe_amd_cb_load_privks_plane(tfhe_amd_cb *cb, int u, const int32_t *plane) {
     if (!cb || !plane || u < 0 || u > 1) return TFHE_AMD_ERR_PARAM;
+    if (hipSetDevice(cb->c2->device) != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "hipSetDevice");
     const size_t bytes = (size_t)(cb->p.N2 + 1) * cb->p.t21 * ((size_t)1 << cb->p.bb21) * 2 * cb->p.N1 * 4;
     tfhe_amd_ctx *c = cb->c2;
     if (!cb->privks_d[u] && hipMalloc((void **)&cb->privks_d[u], bytes) != hipSuccess)
@@ -1239,6 +1273,7 @@ int tfhe_amd_cb_load_privks_plane(tfhe_amd_cb *cb, int u, const int32_t *plane) 
 
 int tfhe_amd_privks(tfhe_amd_cb *cb, int32_t *out_d, int u, const int64_t *x_d, int batch) {
     if (!cb || !out_d || !x_d || u < 0 || u > 1 || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (hipSetDevice(cb->c2->device) != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "hipSetDevice");
     if (!cb->privks_d[u]) return cb_fail(cb, TFHE_AMD_ERR_STATE, "privKS plane not loaded");
     if (batch == 0) return TFHE_AMD_OK;
     const long long row = 2LL * cb->p.N1;
@@ -1249,6 +1284,7 @@ int tfhe_amd_privks(tfhe_amd_cb *cb, int32_t *out_d, int u, const int64_t *x_d, 
 
 int tfhe_amd_circuit_bootstrap(tfhe_amd_cb *cb, int32_t *out_d, const int32_t *x_d, int batch) {
     if (!cb || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    if (hipSetDevice(cb->c2->device) != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "hipSetDevice");
     if (!cb->bk || !cb->privks_d[0] || !cb->privks_d[1] || !cb->c10->ks_d)
         return cb_fail(cb, TFHE_AMD_ERR_STATE, "preKS, bk and both privKS planes must be loaded");
     if (batch == 0) return TFHE_AMD_OK;
