@@ -657,16 +657,26 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
                 r1[q][m] = (U)Torus<T>::from_double(fi[q][m]);
             }
     }
+    // (the wave-uniform `rotate` test sits outside the unrolled loops: inside them hipcc keeps one
+    // scalar branch pair per store)
+    if (rotate) {
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        T *p = w.acc + q * N;
+        for (int q = 0; q < 2; q++) {
+            T *p = w.acc + q * N;
 #pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            const int j = G::jA(t, m);
-            if (rotate) {
+            for (int m = 0; m < PPL; m++) {
+                const int j = G::jA(t, m);
                 p[j] = (T)((U)p[j] + r0[q][m]);
                 p[j + NC] = (T)((U)p[j + NC] + r1[q][m]);
-            } else {
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            T *p = w.acc + q * N;
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                const int j = G::jA(t, m);
                 p[j] = (T)r0[q][m];
                 p[j + NC] = (T)r1[q][m];
             }
