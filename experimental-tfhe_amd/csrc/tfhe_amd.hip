@@ -165,13 +165,13 @@ int set_lds(tfhe_amd_ctx *c, KernelT kernel, size_t bytes) {
 }
 
 // one instantiation per (torus, N): waves per workgroup chosen so LDS fits 160 KiB
-template <typename T, int LOGN, int WAVES, int PAIR, bool TWREG = false>
+template <typename T, int LOGN, int WAVES, int PAIR, bool TWREG = false, int LC = 0>
 int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
     using Lds = BlindRotateLds<T, LOGN, WAVES, TWREG>;
-    auto kernel = k_blind_rotate<T, LOGN, WAVES, PAIR, TWREG>;
+    auto kernel = k_blind_rotate<T, LOGN, WAVES, PAIR, TWREG, LC>;
     if (int rc = set_lds(c, kernel, Lds::total)) return rc;
     const int blocks = (a.batch + WAVES - 1) / WAVES;
-    TFHE_LAUNCH((k_blind_rotate<T, LOGN, WAVES, PAIR, TWREG>), dim3(blocks), dim3(WAVES * 64), Lds::total, c->stream, a);
+    TFHE_LAUNCH((k_blind_rotate<T, LOGN, WAVES, PAIR, TWREG, LC>), dim3(blocks), dim3(WAVES * 64), Lds::total, c->stream, a);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
@@ -179,6 +179,12 @@ int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
     // N=1024/Torus32: 2 waves per SIMD (256 VGPRs): digits in pairs.  PPL=16 shapes transform
     // one digit at a time (a pair would need 128 more registers than the file has).
     if (c->logn == 11) return launch_br_t<int32_t, 11, 4, 1>(c, a);
+    if (c->p.l == 2)  // the gate set (and the circuit bootstrap's output gadget): gadget length fixed at compile time
+        switch (c->br_variant) {
+            case 1: return launch_br_t<int32_t, 10, 4, 2, true, 2>(c, a);
+            case 2: return launch_br_t<int32_t, 10, 8, 1, false, 2>(c, a);
+            default: return launch_br_t<int32_t, 10, 8, 2, false, 2>(c, a);
+        }
     switch (c->br_variant) {  // schedules of the same arithmetic (TFHE_AMD_OPT_BR_VARIANT), identical results
         case 1: return launch_br_t<int32_t, 10, 4, 2, true>(c, a);  // 1 wave/SIMD, twiddles in registers
         case 2: return launch_br_t<int32_t, 10, 8, 1>(c, a);        // digits one at a time

@@ -578,7 +578,9 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN, TW> &w, const double2 *_
 // The 2l inverse transforms run one at a time (their key row is prefetched into registers
 // under the transform); the two forward transforms run together, in place on the Fourier
 // accumulator, sharing every twiddle read.
-template <typename T, int LOGN, int PAIR, class TW>
+// LC: the gadget length when it is known at compile time (0: read gd.l) -- the gate set's l = 2 with
+// digits in pairs then has one transform group per polynomial and no odd-digit path in the loop body.
+template <typename T, int LOGN, int PAIR, class TW, int LC = 0>
 TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
                            const Gadget &gd, int t) {
     using G = Geom<LOGN>;
@@ -596,7 +598,8 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
     // coefficients are re-read from LDS for every group instead of being kept across groups:
     // they then die at the digit extraction, which is what lets the transform pair + key row +
     // Fourier accumulator fit the register file; for l == PAIR (the gate set) nothing is read twice.
-    const int groups = (gd.l + PAIR - 1) / PAIR;
+    const int l = LC ? LC : gd.l;
+    const int groups = (l + PAIR - 1) / PAIR;
 #pragma unroll 1
     for (int g = 0; g < 2 * groups; g++) {
         const int q = (g >= groups) ? 1 : 0;
@@ -608,7 +611,10 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
 #else
         if (rotate) {
 #endif
-            const int base = (t - a) & (2 * N - 1);
+            int base = (t - a) & (2 * N - 1);
+            // recomputed in every group on purpose: hoisted out of the loop, the 4*PPL source indices
+            // and sign masks outlive the transforms and are spilled
+            TFHE_OPAQUE(base);
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 lo[m] = (rot_minus_one_hoisted<T, LOGN>(p, base, 64 * m, t) + offset) ^ flip;
@@ -623,10 +629,10 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
             }
         }
         // p = bloc*l + i  (tgsw_functions.cpp:435-443); a trailing odd digit goes alone
-        if (PAIR == 2 && d + 1 < gd.l) {
-            ifft_mac_digits<T, LOGN, 2, TW>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
+        if (PAIR == 2 && ((LC && LC % 2 == 0) || d + 1 < l)) {
+            ifft_mac_digits<T, LOGN, 2, TW>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         } else {
-            ifft_mac_digits<T, LOGN, 1, TW>(w, bkrow, q * gd.l + d, d, lo, hi, gd, fr, fi, t);
+            ifft_mac_digits<T, LOGN, 1, TW>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         }
     }
     // back to coefficients (both polynomials together), round, accumulate into acc
@@ -757,7 +763,7 @@ struct BlindRotateLds {
 #define TFHE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
-template <typename T, int LOGN, int WAVES, int PAIR, bool TWREG>
+template <typename T, int LOGN, int WAVES, int PAIR, bool TWREG, int LC = 0>
 TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T> A) {
     using G = Geom<LOGN>;
     using U = typename Torus<T>::U;
@@ -842,7 +848,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             a = TFHE_UNIFORM(a);
             if (a == 0) continue;  // :348-350
         }
-        cmux_step<T, LOGN, PAIR, TW>(w, bkrow, a, rotate, A.gd, t);
+        cmux_step<T, LOGN, PAIR, TW, LC>(w, bkrow, a, rotate, A.gd, t);
     }
 
     // ---- output
