@@ -864,15 +864,23 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
         const size_t item = A.cmux_period ? (size_t)(ct % A.cmux_period) : (size_t)ct;
         const T *d0 = A.cmux_d0 + item * A.cmux_stride;
         T *dst = A.acc_io + (size_t)ct * 2 * N;
+        // every d0 value is loaded before the first store: dst may alias d0/d1, and with loads and
+        // stores interleaved the compiler has to wait for each load (one L2 round trip per element)
         if (A.flags & BR_CMUX_TRIVIAL) {
+            U v[2 * PPL];
+#pragma unroll
+            for (int m = 0; m < 2 * PPL; m++) v[m] = (U)d0[t + 64 * m];
 #pragma unroll
             for (int m = 0; m < 2 * PPL; m++) {
                 dst[t + 64 * m] = w.acc[t + 64 * m];
-                dst[N + t + 64 * m] = (T)((U)w.acc[N + t + 64 * m] + (U)d0[t + 64 * m]);
+                dst[N + t + 64 * m] = (T)((U)w.acc[N + t + 64 * m] + v[m]);
             }
         } else {
+            U v[4 * PPL];
 #pragma unroll
-            for (int m = 0; m < 4 * PPL; m++) dst[t + 64 * m] = (T)((U)w.acc[t + 64 * m] + (U)d0[t + 64 * m]);
+            for (int m = 0; m < 4 * PPL; m++) v[m] = (U)d0[t + 64 * m];
+#pragma unroll
+            for (int m = 0; m < 4 * PPL; m++) dst[t + 64 * m] = (T)((U)w.acc[t + 64 * m] + v[m]);
         }
     } else {
         T *dst = A.acc_io + (size_t)ct * 2 * N;
