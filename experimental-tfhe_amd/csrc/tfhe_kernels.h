@@ -72,11 +72,12 @@ struct Geom {
     TFHE_HOST_DEVICE static int idx2(int j) { return j + (j >> R); }
     // padded index of register m relative to register 0 of the same lane, for the four
     // (map, padding) pairs the transposes read with; independent of the lane (compile-time)
-    enum ReadMap { RD_A1 = 0, RD_B1 = 1, RD_B2 = 2, RD_C2 = 3 };
+    enum ReadMap { RD_A1 = 0, RD_B1 = 1, RD_B2 = 2, RD_C2 = 3, RD_A2 = 4 };
     TFHE_HOST_DEVICE static constexpr int roff(int map, int m) {
         return map == RD_A1 ? m * (64 + (1 << CB))                 // idx1(jA): t + 64m + (m << CB)
              : map == RD_B1 ? (m << CB)                            // idx1(jB)
              : map == RD_B2 ? (m << CB) + ((m << CB) >> R)         // idx2(jB): 9m (N=1024), 4m + (m>>2) (N=2048)
+             : map == RD_A2 ? m * (64 + (64 >> R))                 // idx2(jA): t + 64m + ((t + 64m) >> R)
                             : m;                                   // idx2(jC)
     }
 };
@@ -910,19 +911,29 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     constexpr int N = G::N, NC = G::NC, PPL = G::PPL;
     TFHE_DYN_LDS(smem);
     double2 *tw = reinterpret_cast<double2 *>(smem);
-    for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = twg[i];
-    __syncthreads();
     const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
     const int t = threadIdx.x & 63;
     const int b = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
-    if (b >= batch) return;
+    const bool live = b < batch;
+    // the polynomial's loads are issued BEFORE the twiddle table is staged, so that their HBM latency
+    // runs under the staging instead of after the barrier (a ragged last workgroup re-reads the last
+    // polynomial: every wave must reach the barrier)
+    const TIN *p = in + (size_t)(live ? b : batch - 1) * N;
+    TIN raw_r[PPL], raw_i[PPL];
+#pragma unroll
+    for (int m = 0; m < PPL; m++) {
+        raw_r[m] = p[G::jA(t, m)];
+        raw_i[m] = p[G::jA(t, m) + NC];
+    }
+    for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = twg[i];
+    __syncthreads();
+    if (!live) return;
     double *xch = reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH;
-    const TIN *p = in + (size_t)b * N;
     double xr[1][PPL], xi[1][PPL];
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
-        xr[0][m] = (double)p[G::jA(t, m)];
-        xi[0][m] = (double)p[G::jA(t, m) + NC];
+        xr[0][m] = (double)raw_r[m];
+        xi[0][m] = (double)raw_i[m];
     }
     const TwLds<LOGN> twp{tw, t};
     WaveFFT<LOGN>::template ifft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
@@ -933,11 +944,18 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
         for (int m = 0; m < PPL; m++) o[64 * m + t] = make_double2(xr[0][m] * scale, xi[0][m] * scale);
         return;
     }
+    // The reference's order has lane t holding PPL CONSECUTIVE outputs (jC): stored from there, every
+    // store instruction would touch 64 different 128-byte lines.  One more pass through the wave's LDS
+    // buffer turns it into the lane-contiguous order jA, 512 contiguous bytes per store instruction.
+    auto wC = [&](int m) { return G::idx2(G::jC(t, m)); };
+    auto rA = [&](int m) { return G::idx2(G::jA(t, m)); };
+    WaveFFT<LOGN>::template transpose<G::RD_A2>(xr[0], xch, wC, rA);
+    WaveFFT<LOGN>::template transpose<G::RD_A2>(xi[0], xch, wC, rA);
     double *o = out + (size_t)b * N;
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
-        o[G::jC(t, m)] = xr[0][m];
-        o[G::jC(t, m) + NC] = xi[0][m];
+        o[G::jA(t, m)] = xr[0][m];
+        o[G::jA(t, m) + NC] = xi[0][m];
     }
 }
 
@@ -949,21 +967,34 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     constexpr int N = G::N, NC = G::NC, PPL = G::PPL;
     TFHE_DYN_LDS(smem);
     double2 *tw = reinterpret_cast<double2 *>(smem);
-    for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = twg[i];
-    __syncthreads();
     const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
     const int t = threadIdx.x & 63;
     const int b = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
-    if (b >= batch) return;
-    double *xch = reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH;
-    const double *p = in + (size_t)b * N;
+    const bool live = b < batch;
+    // loads first (lane-contiguous order jA: 512 contiguous bytes per instruction), then the twiddle
+    // staging and its barrier run under their latency; see k_ifft_batch
+    const double *p = in + (size_t)(live ? b : batch - 1) * N;
     const double scale = 2.0 / (double)N;  // fft_processor_spqlios.cpp:78
     double xr[1][PPL], xi[1][PPL];
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
-        xr[0][m] = p[G::jC(t, m)] * scale;
-        xi[0][m] = p[G::jC(t, m) + NC] * scale;
+        xr[0][m] = p[G::jA(t, m)];
+        xi[0][m] = p[G::jA(t, m) + NC];
     }
+    for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = twg[i];
+    __syncthreads();
+    if (!live) return;
+    double *xch = reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH;
+#pragma unroll
+    for (int m = 0; m < PPL; m++) {
+        xr[0][m] *= scale;
+        xi[0][m] *= scale;
+    }
+    // into the transform's input order (lane t holds the PPL consecutive points jC) through LDS
+    auto wA = [&](int m) { return G::idx2(G::jA(t, m)); };
+    auto rC = [&](int m) { return G::idx2(G::jC(t, m)); };
+    WaveFFT<LOGN>::template transpose<G::RD_C2>(xr[0], xch, wA, rC);
+    WaveFFT<LOGN>::template transpose<G::RD_C2>(xi[0], xch, wA, rC);
     const TwLds<LOGN> twp{tw, t};
     WaveFFT<LOGN>::template fft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
     TOUT *o = out + (size_t)b * N;
