@@ -1159,29 +1159,32 @@ int cb_pass(tfhe_amd_cb *cb, tfhe_amd_ctx *c, int rc) {
     if (rc && cb) cb->err = c->err;
     return rc;
 }
+// `count` samples in groups of `group`: sample s goes to out + (s % group)*stride_in_group + (s / group)*stride_of_group
 template <int BB>
-int launch_privks_t(tfhe_amd_cb *cb, int32_t *out_d, long long out_stride, const int64_t *x_d, const int32_t *tab,
-                    int batch) {
-    constexpr int TB = (BB == 3) ? 8 : 16;
+int launch_privks_t(tfhe_amd_cb *cb, int32_t *out_d, long long stride_in_group, long long stride_of_group, int group,
+                    const int64_t *x_d, const int32_t *tab, int count) {
+    // samples per tile / ints per thread and pass: see k_privks
+    constexpr int TB = (BB == 3) ? 32 : 16, EPT = (BB == 3) ? 2 : 8;
     tfhe_amd_ctx *c = cb->c2;
     const int n2 = cb->p.N2, row = 2 * cb->p.N1;
-    const int tiles = (batch + TB - 1) / TB;
+    const int tiles = (count + TB - 1) / TB;
     // enough i-slices to fill the chip: ~4 workgroups per CU
     int slices = (1024 + tiles - 1) / tiles;
     if (slices < 1) slices = 1;
     int i_per_block = ((n2 + 1 + slices - 1) / slices + 63) / 64 * 64;
     slices = (n2 + 1 + i_per_block - 1) / i_per_block;
-    TFHE_LAUNCH((k_privks<TB, BB>), dim3(tiles, slices), dim3(256), 0, c->stream, out_d, out_stride, x_d, tab, n2,
-                cb->p.t21, row, batch, i_per_block);
+    TFHE_LAUNCH((k_privks<TB, BB, EPT>), dim3(tiles, slices), dim3(256), 0, c->stream, out_d, stride_in_group,
+                stride_of_group, group, x_d, tab, n2, cb->p.t21, row, count, i_per_block);
     if (hipGetLastError() != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "k_privks launch");
     return TFHE_AMD_OK;
 }
-int launch_privks(tfhe_amd_cb *cb, int32_t *out_d, long long out_stride, int u, const int64_t *x_d, int batch) {
+int launch_privks(tfhe_amd_cb *cb, int32_t *out_d, long long stride_in_group, long long stride_of_group, int group, int u,
+                  const int64_t *x_d, int count) {
     const int32_t *tab = cb->privks_d[u];
     switch (cb->p.bb21) {
-        case 1: return launch_privks_t<1>(cb, out_d, out_stride, x_d, tab, batch);
-        case 2: return launch_privks_t<2>(cb, out_d, out_stride, x_d, tab, batch);
-        default: return launch_privks_t<3>(cb, out_d, out_stride, x_d, tab, batch);
+        case 1: return launch_privks_t<1>(cb, out_d, stride_in_group, stride_of_group, group, x_d, tab, count);
+        case 2: return launch_privks_t<2>(cb, out_d, stride_in_group, stride_of_group, group, x_d, tab, count);
+        default: return launch_privks_t<3>(cb, out_d, stride_in_group, stride_of_group, group, x_d, tab, count);
     }
 }
 }  // namespace
@@ -1285,7 +1288,7 @@ int tfhe_amd_privks(tfhe_amd_cb *cb, int32_t *out_d, int u, const int64_t *x_d, 
     const long long row = 2LL * cb->p.N1;
     if (hipMemsetAsync(out_d, 0, (size_t)batch * row * 4, cb->c2->stream) != hipSuccess)
         return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "memset");
-    return launch_privks(cb, out_d, row, u, x_d, batch);
+    return launch_privks(cb, out_d, row, 0, batch, u, x_d, batch);
 }
 
 int tfhe_amd_circuit_bootstrap(tfhe_amd_cb *cb, int32_t *out_d, const int32_t *x_d, int batch) {
@@ -1298,7 +1301,7 @@ int tfhe_amd_circuit_bootstrap(tfhe_amd_cb *cb, int32_t *out_d, const int32_t *x
     tfhe_amd_ctx *c2 = cb->c2;
     int rc = grow(c2, &cb->ws_pre, &cb->ws_pre_bytes, (size_t)batch * (p.n0 + 1) * 4);
     if (!rc) rc = grow(c2, &cb->ws_abar, &cb->ws_abar_bytes, (size_t)batch * (p.n0 + 1) * 4);
-    if (!rc) rc = grow(c2, &cb->ws_boot, &cb->ws_boot_bytes, (size_t)batch * (p.N2 + 1) * 8);
+    if (!rc) rc = grow(c2, &cb->ws_boot, &cb->ws_boot_bytes, (size_t)p.l1 * batch * (p.N2 + 1) * 8);
     if (rc) return cb_pass(cb, c2, rc);
     // preKeySwitch lvl1 -> lvl0, then preModSwitch to [0, 2*N2)
     rc = cb_pass(cb, cb->c10, tfhe_amd_keyswitch(cb->c10, (int32_t *)cb->ws_pre, x_d, batch));
@@ -1307,12 +1310,18 @@ int tfhe_amd_circuit_bootstrap(tfhe_amd_cb *cb, int32_t *out_d, const int32_t *x
     const long long tlwe = 2LL * p.N1, out_stride = 2LL * p.l1 * tlwe;
     if (hipMemsetAsync(out_d, 0, (size_t)batch * out_stride * 4, c2->stream) != hipSuccess)
         return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "memset");
+    // the l1 blind rotations first (one per gadget level w, outputs kept side by side) ...
+    int64_t *boot = (int64_t *)cb->ws_boot;
+    const size_t boot_level = (size_t)batch * (p.N2 + 1);
     for (int w = 0; w < p.l1 && !rc; w++) {
         const int64_t mu1 = (int64_t)(1ull << (64 - (w + 1) * p.Bgbit1));  // poc:846
-        rc = cb_pass(cb, c2, tfhe_amd_cb_bootstrap_woks(c2, (int64_t *)cb->ws_boot, mu1, (const int32_t *)cb->ws_abar, batch));
-        for (int u = 0; u <= 1 && !rc; u++)  // result->samples[u][w]
-            rc = launch_privks(cb, out_d + ((size_t)u * p.l1 + w) * tlwe, out_stride, u, (const int64_t *)cb->ws_boot, batch);
+        rc = cb_pass(cb, c2, tfhe_amd_cb_bootstrap_woks(c2, boot + w * boot_level, mu1, (const int32_t *)cb->ws_abar, batch));
     }
+    // ... then ONE private key switch per plane u over all l1*batch samples: the 1.3 GB plane is the
+    // cost, and it is streamed once per tile of samples whatever level they belong to.
+    // result->samples[u][w] of input b  <-  sample w*batch + b
+    for (int u = 0; u <= 1 && !rc; u++)
+        rc = launch_privks(cb, out_d + (size_t)u * p.l1 * tlwe, out_stride, tlwe, batch, u, boot, p.l1 * batch);
     return rc;
 }
 

@@ -1359,38 +1359,43 @@ TFHE_GLOBAL void k_pack_ks(int32_t *__restrict__ dst, const int32_t *__restrict_
 // circuitPrivKS (poc:667-698): LWE64 sample of dimension n2 -> TLWE32 sample, through the key
 // privKS[u][i][j][d] (TLWE32 rows of 2*N1 ints, poc:405-419).  Same digit loop as the LWE key
 // switch but on 64-bit coefficients (b included as index n2) and with 8 KB rows, so the key
-// (1.3 GB per u at the PoC parameters) streams from HBM: a workgroup owns a tile of TB samples
-// and a slice of the i range, reads each (i,j) block of base-1 candidate rows once for the whole
-// tile (16-byte loads, 8 ints per thread), and adds its partial sums into the pre-zeroed output
-// with integer atomics (exact and order-independent).
-//   tab: plane u, reference layout [n2+1][t][base][2*N1]; x: [batch][n2+1];
-//   out: sample b at out + b*out_stride, 2*N1 ints, zeroed by the caller
-template <int TB, int BB>
+// (1.3 GB per u at the PoC parameters) streams from HBM and the kernel is bound by how often it
+// has to be streamed: a workgroup owns a tile of TB samples and a slice of the i range and reads
+// each (i,j) block of base-1 candidate rows ONCE for the whole tile.  Reading all base-1 rows for
+// a tile costs as much as gathering one row for each of base-1 samples, so the tile only pays
+// off beyond that: TB = 32 at base 8 (each thread then keeps EPT = 2 ints of the row per pass
+// and a workgroup makes 2*N1/(256*EPT) passes), TB = 16 at base 2 and 4 (EPT = 8, one pass).
+// Partial sums are added into the pre-zeroed output with integer atomics (exact, order-free).
+//   tab: plane u, reference layout [n2+1][t][base][2*N1]; x: [count][n2+1];
+//   out: sample s at out + (s % group) * stride_in_group + (s / group) * stride_of_group, 2*N1 ints
+//        (the circuit bootstrap runs its l1 gadget levels as l1 groups of one launch)
+template <int TB, int BB, int EPT>
 TFHE_GLOBAL void __launch_bounds__(256)
-    k_privks(int32_t *__restrict__ out, long long out_stride, const int64_t *__restrict__ x,
-             const int32_t *__restrict__ tab, int n2, int t, int row_ints, int batch, int i_per_block) {
-    constexpr int NR = (1 << BB) - 1, BASE = 1 << BB;
+    k_privks(int32_t *__restrict__ out, long long stride_in_group, long long stride_of_group, int group,
+             const int64_t *__restrict__ x, const int32_t *__restrict__ tab, int n2, int t, int row_ints, int count,
+             int i_per_block) {
+    constexpr int NR = (1 << BB) - 1, BASE = 1 << BB, SEG = 256 * EPT;
     constexpr uint64_t mask = (uint64_t)BASE - 1;
     const int lane = threadIdx.x & 63;
     const int tile0 = blockIdx.x * TB;
     const int i_begin = blockIdx.y * i_per_block;
     const int i_end = (i_begin + i_per_block < n2 + 1) ? i_begin + i_per_block : n2 + 1;
     const uint64_t prec_offset = 1ull << (64 - (1 + BB * t));
-    // row segments of 2048 ints: thread owns ints [seg*2048 + 8*tid, +8)
-    for (int seg = 0; seg * 2048 < row_ints; seg++) {
-        const int e0 = seg * 2048 + 8 * (int)threadIdx.x;
+    // row segments of SEG ints: thread owns ints [seg*SEG + EPT*tid, +EPT)
+    for (int seg = 0; seg * SEG < row_ints; seg++) {
+        const int e0 = seg * SEG + EPT * (int)threadIdx.x;
         if (e0 >= row_ints) continue;  // (row_ints is a multiple of 8)
-        uint32_t acc[TB][8];
+        uint32_t acc[TB][EPT];
 #pragma unroll
         for (int b = 0; b < TB; b++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[b][e] = 0u;
+            for (int e = 0; e < EPT; e++) acc[b][e] = 0u;
 #pragma unroll 1
         for (int i0 = i_begin; i0 < i_end; i0 += 64) {
             int alo[TB], ahi[TB];  // lane L: x[b][i0+L] + prec_offset (0 => all digits 0)
 #pragma unroll
             for (int b = 0; b < TB; b++) {
-                const bool ok = (tile0 + b < batch) && (i0 + lane < i_end);
+                const bool ok = (tile0 + b < count) && (i0 + lane < i_end);
                 const uint64_t v = ok ? (uint64_t)x[(size_t)(tile0 + b) * (n2 + 1) + i0 + lane] + prec_offset : 0ull;
                 alo[b] = (int)(uint32_t)v;
                 ahi[b] = (int)(uint32_t)(v >> 32);
@@ -1406,11 +1411,11 @@ TFHE_GLOBAL void __launch_bounds__(256)
                 for (int j = 0; j < t; j++) {
                     const int sh = 64 - (j + 1) * BB;
                     const int32_t *rows = tab + (((size_t)(i0 + ii) * t + j) * BASE + 1) * row_ints + e0;
-                    uint32_t r[NR][8];
+                    uint32_t r[NR][EPT];
 #pragma unroll
                     for (int d = 0; d < NR; d++)
 #pragma unroll
-                        for (int e = 0; e < 8; e++) r[d][e] = (uint32_t)rows[(size_t)d * row_ints + e];
+                        for (int e = 0; e < EPT; e++) r[d][e] = (uint32_t)rows[(size_t)d * row_ints + e];
 #pragma unroll
                     for (int b = 0; b < TB; b++) {
                         const uint32_t dig = (uint32_t)((ab[b] >> sh) & mask);  // wave-uniform
@@ -1420,7 +1425,7 @@ TFHE_GLOBAL void __launch_bounds__(256)
                             if (dig == (uint32_t)(d + 1)) {
                                 TFHE_KEEP_BRANCH();
 #pragma unroll
-                                for (int e = 0; e < 8; e++) acc[b][e] -= r[d][e];
+                                for (int e = 0; e < EPT; e++) acc[b][e] -= r[d][e];
                             }
                         }
                     }
@@ -1429,10 +1434,12 @@ TFHE_GLOBAL void __launch_bounds__(256)
         }
 #pragma unroll
         for (int b = 0; b < TB; b++) {
-            if (tile0 + b >= batch) continue;
-            uint32_t *o = reinterpret_cast<uint32_t *>(out) + (size_t)(tile0 + b) * out_stride + e0;
+            const int s = tile0 + b;
+            if (s >= count) continue;
+            uint32_t *o = reinterpret_cast<uint32_t *>(out) + (size_t)(s % group) * stride_in_group +
+                          (size_t)(s / group) * stride_of_group + e0;
 #pragma unroll
-            for (int e = 0; e < 8; e++)
+            for (int e = 0; e < EPT; e++)
                 if (acc[b][e]) atomicAdd(&o[e], acc[b][e]);
         }
     }

@@ -150,11 +150,11 @@ def bench_cb(T, a):
         "preKeySwitch": lambda: cb._chk(lib.tfhe_amd_keyswitch(c10, d_pre, d_x, B)),
         "preModSwitch": lambda: cb._chk(lib.tfhe_amd_modswitch(c2, d_abar, d_pre, B)),
         "circuitBootstrapWoKS (one of l1)": lambda: cb._chk(lib.tfhe_amd_cb_bootstrap_woks(c2, d_boot, 1 << 55, d_abar, B)),
-        "circuitPrivKS (one of 2*l1)": lambda: cb._chk(lib.tfhe_amd_privks(cb.cb, d_row, 0, d_boot, B)),
+        "circuitPrivKS (one plane, batch samples; the pipeline runs 2 launches of l1*batch)": lambda: cb._chk(lib.tfhe_amd_privks(cb.cb, d_row, 0, d_boot, B)),
     }
     line["stages_ms"] = {k: timed(ev, a.reps, f)[0] for k, f in stages.items()}
     plane_bytes = (N2 + 1) * t21 * (1 << bb21) * 2 * N1 * 4
-    t_priv = line["stages_ms"]["circuitPrivKS (one of 2*l1)"] * 1e-3
+    t_priv = line["stages_ms"]["circuitPrivKS (one plane, batch samples; the pipeline runs 2 launches of l1*batch)"] * 1e-3
     line["privks_hbm"] = {"note": "batch-major: one launch streams one table plane once (SURVEY 8a a19: 2.69 GB in two planes)",
                           "algorithmic_bytes_per_launch": plane_bytes, "achieved_GBps": plane_bytes / t_priv / 1e9,
                           "peak_GBps": HBM_PEAK / 1e9, "frac": plane_bytes / t_priv / HBM_PEAK}
