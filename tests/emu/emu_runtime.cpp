@@ -30,7 +30,9 @@ struct Fiber {
     unsigned tid = 0;
 };
 struct Block {
-    std::vector<int> lane_xchg;  // per work-item slot for readlane
+    std::vector<int> lane_xchg;  // readlane: two slots per work-item, used alternately (one fence per call)
+    std::vector<unsigned char> rl_phase;
+    std::vector<int> any_xchg;   // wave_any
     std::vector<Fiber> fibers;
     Rendezvous all;
     std::vector<Rendezvous> waves;
@@ -75,7 +77,9 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
     b.body = &body;
     const unsigned nt = block.x;
     b.fibers.resize(nt);
-    b.lane_xchg.resize(nt);
+    b.lane_xchg.assign((size_t)2 * nt, 0);
+    b.rl_phase.assign(nt, 0);
+    b.any_xchg.assign(nt, 0);
     b.all.expected = (int)nt;
     b.waves.resize((nt + 63) / 64);
     for (unsigned w = 0; w < b.waves.size(); w++) b.waves[w].expected = (int)std::min(64u, nt - 64 * w);
@@ -120,21 +124,22 @@ void wave_fence() { arrive(t_blk->waves[t_threadIdx.x / 64]); }
 unsigned char *dyn_smem() { return t_blk->smem; }
 bool wave_any(bool cond) {
     const unsigned tid = t_threadIdx.x, base = tid & ~63u;
-    t_blk->lane_xchg[tid] = cond ? 1 : 0;
+    t_blk->any_xchg[tid] = cond ? 1 : 0;
     wave_fence();
     bool any = false;
-    const unsigned end = std::min<unsigned>(base + 64, (unsigned)t_blk->lane_xchg.size());
-    for (unsigned i = base; i < end; i++) any |= (t_blk->fibers[i].done ? false : t_blk->lane_xchg[i] != 0);
+    const unsigned end = std::min<unsigned>(base + 64, (unsigned)t_blk->any_xchg.size());
+    for (unsigned i = base; i < end; i++) any |= (t_blk->fibers[i].done ? false : t_blk->any_xchg[i] != 0);
     wave_fence();
     return any;
 }
+// Two slot arrays used alternately: a lane can reach call k+2 (same slots as call k) only after the
+// fence of call k+1, which every lane passes only once it has finished reading the slots of call k.
 int readlane(int v, int lane) {
     const unsigned tid = t_threadIdx.x;
-    t_blk->lane_xchg[tid] = v;
+    const size_t nt = t_blk->rl_phase.size(), buf = (t_blk->rl_phase[tid]++ & 1u) * nt;
+    t_blk->lane_xchg[buf + tid] = v;
     wave_fence();
-    const int r = t_blk->lane_xchg[(tid & ~63u) + (unsigned)lane];
-    wave_fence();
-    return r;
+    return t_blk->lane_xchg[buf + (tid & ~63u) + (unsigned)lane];
 }
 
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes) {

@@ -77,8 +77,10 @@ def test_lut_eval_poc_gadget_emu(emu_lib):
 
 
 def test_circuit_bootstrap_emu(emu_lib):
-    # N2 = 2048, l2 = 4, Bgbit2 = 9, privKS base 8 as in the PoC; short n0 / key-switch lengths
-    P.check_circuit_bootstrap(emu_lib, n0=2, N1=1024, N2=2048, l1=2, bg1=8, l2=4, bg2=9, t10=3, bb10=2, t21=2,
+    # l2 = 4, Bgbit2 = 9, privKS base 8 as in the PoC; short n0 / key-switch lengths and N2 = 1024 (every
+    # readlane of the 32-sample private-key-switch tile is a fiber rendezvous here; the N2 = 2048 Torus64
+    # path has its own test below, the full pipeline shape runs in the GPU suite)
+    P.check_circuit_bootstrap(emu_lib, n0=2, N1=1024, N2=1024, l1=2, bg1=8, l2=4, bg2=9, t10=3, bb10=2, t21=2,
                               bb21=3, B=2)
 
 
