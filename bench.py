@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--br-variant", type=int, default=0,
                     help="TFHE_AMD_OPT_BR_VARIANT: 0 default schedule, 1 register twiddles (1 wave/SIMD), 2 unpaired digits")
     ap.add_argument("--ks-gather", action="store_true", help="per-sample gather key switch instead of the tiled one")
+    ap.add_argument("--ks-stream", action="store_true",
+                    help="key switch by the streaming kernel (32-sample tiles, global atomics) instead of the tiled one")
     ap.add_argument("--lib", default=None,
                     help="alternative build of the engine library to time (e.g. libtfhe_amd_asmlds.so from "
                          "`build.py --asm-lds`); default: the shipped libtfhe_amd.so")
@@ -132,6 +134,7 @@ def main():
     eng, lib = job.eng, job.eng.lib
     eng.set_option(T.OPT_BR_VARIANT, a.br_variant)
     eng.set_option(T.OPT_KS_GATHER, int(a.ks_gather))
+    eng.set_option(T.OPT_KS_STREAM, int(a.ks_stream))
 
     B = a.batch
     x_host = shard.synthetic_samples(cfg, B, seed=1234 + rank)
@@ -234,7 +237,7 @@ def main():
             "config": {"workload": f"batch {B} gate bootstraps per GPU per step, {cfg.describe()}, persistent "
                                    "blind-rotation kernel + key-switch kernel, inputs resident in HBM",
                        "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, keys replicated",
-                       "br_variant": a.br_variant, "ks_kernel": "gather" if a.ks_gather else "tiled",
+                       "br_variant": a.br_variant, "ks_kernel": "gather" if a.ks_gather else ("stream" if a.ks_stream else "tiled"),
                        "library": os.path.basename(a.lib) if a.lib else "libtfhe_amd.so"},
             "roofline": {"bound": "hbm", "kernel": "k_blind_rotate<int32,N=1024>", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,

@@ -44,6 +44,7 @@ struct tfhe_amd_ctx {
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
     bool ks_force_gather;  // TFHE_AMD_OPT_KS_GATHER: per-sample gather kernel even when the tiled one applies
+    bool ks_stream;        // TFHE_AMD_OPT_KS_STREAM: 64-sample tiles streamed by the private-key-switch kernel
     int br_variant;        // TFHE_AMD_OPT_BR_VARIANT
     int fft_waves;         // TFHE_AMD_OPT_FFT_WAVES
     // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
@@ -303,6 +304,37 @@ int launch_ks_tiled(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int ba
     }
 }
 
+// streamed LWE key switch (TFHE_AMD_OPT_KS_KERNEL = 2): the private-key-switch kernel on the tiled key
+// layout -- 32-sample tiles (the key is read once per 32 samples instead of once per 16), the i range
+// split over workgroups, partial sums added with global integer atomics into the seeded output
+template <int BB>
+int launch_ks_stream_t(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
+    constexpr int TB = 32, EPT = 2, THREADS = 320;  // 5 waves x 64 lanes x 2 ints = the 640-int padded row
+    const int N = c->p.N, n_out = c->p.ks_n_out;
+    const long long total = (long long)batch * (n_out + 1);
+    TFHE_LAUNCH_FLAT(k_ks_seed, dim3((unsigned)((total + 255) / 256)), dim3(256), c->stream, out_d, in_d, N, n_out, total);
+    HIPCHECK(c, hipGetLastError());
+    const int tiles = (batch + TB - 1) / TB;
+    int slices = (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU
+    if (slices > N / 64) slices = N / 64;
+    if (slices < 1) slices = 1;
+    int i_per_block = ((N + slices - 1) / slices + 63) / 64 * 64;
+    slices = (N + i_per_block - 1) / i_per_block;
+    // the kernel's "n2 + 1" inputs are the N mask coefficients here (the b term is the seed)
+    TFHE_LAUNCH((k_privks<int32_t, TB, BB, EPT, THREADS, true>), dim3(tiles, slices), dim3(THREADS), 0, c->stream, out_d,
+                (long long)(n_out + 1), 0LL, batch, in_d, N + 1, (const int32_t *)c->ksd_d, N - 1, c->p.ks_t,
+                ks_nch(n_out) * 128, batch, i_per_block);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+int launch_ks_stream(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
+    switch (c->p.ks_basebit) {
+        case 1: return launch_ks_stream_t<1>(c, out_d, in_d, batch);
+        case 2: return launch_ks_stream_t<2>(c, out_d, in_d, batch);
+        default: return launch_ks_stream_t<3>(c, out_d, in_d, batch);
+    }
+}
+
 // common part of every blind-rotation-shaped call
 template <typename T>
 void fill_common(const tfhe_amd_ctx *c, BlindRotateArgs<T> &a, const tfhe_amd_gsw *g, int index, int steps, int batch) {
@@ -445,6 +477,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") != nullptr;
     c->br_variant = getenv("TFHE_AMD_BR_VARIANT") ? atoi(getenv("TFHE_AMD_BR_VARIANT")) : 0;
     c->fft_waves = 4;
+    c->ks_stream = false;
     c->streamed_graph = false;
     c->streamed_warm = 0;
     memset(&c->sg, 0, sizeof(c->sg));
@@ -540,6 +573,10 @@ int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_KS_GATHER:
             c->ks_force_gather = value != 0;
+            return TFHE_AMD_OK;
+        case TFHE_AMD_OPT_KS_STREAM:
+            c->ks_stream = value != 0;
+            drop_streamed_graph(c);
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_STREAMED_GRAPH:
             c->streamed_graph = value != 0;
@@ -917,7 +954,7 @@ int tfhe_amd_keyswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int
     ENTER(c);
     if (!c->ks_d) return fail(c, TFHE_AMD_ERR_STATE, "no key-switch key");
     if (batch == 0) return TFHE_AMD_OK;
-    if (c->ksd_d && !c->ks_force_gather) return launch_ks_tiled(c, out_d, in_d, batch);
+    if (c->ksd_d && !c->ks_force_gather) return c->ks_stream ? launch_ks_stream(c, out_d, in_d, batch) : launch_ks_tiled(c, out_d, in_d, batch);
     TFHE_LAUNCH_FLAT(k_keyswitch32, dim3(batch), dim3(256), c->stream, out_d, in_d, (const int32_t *)c->ks_d, c->p.N,
                 c->p.ks_n_out, c->p.ks_t, c->p.ks_basebit, batch);
     HIPCHECK(c, hipGetLastError());
@@ -1173,8 +1210,12 @@ int launch_privks_t(tfhe_amd_cb *cb, int32_t *out_d, long long stride_in_group, 
     if (slices < 1) slices = 1;
     int i_per_block = ((n2 + 1 + slices - 1) / slices + 63) / 64 * 64;
     slices = (n2 + 1 + i_per_block - 1) / i_per_block;
-    TFHE_LAUNCH((k_privks<TB, BB, EPT>), dim3(tiles, slices), dim3(256), 0, c->stream, out_d, stride_in_group,
-                stride_of_group, group, x_d, tab, n2, cb->p.t21, row, count, i_per_block);
+    if (cb->p.t21 * BB <= 32)  // all digits in the upper word of each input
+        TFHE_LAUNCH((k_privks<int64_t, TB, BB, EPT, 256, false, true>), dim3(tiles, slices), dim3(256), 0, c->stream, out_d,
+                    stride_in_group, stride_of_group, group, x_d, n2 + 1, tab, n2, cb->p.t21, row, count, i_per_block);
+    else
+        TFHE_LAUNCH((k_privks<int64_t, TB, BB, EPT, 256, false, false>), dim3(tiles, slices), dim3(256), 0, c->stream, out_d,
+                    stride_in_group, stride_of_group, group, x_d, n2 + 1, tab, n2, cb->p.t21, row, count, i_per_block);
     if (hipGetLastError() != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "k_privks launch");
     return TFHE_AMD_OK;
 }

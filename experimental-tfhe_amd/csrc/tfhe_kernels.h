@@ -1366,21 +1366,29 @@ TFHE_GLOBAL void k_pack_ks(int32_t *__restrict__ dst, const int32_t *__restrict_
 // off beyond that: TB = 32 at base 8 (each thread then keeps EPT = 2 ints of the row per pass
 // and a workgroup makes 2*N1/(256*EPT) passes), TB = 16 at base 2 and 4 (EPT = 8, one pass).
 // Partial sums are added into the pre-zeroed output with integer atomics (exact, order-free).
-//   tab: plane u, reference layout [n2+1][t][base][2*N1]; x: [count][n2+1];
+//   tab: plane u, reference layout [n2+1][t][base][2*N1]; x: [count][x_stride], inputs 0..n2 of each row used;
 //   out: sample s at out + (s % group) * stride_in_group + (s / group) * stride_of_group, 2*N1 ints
 //        (the circuit bootstrap runs its l1 gadget levels as l1 groups of one launch)
-template <int TB, int BB, int EPT>
-TFHE_GLOBAL void __launch_bounds__(256)
+// The same kernel serves the LWE key switch of the gate bootstrap (XT = int32_t, PACKED: the tiled
+// key layout [n_in][t][base-1][640] without the digit-0 rows, zero-padded rows) as its "stream"
+// variant: 32-sample tiles, one pass of 5 waves x 2 ints over the 640-int row (each wave repeats the
+// scalar digit work for its 128-int chunk: less key traffic than k_keyswitch_tiled, more scalar work).
+// HI_ONLY (64-bit inputs): every digit lies in the upper 32 bits (t * basebit <= 32, as at the PoC's 10 x 3),
+// so only that word of each input is kept and broadcast: half the scalar registers.
+template <typename XT, int TB, int BB, int EPT, int THREADS, bool PACKED, bool HI_ONLY = false>
+TFHE_GLOBAL void __launch_bounds__(THREADS)
     k_privks(int32_t *__restrict__ out, long long stride_in_group, long long stride_of_group, int group,
-             const int64_t *__restrict__ x, const int32_t *__restrict__ tab, int n2, int t, int row_ints, int count,
-             int i_per_block) {
-    constexpr int NR = (1 << BB) - 1, BASE = 1 << BB, SEG = 256 * EPT;
-    constexpr uint64_t mask = (uint64_t)BASE - 1;
+             const XT *__restrict__ x, int x_stride, const int32_t *__restrict__ tab, int n2, int t, int row_ints,
+             int count, int i_per_block) {
+    using UX = typename std::make_unsigned<XT>::type;
+    constexpr int NR = (1 << BB) - 1, BASE = 1 << BB, SEG = THREADS * EPT, W = 8 * (int)sizeof(XT);
+    constexpr int ROWS_PER_BLOCK = PACKED ? NR : BASE, FIRST_ROW = PACKED ? 0 : 1;
+    constexpr UX mask = (UX)BASE - 1;
     const int lane = threadIdx.x & 63;
     const int tile0 = blockIdx.x * TB;
     const int i_begin = blockIdx.y * i_per_block;
     const int i_end = (i_begin + i_per_block < n2 + 1) ? i_begin + i_per_block : n2 + 1;
-    const uint64_t prec_offset = 1ull << (64 - (1 + BB * t));
+    const UX prec_offset = (UX)1 << (W - (1 + BB * t));
     // row segments of SEG ints: thread owns ints [seg*SEG + EPT*tid, +EPT)
     for (int seg = 0; seg * SEG < row_ints; seg++) {
         const int e0 = seg * SEG + EPT * (int)threadIdx.x;
@@ -1392,25 +1400,32 @@ TFHE_GLOBAL void __launch_bounds__(256)
             for (int e = 0; e < EPT; e++) acc[b][e] = 0u;
 #pragma unroll 1
         for (int i0 = i_begin; i0 < i_end; i0 += 64) {
-            int alo[TB], ahi[TB];  // lane L: x[b][i0+L] + prec_offset (0 => all digits 0)
+            // lane L: x[b][i0+L] + prec_offset (0 => all digits 0); the words that carry digits
+            constexpr bool TWO_WORDS = sizeof(XT) == 8 && !HI_ONLY;
+            using AB = typename std::conditional<TWO_WORDS, uint64_t, uint32_t>::type;
+            constexpr int WA = TWO_WORDS ? 64 : 32;
+            int a0[TB], a1[TWO_WORDS ? TB : 1];
 #pragma unroll
             for (int b = 0; b < TB; b++) {
                 const bool ok = (tile0 + b < count) && (i0 + lane < i_end);
-                const uint64_t v = ok ? (uint64_t)x[(size_t)(tile0 + b) * (n2 + 1) + i0 + lane] + prec_offset : 0ull;
-                alo[b] = (int)(uint32_t)v;
-                ahi[b] = (int)(uint32_t)(v >> 32);
+                const UX v = ok ? (UX)((UX)x[(size_t)(tile0 + b) * x_stride + i0 + lane] + prec_offset) : (UX)0;
+                a0[b] = (sizeof(XT) == 8 && HI_ONLY) ? (int)(uint32_t)((uint64_t)v >> 32) : (int)(uint32_t)v;
+                if (TWO_WORDS) a1[TWO_WORDS ? b : 0] = (int)(uint32_t)((uint64_t)v >> 32);
             }
             const int cnt = (i_end - i0 < 64) ? (i_end - i0) : 64;
 #pragma unroll 1
             for (int ii = 0; ii < cnt; ii++) {
-                uint64_t ab[TB];
+                AB ab[TB];
 #pragma unroll
-                for (int b = 0; b < TB; b++)
-                    ab[b] = ((uint64_t)(uint32_t)TFHE_READLANE(ahi[b], ii) << 32) | (uint32_t)TFHE_READLANE(alo[b], ii);
+                for (int b = 0; b < TB; b++) {
+                    uint64_t v = (uint32_t)TFHE_READLANE(a0[b], ii);
+                    if (TWO_WORDS) v |= (uint64_t)(uint32_t)TFHE_READLANE(a1[TWO_WORDS ? b : 0], ii) << 32;
+                    ab[b] = (AB)v;
+                }
 #pragma unroll 1
                 for (int j = 0; j < t; j++) {
-                    const int sh = 64 - (j + 1) * BB;
-                    const int32_t *rows = tab + (((size_t)(i0 + ii) * t + j) * BASE + 1) * row_ints + e0;
+                    const int sh = WA - (j + 1) * BB;
+                    const int32_t *rows = tab + (((size_t)(i0 + ii) * t + j) * ROWS_PER_BLOCK + FIRST_ROW) * row_ints + e0;
                     uint32_t r[NR][EPT];
 #pragma unroll
                     for (int d = 0; d < NR; d++)
@@ -1418,7 +1433,7 @@ TFHE_GLOBAL void __launch_bounds__(256)
                         for (int e = 0; e < EPT; e++) r[d][e] = (uint32_t)rows[(size_t)d * row_ints + e];
 #pragma unroll
                     for (int b = 0; b < TB; b++) {
-                        const uint32_t dig = (uint32_t)((ab[b] >> sh) & mask);  // wave-uniform
+                        const uint32_t dig = (uint32_t)((ab[b] >> sh) & (AB)mask);  // wave-uniform
                         if (dig == 0) continue;
 #pragma unroll
                         for (int d = 0; d < NR; d++) {
@@ -1443,6 +1458,14 @@ TFHE_GLOBAL void __launch_bounds__(256)
                 if (acc[b][e]) atomicAdd(&o[e], acc[b][e]);
         }
     }
+}
+// seeds the output of the streamed LWE key switch: (0, ..., 0, b)   (lweNoiselessTrivial, lwe_functions.cpp:141)
+TFHE_GLOBAL void k_ks_seed(int32_t *__restrict__ out, const int32_t *__restrict__ in, int n_in, int n_out, long long total) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const long long b = gid / (n_out + 1);
+    const int h = (int)(gid - b * (n_out + 1));
+    out[gid] = (h == n_out) ? in[b * (n_in + 1) + n_in] : 0;
 }
 
 }  // namespace tfhe

@@ -414,5 +414,9 @@ def check_keyswitch_shapes(lib_path, N, n_out, ks_t, ks_bb, B, seed=51):
         for force_gather in (0, 1):
             e.set_option(T.OPT_KS_GATHER, force_gather)
             assert np.array_equal(e.keyswitch(x), want), f"key switch (gather={force_gather})"
+        e.set_option(T.OPT_KS_GATHER, 0)
+        e.set_option(T.OPT_KS_STREAM, 1)   # 64-sample tiles through the private-key-switch kernel
+        assert np.array_equal(e.keyswitch(x), want), "key switch (stream)"
+        assert np.array_equal(e.keyswitch(x[:1]), want[:1]), "key switch (stream), one sample"
     finally:
         e.close()

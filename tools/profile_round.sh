@@ -37,6 +37,10 @@ except Exception as e:
 PY
 done
 
+echo "== bench, key switch by the streaming kernel" | tee -a "$OUT/log.txt"
+timeout 300 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --ks-stream > "$OUT/bench_ksstream.json" 2> "$OUT/bench_ksstream.err"
+tail -c 300 "$OUT/bench_ksstream.json" | tee -a "$OUT/log.txt"
+
 echo "== experiment build: hand-placed ds_read_b64 in the transposes (parity first, then timing)" | tee -a "$OUT/log.txt"
 TFHE_AMD_TEST_LIB=experimental-tfhe_amd/libtfhe_amd_asmlds.so timeout 300 python3 tests/gpu_stage_check.py 4 2>&1 | tail -4 | tee -a "$OUT/log.txt"
 timeout 300 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --lib experimental-tfhe_amd/libtfhe_amd_asmlds.so \
