@@ -1285,45 +1285,79 @@ TFHE_GLOBAL void __launch_bounds__(SPLIT * 64)
     for (int i0 = i_begin; i0 < i_end; i0 += 64) {
         int avec[TB];  // lane L: a[i0+L] + prec_offset of sample b (0 => all digits 0)
 #pragma unroll
+        for (int b = 0; b < TB; b++) {  // unconditional loads from clamped addresses, all issued ...
+            const int bs = (tile0 + b < batch) ? tile0 + b : batch - 1, li = (i0 + lane < n_in) ? i0 + lane : n_in - 1;
+            avec[b] = in[(size_t)bs * (n_in + 1) + li];
+        }
+#pragma unroll
+        for (int b = 0; b < TB; b++) TFHE_OPAQUE(avec[b]);  // ... before the first one is waited for
+#pragma unroll
         for (int b = 0; b < TB; b++) {
             const bool ok = (tile0 + b < batch) && (i0 + lane < n_in);
-            avec[b] = ok ? (int)((uint32_t)in[(size_t)(tile0 + b) * (n_in + 1) + i0 + lane] + prec_offset) : 0;
+            avec[b] = ok ? (int)((uint32_t)avec[b] + prec_offset) : 0;
         }
         const int cnt = (i_end - i0 < 64) ? (i_end - i0) : 64;
-#pragma unroll 1
-        for (int ii = 0; ii < cnt; ii++) {
-            uint32_t ab[TB];
+        // one flat loop over (ii, j): the key blocks of consecutive (i, j) are contiguous, and the rows
+        // of step q+1 are requested before the rows of step q are consumed, so that their L2 latency
+        // runs under the digit tests instead of in front of them
+        const int32_t *blk = ksd + (size_t)i0 * t * NR * ROWP;
+        uint32_t rn[NR][NCH][2];
 #pragma unroll
-            for (int b = 0; b < TB; b++) ab[b] = (uint32_t)TFHE_READLANE(avec[b], ii);
+        for (int d = 0; d < NR; d++)
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int32_t *src = blk + d * ROWP + c * 128 + 2 * lane;
+                rn[d][c][0] = (uint32_t)src[0];
+                rn[d][c][1] = (uint32_t)src[1];
+            }
+        uint32_t ab[TB];
+        const int steps = cnt * t;
+        int ii = 0, j = 0;
 #pragma unroll 1
-            for (int j = 0; j < t; j++) {
-                const int sh = 32 - (j + 1) * BB;
-                const int32_t *rows = ksd + ((size_t)(i0 + ii) * t + j) * NR * ROWP;
-                uint32_t r[NR][NCH][2];
+        for (int q = 0; q < steps; q++) {
+            if (j == 0) {
+#pragma unroll
+                for (int b = 0; b < TB; b++) ab[b] = (uint32_t)TFHE_READLANE(avec[b], ii);
+            }
+            uint32_t r[NR][NCH][2];
+#pragma unroll
+            for (int d = 0; d < NR; d++)
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    r[d][c][0] = rn[d][c][0];
+                    r[d][c][1] = rn[d][c][1];
+                }
+            if (q + 1 < steps) {
+                const int32_t *rows = blk + (size_t)(q + 1) * NR * ROWP;
 #pragma unroll
                 for (int d = 0; d < NR; d++)
 #pragma unroll
                     for (int c = 0; c < NCH; c++) {
                         const int32_t *src = rows + d * ROWP + c * 128 + 2 * lane;
-                        r[d][c][0] = (uint32_t)src[0];
-                        r[d][c][1] = (uint32_t)src[1];
+                        rn[d][c][0] = (uint32_t)src[0];
+                        rn[d][c][1] = (uint32_t)src[1];
                     }
+            }
+            const int sh = 32 - (j + 1) * BB;
 #pragma unroll
-                for (int b = 0; b < TB; b++) {
-                    const uint32_t dig = (ab[b] >> sh) & mask;  // wave-uniform (scalar registers)
-                    if (dig == 0) continue;
+            for (int b = 0; b < TB; b++) {
+                const uint32_t dig = (ab[b] >> sh) & mask;  // wave-uniform (scalar registers)
+                if (dig == 0) continue;
 #pragma unroll
-                    for (int d = 0; d < NR; d++) {
-                        if (dig == (uint32_t)(d + 1)) {
-                            TFHE_KEEP_BRANCH();
+                for (int d = 0; d < NR; d++) {
+                    if (dig == (uint32_t)(d + 1)) {
+                        TFHE_KEEP_BRANCH();
 #pragma unroll
-                            for (int c = 0; c < NCH; c++) {
-                                acc[b][c][0] -= r[d][c][0];
-                                acc[b][c][1] -= r[d][c][1];
-                            }
+                        for (int c = 0; c < NCH; c++) {
+                            acc[b][c][0] -= r[d][c][0];
+                            acc[b][c][1] -= r[d][c][1];
                         }
                     }
                 }
+            }
+            if (++j == t) {
+                j = 0;
+                ii++;
             }
         }
     }
@@ -1405,10 +1439,18 @@ TFHE_GLOBAL void __launch_bounds__(THREADS)
             using AB = typename std::conditional<TWO_WORDS, uint64_t, uint32_t>::type;
             constexpr int WA = TWO_WORDS ? 64 : 32;
             int a0[TB], a1[TWO_WORDS ? TB : 1];
+            UX raw[TB];
+#pragma unroll
+            for (int b = 0; b < TB; b++) {  // unconditional loads from clamped addresses, all issued ...
+                const int bs = (tile0 + b < count) ? tile0 + b : count - 1, li = (i0 + lane < i_end) ? i0 + lane : i_end - 1;
+                raw[b] = (UX)x[(size_t)bs * x_stride + li];
+            }
+#pragma unroll
+            for (int b = 0; b < TB; b++) TFHE_OPAQUE(raw[b]);  // ... before the first one is waited for
 #pragma unroll
             for (int b = 0; b < TB; b++) {
                 const bool ok = (tile0 + b < count) && (i0 + lane < i_end);
-                const UX v = ok ? (UX)((UX)x[(size_t)(tile0 + b) * x_stride + i0 + lane] + prec_offset) : (UX)0;
+                const UX v = ok ? (UX)(raw[b] + prec_offset) : (UX)0;
                 a0[b] = (sizeof(XT) == 8 && HI_ONLY) ? (int)(uint32_t)((uint64_t)v >> 32) : (int)(uint32_t)v;
                 if (TWO_WORDS) a1[TWO_WORDS ? b : 0] = (int)(uint32_t)((uint64_t)v >> 32);
             }
@@ -1422,6 +1464,8 @@ TFHE_GLOBAL void __launch_bounds__(THREADS)
                     if (TWO_WORDS) v |= (uint64_t)(uint32_t)TFHE_READLANE(a1[TWO_WORDS ? b : 0], ii) << 32;
                     ab[b] = (AB)v;
                 }
+                // (no software prefetch of the next rows here, unlike k_keyswitch_tiled: it costs this
+                // kernel its third wave per SIMD, which hides the same latency)
 #pragma unroll 1
                 for (int j = 0; j < t; j++) {
                     const int sh = WA - (j + 1) * BB;
