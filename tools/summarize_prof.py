@@ -76,7 +76,8 @@ def main():
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     kernel_stats(root, prefix + "_kernel_stats.txt")
     pmc(root, prefix + "_pmc.txt")
-    for f in glob.glob(os.path.join(root, "bench*.json")) + [os.path.join(root, "log.txt")]:
+    for f in (glob.glob(os.path.join(root, "bench*.json")) + glob.glob(os.path.join(root, "configs*.jsonl")) +
+              [os.path.join(root, "log.txt"), os.path.join(root, "ablate.txt")]):
         if os.path.exists(f):
             shutil.copy(f, prefix + "_" + os.path.basename(f))
     print("wrote", prefix + "_*")
