@@ -217,6 +217,16 @@ def main():
         eng.set_option(T.OPT_STREAMED_GRAPH, 0)
 
     if rank == 0:
+        # HBM bytes per launch of the dominant kernel as measured by the PMC passes of an earlier profile of
+        # this same command (tools/summarize_prof.py -> profiles/traffic.json); null until such a profile exists
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and B == BATCH_PER_GPU and not a.lib:
+            try:
+                tj = json.load(open(tpath))
+                traffic, traffic_src = float(tj["bytes_per_launch"]), tj.get("source")
+            except (ValueError, KeyError):
+                pass
         total = B * world * a.steps
         algo_bytes = B * cfg.n * BYTES_PER_CMUX + cfg.n * BYTES_PER_ROW
         achieved = algo_bytes / (br_ms * 1e-3)
@@ -240,7 +250,7 @@ def main():
                        "br_variant": a.br_variant, "ks_kernel": "gather" if a.ks_gather else ("stream" if a.ks_stream else "tiled"),
                        "library": os.path.basename(a.lib) if a.lib else "libtfhe_amd.so"},
             "roofline": {"bound": "hbm", "kernel": "k_blind_rotate<int32,N=1024>", "achieved": achieved / 1e9,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": br_ms, "algorithmic_bytes_per_launch": algo_bytes,
                          "fp64_valu": {"achieved_tflops": flops / 1e12, "peak_tflops": FP64_PEAK / 1e12,
                                        "frac": flops / FP64_PEAK}},

@@ -71,11 +71,43 @@ def pmc(root, out):
             o.write("\n")
 
 
+def traffic(root, out):
+    """HBM bytes per launch of the blind-rotation kernel from the FETCH_SIZE and WRITE_SIZE passes (KiB units,
+    FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes) -> profiles/traffic.json, which bench.py
+    reports as roofline.traffic (with this file named as the source)"""
+    import json
+    per = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        n, tot = 0, 0.0
+        for d in glob.glob(os.path.join(root, "pmc_" + cname + "*")):
+            for f in find(d, "*counter_collection.csv"):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if "k_blind_rotate" in r.get("Kernel_Name", "") and r.get("Counter_Name") == cname:
+                            try:
+                                tot += float(r["Counter_Value"])
+                                n += 1
+                            except (KeyError, ValueError):
+                                pass
+        if n:
+            per[cname] = tot / n * 1024 * (2 if cname == "FETCH_SIZE" else 1)
+    if len(per) == 2:
+        with open(out, "w") as o:
+            json.dump({"kernel": "k_blind_rotate", "fetch_bytes_per_launch": per["FETCH_SIZE"],
+                       "write_bytes_per_launch": per["WRITE_SIZE"], "bytes_per_launch": per["FETCH_SIZE"] + per["WRITE_SIZE"],
+                       "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes under {root} (bench.py --steps 1 --warmup 0, "
+                                 "default batch), FETCH_SIZE x2 gfx950 correction applied"}, o, indent=1)
+        return True
+    return False
+
+
 def main():
     root, prefix = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     kernel_stats(root, prefix + "_kernel_stats.txt")
     pmc(root, prefix + "_pmc.txt")
+    if traffic(root, os.path.join(os.path.dirname(prefix) or ".", "traffic.json")):
+        print("wrote", os.path.join(os.path.dirname(prefix) or ".", "traffic.json"))
     for f in (glob.glob(os.path.join(root, "bench*.json")) + glob.glob(os.path.join(root, "configs*.jsonl")) +
               [os.path.join(root, "log.txt"), os.path.join(root, "ablate.txt")]):
         if os.path.exists(f):
