@@ -205,8 +205,10 @@ struct WaveFFT {
         for (int m = 0; m < PPL; m++) xch[widx(m)] = x[m];
         TFHE_WAVE_FENCE();
 #if defined(TFHE_LDS_READ_ASM) && !defined(TFHE_EMU)
-        // low 32 bits of a flat pointer into LDS = its LDS byte offset
-        const uint32_t addr = (uint32_t)(uintptr_t)(xch + ridx(0));
+        // LDS byte offset of the first element: an explicit generic -> LDS address-space cast, so the
+        // compiler (not an assumption about the aperture layout) produces the 32-bit DS address
+        typedef __attribute__((address_space(3))) double lds_double;
+        const uint32_t addr = (uint32_t)(uintptr_t)(lds_double *)(xch + ridx(0));
         read8<MAP, 0>(x, addr);
         if (PPL == 16) read8<MAP, (PPL == 16 ? 8 : 0)>(x, addr);
 #else
