@@ -2,7 +2,7 @@
 """Timings for the BASELINE configs that are NOT the bench.py line (run on the GPU box):
 
     python tools/bench_configs.py fft   [--batch 8192] [--reps 5]     BASELINE config 4
-    python tools/bench_configs.py cb    [--batch 256]  [--reps 3]     BASELINE config 3
+    python tools/bench_configs.py cb    [--cb-batch 768] [--reps 3]   BASELINE config 3
     python tools/bench_configs.py all
 
 fft  batched N=2048 transforms through the FFT-plugin entry points: 8,192
@@ -180,7 +180,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["fft", "cb", "all"])
     ap.add_argument("--batch", type=int, default=8192, help="polynomials per launch (fft)")
-    ap.add_argument("--cb-batch", type=int, default=256, help="LWE inputs per circuit-bootstrap launch")
+    ap.add_argument("--cb-batch", type=int, default=768,
+                    help="LWE inputs per circuit-bootstrap launch (default 768 = one Torus64 N=2048 accumulator per wave, "
+                         "3 waves per CU, 256 CUs: the smallest batch that fills the chip)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--fft-waves", type=int, default=4, choices=[4, 8, 12], help="TFHE_AMD_OPT_FFT_WAVES")
     ap.add_argument("--lib", default=None)
