@@ -30,6 +30,11 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The reference's PoC header defines `k` as a macro (`#define k 1`, CB/poc_types.h:10); this header names
+ * a struct field k.  Keep both usable in one translation unit, whichever is included first. */
+#pragma push_macro("k")
+#undef k
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -275,4 +280,5 @@ int tfhe_amd_keygen_ks32(int32_t *ks, const int32_t *in_key, int n_in, const int
 #ifdef __cplusplus
 }
 #endif
+#pragma pop_macro("k")
 #endif /* TFHE_AMD_H */

@@ -40,6 +40,10 @@
 
 #include "tfhe_amd.h"
 
+// see tfhe_amd.h: the PoC's `#define k 1` must not rewrite the library-form field names below
+#pragma push_macro("k")
+#undef k
+
 namespace tfhe_amd_compat {
 
 typedef int32_t Torus32;
@@ -521,4 +525,5 @@ class PocEngine {
 };
 
 }  // namespace tfhe_amd_compat
+#pragma pop_macro("k")
 #endif

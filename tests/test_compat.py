@@ -140,3 +140,13 @@ def test_library_form_shims_gpu(gpu_driver, tmp_path):
 @pytest.mark.gpu
 def test_poc_form_shims_gpu(gpu_driver, tmp_path):
     run_poc_form(gpu_driver, tmp_path, n0=8, N2=2048, l2=4, bg2=9, t21=2, bb21=3, count=2)
+
+
+REF_SRC = "/root/reference/circuit-bootstrapping/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="reference sources not present (GPU box)")
+def test_shims_compile_against_reference_types():
+    """include/tfhe_amd_compat.hpp instantiated on the reference's own poc_types.h (as its Makefile builds it: -DUSE_FFT)"""
+    subprocess.check_call(["g++", "-std=gnu++11", "-DUSE_FFT", "-fsyntax-only", "-I" + REF_SRC, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "compat", "poc_types_check.cpp")])
