@@ -223,10 +223,14 @@ struct WaveFFT {
     // Out: register m = position jC(t,m) of the reference's output order.
     template <int NP, class TW>
     TFHE_DEVICE static void ifft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, double *xch, int t) {
+        // Every twiddle is requested one step before the step that uses it (wn), so that its LDS
+        // latency runs under the previous step's arithmetic instead of in front of its own.
         // twist by omega^j (spqlios-ifft-fma.s:63-78)
+        double2 wn = tw.twist(0);
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
-            const double2 w = tw.twist(m);
+            const double2 w = wn;
+            wn = (m + 1 < PPL) ? tw.twist(m + 1) : tw.passA(PPL / 2, 0);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 const double r = xr[p][m], i = xi[p][m];
@@ -240,7 +244,15 @@ struct WaveFFT {
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 if (m & s) continue;
-                const double2 w = tw.passA(s, m);
+                const double2 w = wn;
+                {   // next butterfly group of this stage, else the first of the next stage
+                    int mn = m + 1;
+                    while (mn < PPL && (mn & s)) mn++;
+                    if (mn < PPL)
+                        wn = tw.passA(s, mn);
+                    else if (s > 1)
+                        wn = tw.passA(s >> 1, 0);
+                }
 #pragma unroll
                 for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], w.x, w.y);
             }
