@@ -401,9 +401,11 @@ struct WaveFFT {
         }
         // final twist by conj(omega^j), four rounded products (spqlios-fft-fma.s:255-274):
         // re' = re*c - im*(-s) = re*c + im*s ; im' = re*(-s) + im*c = im*c - re*s
+        double2 wn = tw.twist(0);  // requested one step ahead, as in ifft
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
-            const double2 w = tw.twist(m);
+            const double2 w = wn;
+            if (m + 1 < PPL) wn = tw.twist(m + 1);
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 const double r = xr[p][m], i = xi[p][m];
