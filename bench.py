@@ -256,6 +256,7 @@ def main():
                                        "frac": flops / FP64_PEAK}},
             "kernels_ms": {"blind_rotate_extract": br_ms, "keyswitch": ks_ms},
             "decrypt_check": bool(ok),
+            "device": T.device_info(local, a.lib),
         }
         if streamed is not None:
             line["streamed_schedule"] = streamed

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_from_torus_d", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
     "tfhe_amd_set_bootstrap_key", "tfhe_amd_load_keyswitch_key",
     "tfhe_amd_ifft_int32", "tfhe_amd_ifft_torus64", "tfhe_amd_fft_torus32", "tfhe_amd_fft_torus64",
-    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_hp_twiddles", "tfhe_amd_hp_ifft", "tfhe_amd_hp_fft",
+    "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_device_info", "tfhe_amd_hp_twiddles", "tfhe_amd_hp_ifft", "tfhe_amd_hp_fft",
     "tfhe_amd_mux_rotate", "tfhe_amd_extern_mul_exact", "tfhe_amd_cmux", "tfhe_amd_lut_eval",
     "tfhe_amd_blind_rotate", "tfhe_amd_blind_rotate_extract", "tfhe_amd_bootstrap_woks",
     "tfhe_amd_keyswitch", "tfhe_amd_bootstrap", "tfhe_amd_bootstrap_streamed", "tfhe_amd_bootstrap_host",
@@ -601,3 +601,11 @@ def hp_twiddles(n, lib_path=None):
     a, b = np.empty((n, 4), np.uint64), np.empty((n, 4), np.uint64)
     assert lib.tfhe_amd_hp_twiddles(n, _np_ptr(a), _np_ptr(b)) == OK
     return a, b
+
+
+def device_info(device=0, lib_path=None):
+    """one-line description of the GPU (tfhe_amd_device_info), or None when there is none"""
+    lib = load_library(lib_path)
+    buf = C.create_string_buffer(512)
+    lib.tfhe_amd_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    return buf.value.decode() if lib.tfhe_amd_device_info(device, buf, 512) == OK else None

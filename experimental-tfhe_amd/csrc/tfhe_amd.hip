@@ -449,6 +449,26 @@ int lut_eval_t(tfhe_amd_ctx *c, void *lwe_out_d, const tfhe_amd_gsw *bits, int d
 // ------------------------------------------------------------------ C ABI
 extern "C" {
 
+int tfhe_amd_device_info(int device, char *buf, size_t len) {
+    if (!buf || len == 0) return TFHE_AMD_ERR_PARAM;
+#ifdef TFHE_EMU
+    (void)device;
+    snprintf(buf, len, "CPU emulation of the kernels (tests/emu), not a device");
+    return TFHE_AMD_OK;
+#else
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return TFHE_AMD_ERR_DEVICE;
+    int rt = 0, drv = 0;
+    (void)hipRuntimeGetVersion(&rt);
+    (void)hipDriverGetVersion(&drv);
+    snprintf(buf, len, "%s (%s), %d CUs, %d MHz, %.1f GiB, LDS/workgroup %zu KiB (opt-in %zu KiB), L2 %d MiB, wave %d, "
+                       "HIP runtime %d driver %d",
+             p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000, (double)p.totalGlobalMem / (1 << 30),
+             p.sharedMemPerBlock >> 10, (size_t)p.sharedMemPerBlockOptin >> 10, p.l2CacheSize >> 20, p.warpSize, rt, drv);
+    return TFHE_AMD_OK;
+#endif
+}
+
 const char *tfhe_amd_version(void) { return "experimental-tfhe_amd 0.1 (gfx950)"; }
 
 int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out) {

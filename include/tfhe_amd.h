@@ -71,6 +71,8 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *params, int device, tfhe_amd_ctx 
 void tfhe_amd_ctx_destroy(tfhe_amd_ctx *ctx);
 const char *tfhe_amd_last_error(const tfhe_amd_ctx *ctx);
 const char *tfhe_amd_version(void);
+/* one-line description of a device (name, gfx target, CUs, clock, memory, LDS limits, runtime version) for logs */
+int tfhe_amd_device_info(int device, char *buf, size_t len);
 /* use an existing hipStream_t (passed as void*); NULL = the context's own stream */
 int tfhe_amd_set_stream(tfhe_amd_ctx *ctx, void *hip_stream);
 int tfhe_amd_sync(tfhe_amd_ctx *ctx);

@@ -25,6 +25,7 @@ def say(*a):
     print(time.strftime("%H:%M:%S"), *a, flush=True)
 
 
+say("device:", T.device_info(0))
 say("stage 1: context + N=1024 ifft of 4 polynomials")
 e = T.Engine(torus_bits=32, n=1, N=1024, l=2, Bgbit=10, ks_t=0)
 rs = np.random.RandomState(0)
