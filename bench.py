@@ -46,6 +46,9 @@ FP64_PEAK = 78.6e12      # flop/s vector fp64 (256 CU x 128 flop/clk x 2.4 GHz)
 BYTES_PER_CMUX = 16388   # acc read+write 16,384 + rotation 4
 BYTES_PER_ROW = 65536    # bootstrapping-key row, once per CMux per launch
 FLOP_PER_CMUX = 173056
+FP64_INSTR_PER_CMUX = 2144  # v_*_f64 wave-instructions per CMux per sample: floor of the bit-exact radix-2 DAG
+FP64_ISSUE_CYCLES = 4       # cycles per wave64 fp64 instruction on one SIMD
+SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 
 
 def cpu_baseline(cfg, seconds=10.0):
@@ -54,6 +57,11 @@ def cpu_baseline(cfg, seconds=10.0):
     # one single-threaded process per core, ~125 MB each (key tables); capped so a many-core host
     # cannot be pushed into memory pressure by a baseline measurement
     cores = min(os.cpu_count() or 1, 64)
+    try:  # never more than a quarter of the free memory, whatever the core count
+        avail_kb = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable"))
+        cores = max(1, min(cores, int(0.25 * avail_kb * 1024 // (130 << 20))))
+    except (OSError, StopIteration, ValueError):
+        cores = min(cores, 8)
     if os.path.exists(ref) and os.access(ref, os.X_OK) and cfg.N == 1024:
         args = [ref, "bench32", "/dev/null", "/dev/null", str(cfg.n), str(cfg.l), str(cfg.Bgbit), str(cfg.ks_t),
                 str(cfg.ks_basebit), str(int(seconds))]
@@ -114,8 +122,23 @@ def main():
     if a.lib is None and not os.path.exists(T.DEFAULT_LIB):
         importlib.import_module("experimental-tfhe_amd.build").build()
     cpu_line = None
+    B = a.batch
+    x_host = shard.synthetic_samples(cfg, B, seed=1234 + rank)
+    nchk = min(16, B)
+    oracle_idx, oracle_want = list(range(nchk, min(nchk + 8, B))), None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu_line = cpu_baseline(cfg, a.cpu_seconds)
+        # the checker's answers for a few of the timed inputs, computed NOW (before the GPU is touched);
+        # compared bit for bit with the GPU's outputs after the timed region
+        if oracle_idx and a.lib is None:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_py as O
+            lk, tk = O.keygen_binary(cfg.n, SEED, 1), O.keygen_binary(cfg.N, SEED, 2)
+            obk = O.bk_create32(cfg.N, lk, tk, cfg.l, cfg.Bgbit, cfg.bk_stdev, SEED, 1000)
+            oks = O.ks_create32(tk, lk, cfg.ks_t, cfg.ks_basebit, cfg.ks_stdev, SEED, 100000)
+            oracle_want = np.stack([O.bootstrap32(cfg.N, obk, oks, 1 << 29, x_host[i], cfg.l, cfg.Bgbit, cfg.ks_t,
+                                                  cfg.ks_basebit) for i in oracle_idx])
+            del obk, oks
 
     dist = None
     if world > 1:
@@ -136,10 +159,7 @@ def main():
     eng.set_option(T.OPT_KS_GATHER, int(a.ks_gather))
     eng.set_option(T.OPT_KS_STREAM, int(a.ks_stream))
 
-    B = a.batch
-    x_host = shard.synthetic_samples(cfg, B, seed=1234 + rank)
     # a few real encryptions at the front: decrypt-checked after the timed region
-    nchk = min(16, B)
     msgs = [(1 << 29) if (i & 1) else -(1 << 29) for i in range(nchk)]
     x_host[:nchk] = job.encrypt(msgs)
     x_d = eng.to_device(x_host)                     # inputs resident in HBM before timing
@@ -178,8 +198,10 @@ def main():
         elapsed = shard.max_over_ranks(elapsed, dev)
 
     # outside the timed region: the real encryptions must decrypt to their sign
-    out = out_d.download(np.int32, (B, cfg.n + 1))[:nchk]
+    out_all = out_d.download(np.int32, (B, cfg.n + 1))
+    out = out_all[:nchk]
     ok = all((job.phase(out[i]) > 0) == (msgs[i] > 0) for i in range(nchk))
+    oracle_ok = None if oracle_want is None else bool(np.array_equal(out_all[oracle_idx], oracle_want))
     br_ms = float(np.mean([eng.elapsed_ms(ev[k][0], ev[k][1]) for k in range(a.steps)]))
     ks_ms = float(np.mean([eng.elapsed_ms(ev[k][1], ev[k][2]) for k in range(a.steps)]))
 
@@ -252,10 +274,17 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_blind_rotate<int32,N=1024>", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": br_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "north-star accounting: bytes of the one-launch-per-CMux schedule; the persistent "
+                                 "kernel keeps the accumulator in LDS and is bound by fp64 issue (fp64_issue below)",
                          "fp64_valu": {"achieved_tflops": flops / 1e12, "peak_tflops": FP64_PEAK / 1e12,
-                                       "frac": flops / FP64_PEAK}},
+                                       "frac": flops / FP64_PEAK},
+                         "fp64_issue": {"cmux_per_s": B * cfg.n / (br_ms * 1e-3),
+                                        "floor_cmux_per_s": SIMDS * CLOCK_HZ / (FP64_INSTR_PER_CMUX * FP64_ISSUE_CYCLES),
+                                        "frac": (B * cfg.n / (br_ms * 1e-3)) /
+                                                (SIMDS * CLOCK_HZ / (FP64_INSTR_PER_CMUX * FP64_ISSUE_CYCLES))}},
             "kernels_ms": {"blind_rotate_extract": br_ms, "keyswitch": ks_ms},
             "decrypt_check": bool(ok),
+            "oracle_bit_check": None if oracle_want is None else {"samples": len(oracle_idx), "identical": oracle_ok},
             "device": T.device_info(local, a.lib),
         }
         if streamed is not None:
@@ -268,6 +297,8 @@ def main():
         dist.destroy_process_group()
     if not ok:
         raise SystemExit("decrypt check failed")
+    if oracle_ok is False:
+        raise SystemExit("GPU outputs differ from the oracle")
 
 
 if __name__ == "__main__":

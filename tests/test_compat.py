@@ -29,7 +29,9 @@ def build_driver(lib_path, tag):
     return out
 
 
-def run_lib_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=2):
+def run_lib_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=2, phase="both"):
+    """phase: "run" = write the inputs and execute the driver; "check" = compare the outputs the
+    driver left in tmp_path with the oracle (no child process); "both" = the two in sequence"""
     rs = np.random.RandomState(7)
     lk, tk = O.keygen_binary(n, SEED, 1), O.keygen_binary(N, SEED, 2)
     bk = O.bk_create32(N, lk, tk, l, Bgbit, 2.0 ** -25, SEED, 1000)
@@ -40,11 +42,14 @@ def run_lib_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=
     acc = rs.randint(-2 ** 31, 2 ** 31, size=(count, 2, N)).astype(np.int32)
     v = rs.randint(-2 ** 31, 2 ** 31, size=N).astype(np.int32)
     hdr = np.array([n, N, l, Bgbit, t, bb, count, mu], np.int32)
-    fi, fo = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
-    with open(fi, "wb") as f:
-        for a in (hdr, bk, ks, x, rot, acc, v):
-            f.write(np.ascontiguousarray(a).tobytes())
-    subprocess.check_call([driver, "lib", fi, fo])
+    fi, fo = os.path.join(str(tmp_path), "in.bin"), os.path.join(str(tmp_path), "out.bin")
+    if phase in ("run", "both"):
+        with open(fi, "wb") as f:
+            for a in (hdr, bk, ks, x, rot, acc, v):
+                f.write(np.ascontiguousarray(a).tobytes())
+        subprocess.check_call([driver, "lib", fi, fo])
+        if phase == "run":
+            return
     raw = open(fo, "rb").read()
     pos = 0
 
@@ -77,7 +82,7 @@ def run_lib_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=
 
 
 def run_poc_form(driver, tmp_path, n0=3, N1=1024, N2=1024, l1=2, bg1=8, l2=3, bg2=10, t10=3, bb10=2, t21=2, bb21=2,
-                 count=2):
+                 count=2, phase="both"):
     rs = np.random.RandomState(8)
     key0, key2 = O.keygen_binary(n0, SEED, 21), O.keygen_binary(N2, SEED, 23)
     bk = O.bk_create64(N2, key0, key2, l2, bg2, 2.0 ** -44, SEED, 3000)
@@ -86,11 +91,14 @@ def run_poc_form(driver, tmp_path, n0=3, N1=1024, N2=1024, l1=2, bg1=8, l2=3, bg
     x = rs.randint(-2 ** 31, 2 ** 31, size=(count, N1 + 1)).astype(np.int32)
     x64 = rs.randint(-2 ** 63, 2 ** 63 - 1, size=(count, N2 + 1), dtype=np.int64)
     hdr = np.array([n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, count], np.int32)
-    fi, fo = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
-    with open(fi, "wb") as f:
-        for a in (hdr, preks, bk, privks, x, x64):
-            f.write(np.ascontiguousarray(a).tobytes())
-    subprocess.check_call([driver, "poc", fi, fo])
+    fi, fo = os.path.join(str(tmp_path), "in.bin"), os.path.join(str(tmp_path), "out.bin")
+    if phase in ("run", "both"):
+        with open(fi, "wb") as f:
+            for a in (hdr, preks, bk, privks, x, x64):
+                f.write(np.ascontiguousarray(a).tobytes())
+        subprocess.check_call([driver, "poc", fi, fo])
+        if phase == "run":
+            return
     raw = open(fo, "rb").read()
     pos = 0
 
@@ -123,23 +131,43 @@ def test_poc_form_shims_emu(emu_lib, tmp_path):
     run_poc_form(build_driver(emu_lib, "emu"), tmp_path)
 
 
-@pytest.fixture(scope="module")
-def gpu_driver():
-    """built at collection-independent time, BEFORE any GPU use in this process (no fork/exec after
-    GPU init); the driver itself is a separate process"""
+GPU_LIB_ARGS = dict(n=16, count=3)
+GPU_POC_ARGS = dict(n0=8, N2=2048, l2=4, bg2=9, t21=2, bb21=3, count=2)
+GPU_RUN_DIR = os.path.join(ROOT, "tests", "emu", "_build", "compat_gpu_run")
+
+
+def prerun_gpu_drivers():
+    """called by conftest.pytest_collection_finish on a GPU box, BEFORE this process initialises
+    the GPU: build the driver against the HIP library and run it (the driver is its own GPU
+    process); the two tests below only compare its output files with the oracle."""
     import importlib
     T = importlib.import_module("experimental-tfhe_amd")
-    return build_driver(T.DEFAULT_LIB, "hip")
+    drv = build_driver(T.DEFAULT_LIB, "hip")
+    for form, fn, args in (("lib", run_lib_form, GPU_LIB_ARGS), ("poc", run_poc_form, GPU_POC_ARGS)):
+        d = os.path.join(GPU_RUN_DIR, form)
+        os.makedirs(d, exist_ok=True)
+        for f in ("in.bin", "out.bin"):
+            if os.path.exists(os.path.join(d, f)):
+                os.remove(os.path.join(d, f))
+        fn(drv, d, phase="run", **args)
+
+
+def _need(form):
+    d = os.path.join(GPU_RUN_DIR, form)
+    assert os.path.exists(os.path.join(d, "out.bin")), (
+        "the shim driver did not run before the session's GPU tests (conftest.pytest_collection_finish runs it "
+        "on a GPU box; see stderr for its failure)")
+    return d
 
 
 @pytest.mark.gpu
-def test_library_form_shims_gpu(gpu_driver, tmp_path):
-    run_lib_form(gpu_driver, tmp_path, n=16, count=3)
+def test_library_form_shims_gpu():
+    run_lib_form(None, _need("lib"), phase="check", **GPU_LIB_ARGS)
 
 
 @pytest.mark.gpu
-def test_poc_form_shims_gpu(gpu_driver, tmp_path):
-    run_poc_form(gpu_driver, tmp_path, n0=8, N2=2048, l2=4, bg2=9, t21=2, bb21=3, count=2)
+def test_poc_form_shims_gpu():
+    run_poc_form(None, _need("poc"), phase="check", **GPU_POC_ARGS)
 
 
 REF_SRC = "/root/reference/circuit-bootstrapping/src"
