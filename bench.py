@@ -51,6 +51,16 @@ FP64_ISSUE_CYCLES = 4       # cycles per wave64 fp64 instruction on one SIMD
 SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 
 
+def kernel_sources_sha256():
+    """identity of the kernel sources a PMC traffic figure belongs to (tools/make_traffic.py writes the same hash)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tfhe_kernels.h", "tfhe_amd.hip", "devport.h"):
+        with open(os.path.join(ROOT, "experimental-tfhe_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def cpu_baseline(cfg, seconds=10.0):
     """bounded CPU sample on this host: returns the cpu_baseline object"""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
@@ -246,7 +256,11 @@ def main():
         if os.path.exists(tpath) and B == BATCH_PER_GPU and not a.lib:
             try:
                 tj = json.load(open(tpath))
-                traffic, traffic_src = float(tj["bytes_per_launch"]), tj.get("source")
+                # a PMC figure is only valid for the kernel sources it was measured on
+                if tj.get("kernel_sources_sha256") == kernel_sources_sha256():
+                    traffic, traffic_src = float(tj["bytes_per_launch"]), tj.get("source")
+                else:
+                    traffic_src = "profiles/traffic.json is stale (kernel sources changed since it was measured)"
             except (ValueError, KeyError):
                 pass
         total = B * world * a.steps
