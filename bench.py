@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BATCH_PER_GPU = 4096
+TOTAL_MULTI_GPU = 1 << 20
 SEED = 0x5446484500000001
 HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
 FP64_PEAK = 78.6e12      # flop/s vector fp64 (256 CU x 128 flop/clk x 2.4 GHz)
@@ -104,17 +105,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="bootstraps per GPU per step")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="bootstraps per GPU per step (weak scaling); default: 4096 on one GPU (BASELINE config 2)")
+    ap.add_argument("--total", type=int, default=None,
+                    help="bootstraps per step over ALL GPUs, sharded contiguously (strong scaling); default with "
+                         "--gpus > 1: 2^20 (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--br-variant", type=int, default=0,
-                    help="TFHE_AMD_OPT_BR_VARIANT: 0 default schedule, 1 register twiddles (1 wave/SIMD), 2 unpaired digits")
     ap.add_argument("--ks-gather", action="store_true", help="per-sample gather key switch instead of the tiled one")
-    ap.add_argument("--ks-stream", action="store_true",
-                    help="key switch by the streaming kernel (32-sample tiles, global atomics) instead of the tiled one")
     ap.add_argument("--lib", default=None,
-                    help="alternative build of the engine library to time (e.g. libtfhe_amd_asmlds.so from "
-                         "`build.py --asm-lds`); default: the shipped libtfhe_amd.so")
+                    help="alternative build of the engine library to time (A/B experiments, tools/ab.py); "
+                         "default: the shipped libtfhe_amd.so")
     ap.add_argument("--streamed", action="store_true",
                     help="also time BASELINE config 2's literal schedule (one launch per CMux) after the timed region; "
                          "off by default so a rocprofv3 --stats run of the default command sees k_blind_rotate only "
@@ -132,7 +133,16 @@ def main():
     if a.lib is None and not os.path.exists(T.DEFAULT_LIB):
         importlib.import_module("experimental-tfhe_amd.build").build()
     cpu_line = None
-    B = a.batch
+    # workload: one GPU = BASELINE config 2 (batch 4096); several = config 5 (2^20 samples sharded
+    # contiguously over the ranks, strong scaling) unless --batch asks for a fixed per-GPU batch
+    if a.batch is not None:
+        B, scaling, total_per_step = a.batch, "weak", a.batch * world
+    elif a.total is not None or world > 1:
+        total_per_step = a.total if a.total is not None else TOTAL_MULTI_GPU
+        lo, hi = shard.shard_range(total_per_step, rank, world)
+        B, scaling = hi - lo, "strong"
+    else:
+        B, scaling, total_per_step = BATCH_PER_GPU, "weak", BATCH_PER_GPU
     x_host = shard.synthetic_samples(cfg, B, seed=1234 + rank)
     nchk = min(16, B)
     oracle_idx, oracle_want = list(range(nchk, min(nchk + 8, B))), None
@@ -165,9 +175,7 @@ def main():
     except T.TfheAmdError as e:
         raise SystemExit(f"bench.py needs a GPU: the engine has no CPU path ({e})")
     eng, lib = job.eng, job.eng.lib
-    eng.set_option(T.OPT_BR_VARIANT, a.br_variant)
     eng.set_option(T.OPT_KS_GATHER, int(a.ks_gather))
-    eng.set_option(T.OPT_KS_STREAM, int(a.ks_stream))
 
     # a few real encryptions at the front: decrypt-checked after the timed region
     msgs = [(1 << 29) if (i & 1) else -(1 << 29) for i in range(nchk)]
@@ -250,7 +258,7 @@ def main():
 
     if rank == 0:
         # HBM bytes per launch of the dominant kernel as measured by the PMC passes of an earlier profile of
-        # this same command (tools/summarize_prof.py -> profiles/traffic.json); null until such a profile exists
+        # this same command (tools/make_traffic.py -> profiles/traffic.json); null until such a profile exists
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and B == BATCH_PER_GPU and not a.lib:
@@ -263,7 +271,7 @@ def main():
                     traffic_src = "profiles/traffic.json is stale (kernel sources changed since it was measured)"
             except (ValueError, KeyError):
                 pass
-        total = B * world * a.steps
+        total = total_per_step * a.steps
         algo_bytes = B * cfg.n * BYTES_PER_CMUX + cfg.n * BYTES_PER_ROW
         achieved = algo_bytes / (br_ms * 1e-3)
         flops = B * cfg.n * FLOP_PER_CMUX / (br_ms * 1e-3)
@@ -276,14 +284,15 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64 (anticyclic FFT) over int32 torus",
             "data": "synthetic",
-            "config": {"workload": f"batch {B} gate bootstraps per GPU per step, {cfg.describe()}, persistent "
+            "config": {"workload": f"{total_per_step} gate bootstraps per step ({B} on rank 0), {cfg.describe()}, persistent "
                                    "blind-rotation kernel + key-switch kernel, inputs resident in HBM",
-                       "batch_per_gpu": B, "parallelism": f"batch-sharded x{world}, keys replicated",
-                       "br_variant": a.br_variant, "ks_kernel": "gather" if a.ks_gather else ("stream" if a.ks_stream else "tiled"),
+                       "batch_per_gpu": B, "total_per_step": total_per_step,
+                       "parallelism": f"batch-sharded x{world} (contiguous slices), keys replicated, no data-path collective",
+                       "ks_kernel": "gather" if a.ks_gather else "tiled",
                        "library": os.path.basename(a.lib) if a.lib else "libtfhe_amd.so"},
             "roofline": {"bound": "hbm", "kernel": "k_blind_rotate<int32,N=1024>", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,

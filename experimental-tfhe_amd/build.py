@@ -13,8 +13,6 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtfhe_amd.so")
-OUT_ABLATE = os.path.join(HERE, "libtfhe_amd_ablate.so")  # diagnostic build (tools/ablate.py), never loaded by default
-OUT_ASMLDS = os.path.join(HERE, "libtfhe_amd_asmlds.so")  # experiment build (--asm-lds), never loaded by default
 SOURCES = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp"), os.path.join(CSRC, "hp_twiddles.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "devport.h"),
                   os.path.join(os.path.dirname(HERE), "include", "tfhe_amd.h")]
@@ -36,15 +34,11 @@ def stale():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False, ablate=False, asm_lds=False):
-    if ablate or asm_lds:
-        # ablate : timing-only diagnostic library (results wrong by design when a mask is set)
-        # asm_lds: same results as the default library; transposes read LDS through hand-placed
-        #          ds_read_b64 (experiment for A/B timing: bench.py --lib <path>)
-        out, define = (OUT_ABLATE, "-DTFHE_ABLATE") if ablate else (OUT_ASMLDS, "-DTFHE_LDS_READ_ASM")
-        if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in DEPS):
-            return out
-        res = subprocess.run([hipcc()] + FLAGS + [define] + SOURCES + ["-o", out], capture_output=True, text=True)
+def build(force=False, verbose=False, out=None, defines=()):
+    """default: the shipped library.  `out` + `defines`: an experiment build for A/B timing (tools/ab.py),
+    never loaded by default"""
+    if out is not None:
+        res = subprocess.run([hipcc()] + FLAGS + ["-D" + d for d in defines] + SOURCES + ["-o", out], capture_output=True, text=True)
         if res.returncode != 0:
             sys.stderr.write(res.stdout + res.stderr)
             raise RuntimeError("hipcc failed")
@@ -61,5 +55,4 @@ def build(force=False, verbose=False, ablate=False, asm_lds=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, ablate="--ablate" in sys.argv,
-                asm_lds="--asm-lds" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

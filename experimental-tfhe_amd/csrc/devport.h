@@ -35,6 +35,41 @@
 // makes a register value opaque at this point: arithmetic on it cannot be hoisted above (used to
 // keep a rarely taken fallback from being computed speculatively on the hot path)
 #define TFHE_OPAQUE(x) asm volatile("" : "+v"(x))
+// *p += v on an LDS word owned by this lane, as ONE DS instruction with no result (ds_add_u32 /
+// ds_add_u64): no read, no VALU add, no wait.  Ordered with the wave's other DS operations.
+#define TFHE_LDS_ADD(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+// Three-operand integer forms the compiler does not select by itself here (it re-associates the
+// source expression into longer sequences); each is ONE VALU instruction.
+//   tfhe_and_or(x, m, o)  = (x & m) | o          v_and_or_b32   (m wave-uniform)
+//   tfhe_sign_mask(x)     = bit BIT of x as 0/-1 v_bfe_i32
+//   tfhe_xad(a, b, c)     = (a ^ b) + c          v_xad_u32
+__device__ __forceinline__ uint32_t tfhe_and_or(uint32_t x, uint32_t m, uint32_t o) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(m), "v"(o));
+    return r;
+}
+template <int BIT>
+__device__ __forceinline__ uint32_t tfhe_sign_mask(uint32_t x) {
+    uint32_t r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(x), "n"(BIT));
+    return r;
+}
+__device__ __forceinline__ uint32_t tfhe_xad(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// byte offset of an LDS object inside the workgroup's LDS segment (generic -> LDS address-space cast)
+__device__ __forceinline__ uint32_t tfhe_lds_offset(const void *p) {
+    typedef __attribute__((address_space(3))) const unsigned char lds_byte;
+    return (uint32_t)(uintptr_t)(lds_byte *)p;
+}
+// 32-bit load from LDS byte offset `off` (as returned by tfhe_lds_offset, plus arithmetic)
+__device__ __forceinline__ uint32_t tfhe_lds_load32(const void *, uint32_t off) {
+    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+    return *(lds_u32 *)(uintptr_t)off;
+}
+#define TFHE_TRAP() __builtin_trap()
 // value of `v` held by lane `lane` (wave-uniform lane index) -> scalar register
 #define TFHE_READLANE(v, lane) __builtin_amdgcn_readlane((v), (lane))
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \

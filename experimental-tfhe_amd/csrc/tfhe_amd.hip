@@ -44,8 +44,6 @@ struct tfhe_amd_ctx {
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
     bool ks_force_gather;  // TFHE_AMD_OPT_KS_GATHER: per-sample gather kernel even when the tiled one applies
-    bool ks_stream;        // TFHE_AMD_OPT_KS_STREAM: 64-sample tiles streamed by the private-key-switch kernel
-    int br_variant;        // TFHE_AMD_OPT_BR_VARIANT
     int fft_waves;         // TFHE_AMD_OPT_FFT_WAVES
     // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
     // hipGraph and replayed while the call's arguments stay the same
@@ -55,7 +53,7 @@ struct tfhe_amd_ctx {
         void *exec;  // hipGraphExec_t
         const void *x, *out;
         int32_t mu;
-        int batch, variant;
+        int batch;
         bool ks_gather;
     } sg;
     std::vector<const void *> lds_configured;  // kernels whose dynamic-LDS limit is raised on this device
@@ -166,31 +164,26 @@ int set_lds(tfhe_amd_ctx *c, KernelT kernel, size_t bytes) {
 }
 
 // one instantiation per (torus, N): waves per workgroup chosen so LDS fits 160 KiB
-template <typename T, int LOGN, int WAVES, int PAIR, bool TWREG = false, int LC = 0>
+template <typename T, int LOGN, int WAVES, int PAIR, int LC = 0, int BGC = 0>
 int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
-    using Lds = BlindRotateLds<T, LOGN, WAVES, TWREG>;
-    auto kernel = k_blind_rotate<T, LOGN, WAVES, PAIR, TWREG, LC>;
+    using Lds = BlindRotateLds<T, LOGN, WAVES>;
+    auto kernel = k_blind_rotate<T, LOGN, WAVES, PAIR, LC, BGC>;
     if (int rc = set_lds(c, kernel, Lds::total)) return rc;
     const int blocks = (a.batch + WAVES - 1) / WAVES;
-    TFHE_LAUNCH((k_blind_rotate<T, LOGN, WAVES, PAIR, TWREG, LC>), dim3(blocks), dim3(WAVES * 64), Lds::total, c->stream, a);
+    TFHE_LAUNCH((k_blind_rotate<T, LOGN, WAVES, PAIR, LC, BGC>), dim3(blocks), dim3(WAVES * 64), Lds::total, c->stream, a);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
 int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
-    // N=1024/Torus32: 2 waves per SIMD (256 VGPRs): digits in pairs.  PPL=16 shapes transform
+    // N=1024/Torus32: 2 waves per SIMD (256 VGPRs), digits in pairs.  PPL=16 shapes transform
     // one digit at a time (a pair would need 128 more registers than the file has).
     if (c->logn == 11) return launch_br_t<int32_t, 11, 4, 1>(c, a);
-    if (c->p.l == 2)  // the gate set (and the circuit bootstrap's output gadget): gadget length fixed at compile time
-        switch (c->br_variant) {
-            case 1: return launch_br_t<int32_t, 10, 4, 2, true, 2>(c, a);
-            case 2: return launch_br_t<int32_t, 10, 8, 1, false, 2>(c, a);
-            default: return launch_br_t<int32_t, 10, 8, 2, false, 2>(c, a);
-        }
-    switch (c->br_variant) {  // schedules of the same arithmetic (TFHE_AMD_OPT_BR_VARIANT), identical results
-        case 1: return launch_br_t<int32_t, 10, 4, 2, true>(c, a);  // 1 wave/SIMD, twiddles in registers
-        case 2: return launch_br_t<int32_t, 10, 8, 1>(c, a);        // digits one at a time
-        default: return launch_br_t<int32_t, 10, 8, 2>(c, a);       // 2 waves/SIMD, LDS twiddles, digit pairs
-    }
+    // gadget length (and, for the gate set, Bgbit) fixed at compile time: the two transform groups
+    // of a CMux are unrolled and each digit is one bit-field extract (tfhe_kernels.h, cmux_step)
+    if (c->p.l == 2 && c->p.Bgbit == 10) return launch_br_t<int32_t, 10, 8, 2, 2, 10>(c, a);  // gate set
+    if (c->p.l == 2 && c->p.Bgbit == 8) return launch_br_t<int32_t, 10, 8, 2, 2, 8>(c, a);    // circuit bootstrap's output gadget
+    if (c->p.l == 2) return launch_br_t<int32_t, 10, 8, 2, 2>(c, a);
+    return launch_br_t<int32_t, 10, 8, 2>(c, a);
 }
 int launch_br64(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
     return c->logn == 10 ? launch_br_t<int64_t, 10, 4, 2>(c, a) : launch_br_t<int64_t, 11, 3, 1>(c, a);
@@ -301,37 +294,6 @@ int launch_ks_tiled(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int ba
         case 1: return launch_ks_tiled_n<1>(c, out_d, in_d, batch);
         case 4: return launch_ks_tiled_n<4>(c, out_d, in_d, batch);
         default: return launch_ks_tiled_n<5>(c, out_d, in_d, batch);
-    }
-}
-
-// streamed LWE key switch (TFHE_AMD_OPT_KS_KERNEL = 2): the private-key-switch kernel on the tiled key
-// layout -- 32-sample tiles (the key is read once per 32 samples instead of once per 16), the i range
-// split over workgroups, partial sums added with global integer atomics into the seeded output
-template <int BB>
-int launch_ks_stream_t(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
-    constexpr int TB = 32, EPT = 2, THREADS = 320;  // 5 waves x 64 lanes x 2 ints = the 640-int padded row
-    const int N = c->p.N, n_out = c->p.ks_n_out;
-    const long long total = (long long)batch * (n_out + 1);
-    TFHE_LAUNCH_FLAT(k_ks_seed, dim3((unsigned)((total + 255) / 256)), dim3(256), c->stream, out_d, in_d, N, n_out, total);
-    HIPCHECK(c, hipGetLastError());
-    const int tiles = (batch + TB - 1) / TB;
-    int slices = (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU
-    if (slices > N / 64) slices = N / 64;
-    if (slices < 1) slices = 1;
-    int i_per_block = ((N + slices - 1) / slices + 63) / 64 * 64;
-    slices = (N + i_per_block - 1) / i_per_block;
-    // the kernel's "n2 + 1" inputs are the N mask coefficients here (the b term is the seed)
-    TFHE_LAUNCH((k_privks<int32_t, TB, BB, EPT, THREADS, true>), dim3(tiles, slices), dim3(THREADS), 0, c->stream, out_d,
-                (long long)(n_out + 1), 0LL, batch, in_d, N + 1, (const int32_t *)c->ksd_d, N - 1, c->p.ks_t,
-                ks_nch(n_out) * 128, batch, i_per_block);
-    HIPCHECK(c, hipGetLastError());
-    return TFHE_AMD_OK;
-}
-int launch_ks_stream(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
-    switch (c->p.ks_basebit) {
-        case 1: return launch_ks_stream_t<1>(c, out_d, in_d, batch);
-        case 2: return launch_ks_stream_t<2>(c, out_d, in_d, batch);
-        default: return launch_ks_stream_t<3>(c, out_d, in_d, batch);
     }
 }
 
@@ -495,9 +457,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->ks_d = nullptr;
     c->ksd_d = nullptr;
     c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") != nullptr;
-    c->br_variant = getenv("TFHE_AMD_BR_VARIANT") ? atoi(getenv("TFHE_AMD_BR_VARIANT")) : 0;
     c->fft_waves = 4;
-    c->ks_stream = false;
     c->streamed_graph = false;
     c->streamed_warm = 0;
     memset(&c->sg, 0, sizeof(c->sg));
@@ -587,16 +547,8 @@ int tfhe_amd_set_stream(tfhe_amd_ctx *c, void *s) {
 int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
     if (!c) return TFHE_AMD_ERR_PARAM;
     switch (option) {
-        case TFHE_AMD_OPT_BR_VARIANT:
-            REQUIRE(c, value >= 0 && value <= 2, "blind-rotation variant must be 0, 1 or 2");
-            c->br_variant = value;
-            return TFHE_AMD_OK;
         case TFHE_AMD_OPT_KS_GATHER:
             c->ks_force_gather = value != 0;
-            return TFHE_AMD_OK;
-        case TFHE_AMD_OPT_KS_STREAM:
-            c->ks_stream = value != 0;
-            drop_streamed_graph(c);
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_STREAMED_GRAPH:
             c->streamed_graph = value != 0;
@@ -974,7 +926,7 @@ int tfhe_amd_keyswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int
     ENTER(c);
     if (!c->ks_d) return fail(c, TFHE_AMD_ERR_STATE, "no key-switch key");
     if (batch == 0) return TFHE_AMD_OK;
-    if (c->ksd_d && !c->ks_force_gather) return c->ks_stream ? launch_ks_stream(c, out_d, in_d, batch) : launch_ks_tiled(c, out_d, in_d, batch);
+    if (c->ksd_d && !c->ks_force_gather) return launch_ks_tiled(c, out_d, in_d, batch);
     TFHE_LAUNCH_FLAT(k_keyswitch32, dim3(batch), dim3(256), c->stream, out_d, in_d, (const int32_t *)c->ks_d, c->p.N,
                 c->p.ks_n_out, c->p.ks_t, c->p.ks_basebit, batch);
     HIPCHECK(c, hipGetLastError());
@@ -1042,13 +994,13 @@ int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, con
         // and let the first call of each schedule variant run as plain launches
         if (int rc = grow(c, &c->ws_lwe, &c->ws_lwe_bytes, (size_t)batch * (c->p.N + 1) * 4)) return rc;
         if (int rc = grow(c, &c->ws_acc, &c->ws_acc_bytes, (size_t)batch * 2 * c->p.N * 4)) return rc;
-        const unsigned vbit = 1u << (c->br_variant + (c->ks_force_gather ? 8 : 0));
+        const unsigned vbit = 1u << (c->ks_force_gather ? 1 : 0);
         if (!(c->streamed_warm & vbit)) {
             c->streamed_warm |= vbit;
             return streamed_plain(c, out_d, mu, x_d, batch);
         }
         const bool hit = c->sg.exec && c->sg.x == x_d && c->sg.out == out_d && c->sg.mu == mu && c->sg.batch == batch &&
-                         c->sg.variant == c->br_variant && c->sg.ks_gather == c->ks_force_gather;
+                         c->sg.ks_gather == c->ks_force_gather;
         if (!hit) {
             drop_streamed_graph(c);
             hipGraph_t graph = nullptr;
@@ -1069,7 +1021,6 @@ int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, con
             c->sg.out = out_d;
             c->sg.mu = mu;
             c->sg.batch = batch;
-            c->sg.variant = c->br_variant;
             c->sg.ks_gather = c->ks_force_gather;
         }
         HIPCHECK(c, hipGraphLaunch((hipGraphExec_t)c->sg.exec, c->stream));
@@ -1182,18 +1133,6 @@ int tfhe_amd_hp_fft(tfhe_amd_ctx *c, int64_t *out_d, const uint64_t *in_d, int b
 }
 
 }  // extern "C"
-
-#ifdef TFHE_ABLATE
-// diagnostic build only (build.py --ablate): switch cost components off, see tfhe_kernels.h
-extern "C" int tfhe_amd_debug_set_ablation(unsigned mask) {
-#ifdef TFHE_EMU
-    tfhe::g_ablate = mask;
-    return TFHE_AMD_OK;
-#else
-    return hipMemcpyToSymbol(HIP_SYMBOL(tfhe::g_ablate), &mask, sizeof(mask)) == hipSuccess ? TFHE_AMD_OK : TFHE_AMD_ERR_DEVICE;
-#endif
-}
-#endif
 
 // ---------------------------------------------------------------- circuit bootstrap
 struct tfhe_amd_cb {

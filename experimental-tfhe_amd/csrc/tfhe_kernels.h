@@ -30,20 +30,6 @@
 
 namespace tfhe {
 
-// ---- ablation hooks (DIAGNOSTIC build only: build.py --ablate, tools/ablate.py) -------------
-// With -DTFHE_ABLATE a mask in device memory switches off one cost component at a time (results
-// are then WRONG on purpose; only the timing is read).  The shipped build contains none of this:
-// every hook is inside #ifdef TFHE_ABLATE.
-enum : uint32_t { ABL_NO_BK_LOADS = 1u, ABL_NO_TRANSPOSES = 2u, ABL_NO_TWIDDLE_READS = 4u, ABL_NO_ROTATE_READS = 8u };
-#ifdef TFHE_ABLATE
-#ifdef TFHE_EMU
-static uint32_t g_ablate = 0;
-#else
-__device__ uint32_t g_ablate = 0;
-#endif
-#define TFHE_ABL(bit) ((g_ablate & (bit)) != 0)
-#endif
-
 // ------------------------------------------------------------------ geometry
 template <int LOGN>
 struct Geom {
@@ -110,27 +96,15 @@ TFHE_DEVICE void dit_bfly(double &ar, double &ai, double &br, double &bi, double
 // directions; the fft butterflies flip the sign of c on exactly those entries.
 TFHE_DEVICE double flip_sign_if(double c, bool cond) { return cond ? -c : c; }
 
-// ---- where the butterflies get their twiddles -----------------------------------------
-// TwLds: the workgroup's LDS copy of the table (one ds_read_b128 per use).
-// TwRegs: the lane's own 3*PPL-2 twiddles (twist, pass A, pass B) held in registers for the whole
-//         kernel, pass C (lane-uniform) too -- no LDS twiddle traffic at all; costs 4*(3*PPL+2)
-//         VGPRs, so it goes with one wave per SIMD.
+// ---- where the butterflies get their twiddles: the workgroup's LDS copy of the table (one
+// ds_read_b128 per use).  (A variant holding the lane's twiddles in registers at one wave per SIMD
+// was measured slower on MI355X: profiles/r02_variants.txt, "br1".)
 template <int LOGN>
 struct TwLds {
     using G = Geom<LOGN>;
     const double2 *tw;
     int t;
-#ifdef TFHE_ABLATE
-    struct Fetch {
-        const double2 *p;
-        TFHE_DEVICE double2 operator[](int i) const {
-            return TFHE_ABL(ABL_NO_TWIDDLE_READS) ? make_double2(0.70710678118654757, 0.70710678118654746) : p[i];
-        }
-    };
-#define TFHE_TW_SRC (Fetch{tw})
-#else
 #define TFHE_TW_SRC tw
-#endif
     TFHE_DEVICE double2 twist(int m) const { return TFHE_TW_SRC[G::jA(t, m)]; }
     TFHE_DEVICE double2 passA(int s, int m) const { return TFHE_TW_SRC[G::tw_base(64 * s) + t + 64 * (m & (s - 1))]; }
     TFHE_DEVICE double2 passB(int s, int m) const {
@@ -140,81 +114,39 @@ struct TwLds {
 #undef TFHE_TW_SRC
 };
 template <int LOGN>
-struct TwRegs {
-    using G = Geom<LOGN>;
-    static constexpr int PPL = G::PPL;
-    double2 tws[PPL], a[PPL - 1], b[PPL - 1], c[4];
-    // table: the [2*NC] complex table in global (or LDS) memory
-    TFHE_DEVICE void load(const double2 *table, int t) {
-#pragma unroll
-        for (int m = 0; m < PPL; m++) tws[m] = table[G::jA(t, m)];
-#pragma unroll
-        for (int s = 1; s <= PPL / 2; s <<= 1)
-#pragma unroll
-            for (int k = 0; k < s; k++) {
-                a[s - 1 + k] = table[G::tw_base(64 * s) + t + 64 * k];
-                b[s - 1 + k] = table[G::tw_base(s << G::CB) + (k << G::CB) + (t & ((1 << G::CB) - 1))];
-            }
-#pragma unroll
-        for (int k = 0; k < 4; k++) c[k] = table[G::tw_base(4) + k];
-    }
-    TFHE_DEVICE double2 twist(int m) const { return tws[m]; }
-    TFHE_DEVICE double2 passA(int s, int m) const { return a[s - 1 + (m & (s - 1))]; }
-    TFHE_DEVICE double2 passB(int s, int m) const { return b[s - 1 + (m & (s - 1))]; }
-    TFHE_DEVICE double2 passC(int m) const { return c[m & 3]; }
-};
-
-template <int LOGN>
 struct WaveFFT {
     using G = Geom<LOGN>;
     static constexpr int PPL = G::PPL;
 
-#if defined(TFHE_LDS_READ_ASM) && !defined(TFHE_EMU)
-    // Eight ds_read_b64 from one address register with immediate offsets, then the wait -- in ONE
-    // asm statement, so no result is consumed before it has landed.  Exists because hipcc pairs
-    // adjacent 8-byte LDS reads into ds_read2_b64, which the LDS serves at half the ds_read_b64 rate
-    // (MI355X_MICROARCH.md, LDS table).  Opt-in build (build.py --asm-lds) until measured.
-    template <int MAP, int M0>
-    TFHE_DEVICE static void read8(double (&x)[PPL], uint32_t addr) {
-        asm volatile(
-            "ds_read_b64 %0, %8 offset:%9\n\t"
-            "ds_read_b64 %1, %8 offset:%10\n\t"
-            "ds_read_b64 %2, %8 offset:%11\n\t"
-            "ds_read_b64 %3, %8 offset:%12\n\t"
-            "ds_read_b64 %4, %8 offset:%13\n\t"
-            "ds_read_b64 %5, %8 offset:%14\n\t"
-            "ds_read_b64 %6, %8 offset:%15\n\t"
-            "ds_read_b64 %7, %8 offset:%16\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(x[M0 + 0]), "=&v"(x[M0 + 1]), "=&v"(x[M0 + 2]), "=&v"(x[M0 + 3]), "=&v"(x[M0 + 4]),
-              "=&v"(x[M0 + 5]), "=&v"(x[M0 + 6]), "=&v"(x[M0 + 7])
-            : "v"(addr), "i"(8 * G::roff(MAP, M0 + 0)), "i"(8 * G::roff(MAP, M0 + 1)), "i"(8 * G::roff(MAP, M0 + 2)),
-              "i"(8 * G::roff(MAP, M0 + 3)), "i"(8 * G::roff(MAP, M0 + 4)), "i"(8 * G::roff(MAP, M0 + 5)),
-              "i"(8 * G::roff(MAP, M0 + 6)), "i"(8 * G::roff(MAP, M0 + 7))
-            : "memory");
+    // The wave's transpose buffer with the LANE part of the padded index of every (map, padding) pair:
+    // point index of register m under map M = lane[M] + roff(M, m), roff a compile-time constant, so a
+    // transpose is 2 address registers + immediate offsets (and the compiler pairs the accesses).
+    struct Xch {
+        double *buf;
+        int lane[5];
+    };
+    TFHE_DEVICE static Xch make_xch(double *buf, int t) {
+        Xch x;
+        x.buf = buf;
+        const int hi = t >> G::CB, lo = t & ((1 << G::CB) - 1);
+        x.lane[G::RD_A1] = t;                                           // idx1(jA)
+        x.lane[G::RD_B1] = (hi << 6) + lo + (hi << G::CB);              // idx1(jB)
+        x.lane[G::RD_B2] = (hi << 6) + lo + (hi << (6 - G::R));         // idx2(jB)
+        x.lane[G::RD_C2] = (PPL + 1) * t;                               // idx2(jC)
+        x.lane[G::RD_A2] = t + (t >> G::R);                             // idx2(jA)
+#pragma unroll
+        for (int k = 0; k < 5; k++) TFHE_OPAQUE(x.lane[k]);  // one register each, never re-derived from t
+        return x;
     }
-#endif
-
-    // one wave-wide transpose through LDS: write with map widx, read with map ridx (= read map MAP)
-    template <int MAP, class WIdx, class RIdx>
-    TFHE_DEVICE static void transpose(double (&x)[PPL], double *xch, WIdx widx, RIdx ridx) {
-#ifdef TFHE_ABLATE
-        if (TFHE_ABL(ABL_NO_TRANSPOSES)) return;
-#endif
+    // one wave-wide transpose through LDS: write with map WMAP, read with map RMAP
+    template <int WMAP, int RMAP>
+    TFHE_DEVICE static void transpose(double (&x)[PPL], const Xch &X) {
+        double *w = X.buf + X.lane[WMAP], *r = X.buf + X.lane[RMAP];
 #pragma unroll
-        for (int m = 0; m < PPL; m++) xch[widx(m)] = x[m];
+        for (int m = 0; m < PPL; m++) w[G::roff(WMAP, m)] = x[m];
         TFHE_WAVE_FENCE();
-#if defined(TFHE_LDS_READ_ASM) && !defined(TFHE_EMU)
-        // LDS byte offset of the first element: an explicit generic -> LDS address-space cast, so the
-        // compiler (not an assumption about the aperture layout) produces the 32-bit DS address
-        typedef __attribute__((address_space(3))) double lds_double;
-        const uint32_t addr = (uint32_t)(uintptr_t)(lds_double *)(xch + ridx(0));
-        read8<MAP, 0>(x, addr);
-        if (PPL == 16) read8<MAP, (PPL == 16 ? 8 : 0)>(x, addr);
-#else
 #pragma unroll
-        for (int m = 0; m < PPL; m++) x[m] = xch[ridx(m)];
-#endif
+        for (int m = 0; m < PPL; m++) x[m] = r[G::roff(RMAP, m)];
         TFHE_WAVE_FENCE();
     }
 
@@ -222,7 +154,7 @@ struct WaveFFT {
     // and used by all NP).  In: lane t register m = point jA(t,m) (re = coef j, im = coef j+N/2).
     // Out: register m = position jC(t,m) of the reference's output order.
     template <int NP, class TW>
-    TFHE_DEVICE static void ifft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, double *xch, int t) {
+    TFHE_DEVICE static void ifft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, const Xch &X, int t) {
         // Every twiddle is requested one step before the step that uses it (wn), so that its LDS
         // latency runs under the previous step's arithmetic instead of in front of its own.
         // twist by omega^j (spqlios-ifft-fma.s:63-78)
@@ -257,12 +189,10 @@ struct WaveFFT {
                 for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], w.x, w.y);
             }
         }
-        auto wA = [&](int m) { return G::idx1(G::jA(t, m)); };
-        auto rB = [&](int m) { return G::idx1(G::jB(t, m)); };
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            transpose<G::RD_B1>(xr[p], xch, wA, rB);
-            transpose<G::RD_B1>(xi[p], xch, wA, rB);
+            transpose<G::RD_A1, G::RD_B1>(xr[p], X);
+            transpose<G::RD_A1, G::RD_B1>(xi[p], X);
         }
         // pass B: strides s<<CB
 #pragma unroll
@@ -275,12 +205,10 @@ struct WaveFFT {
                 for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], w.x, w.y);
             }
         }
-        auto wB = [&](int m) { return G::idx2(G::jB(t, m)); };
-        auto rC = [&](int m) { return G::idx2(G::jC(t, m)); };
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            transpose<G::RD_C2>(xr[p], xch, wB, rC);
-            transpose<G::RD_C2>(xi[p], xch, wB, rC);
+            transpose<G::RD_B2, G::RD_C2>(xr[p], X);
+            transpose<G::RD_B2, G::RD_C2>(xi[p], X);
         }
         // pass C: (N=1024 only) stride 4 general stage, then size-4 and size-2 steps
         if (G::CB == 3) {
@@ -321,7 +249,7 @@ struct WaveFFT {
     // Lagrange -> coefficient for NP polynomials (caller has applied the 2/N scale).
     // In: register m = position jC(t,m).  Out: register m = point jA(t,m).
     template <int NP, class TW>
-    TFHE_DEVICE static void fft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, double *xch, int t) {
+    TFHE_DEVICE static void fft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, const Xch &X, int t) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
 #pragma unroll
@@ -356,12 +284,10 @@ struct WaveFFT {
                 for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + 4], xi[p][m + 4], wc, w.y);
             }
         }
-        auto wC = [&](int m) { return G::idx2(G::jC(t, m)); };
-        auto rB = [&](int m) { return G::idx2(G::jB(t, m)); };
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            transpose<G::RD_B2>(xr[p], xch, wC, rB);
-            transpose<G::RD_B2>(xi[p], xch, wC, rB);
+            transpose<G::RD_C2, G::RD_B2>(xr[p], X);
+            transpose<G::RD_C2, G::RD_B2>(xi[p], X);
         }
         const int c = t & ((1 << G::CB) - 1);
 #pragma unroll
@@ -378,12 +304,10 @@ struct WaveFFT {
                 for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], wc, w.y);
             }
         }
-        auto wB = [&](int m) { return G::idx1(G::jB(t, m)); };
-        auto rA = [&](int m) { return G::idx1(G::jA(t, m)); };
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            transpose<G::RD_A1>(xr[p], xch, wB, rA);
-            transpose<G::RD_A1>(xi[p], xch, wB, rA);
+            transpose<G::RD_B1, G::RD_A1>(xr[p], X);
+            transpose<G::RD_B1, G::RD_A1>(xi[p], X);
         }
 #pragma unroll
         for (int s = 1; s <= PPL / 2; s <<= 1) {
@@ -474,28 +398,6 @@ struct Gadget {
     int32_t l;
 };
 
-// one coefficient of (X^a - 1) * p, a in [1, 2N)   (numeric_functions.cpp:304-323)
-template <typename T, int LOGN>
-TFHE_DEVICE typename Torus<T>::U rot_minus_one(const T *p, int i, int a) {
-    using U = typename Torus<T>::U;
-    constexpr int N = 1 << LOGN;
-    const int idx = (i - a) & (2 * N - 1);
-    const U src = (U)p[idx & (N - 1)];
-    const U rot = (idx & N) ? (U)(0 - src) : src;
-    return rot - (U)p[i];
-}
-// The same coefficient with the lane's rotation base hoisted: base = (t - a) mod 2N is computed once
-// per CMux, i = t + K with K a compile-time constant.  Bit LOGN of base+K is the sign of the wrapped
-// term (higher bits do not matter), its low LOGN bits the source index.
-template <typename T, int LOGN>
-TFHE_DEVICE typename Torus<T>::U rot_minus_one_hoisted(const T *p, int base, int K, int t) {
-    using U = typename Torus<T>::U;
-    constexpr int N = 1 << LOGN;
-    const int idx = base + K;
-    const U src = (U)p[idx & (N - 1)];
-    const U rot = (idx & N) ? (U)(0 - src) : src;
-    return rot - (U)p[t + K];
-}
 // one coefficient of X^a * p, a in [0, 2N)   (numeric_functions.cpp:327-347)
 template <typename T, int LOGN>
 TFHE_DEVICE T rot_only(const T *p, int i, int a) {
@@ -507,17 +409,24 @@ TFHE_DEVICE T rot_only(const T *p, int i, int a) {
 }
 
 // --------------------------------------------------------------- CMux step
-// Shared (LDS) state of one wave.
-template <typename T, int LOGN, class TW>
+// Shared (LDS) state of one wave.  Polynomial q of the accumulator starts at LDS byte offset
+// acc_lds + q * N * sizeof(T), a multiple of its own size (BlindRotateLds puts the accumulators
+// first; the kernel checks the segment base), which lets the rotated read form an address with one
+// AND-OR.
+template <typename T, int LOGN>
 struct WaveLds {
-    T *acc;       // [2][N] accumulator
-    double *xch;  // [Geom::XCH] transpose buffer
-    TW tw;        // twiddle source (TwLds / TwRegs)
+    unsigned char *smem;  // workgroup's dynamic LDS block
+    uint32_t acc_lds;     // LDS byte offset of acc (a multiple of the polynomial size)
+    T *acc;               // [2][N] accumulator
+    typename WaveFFT<LOGN>::Xch xch;  // [Geom::XCH] transpose buffer + lane maps
+    TwLds<LOGN> tw;       // twiddle source
 };
 
 // Fourier-domain multiply-accumulate of one decomposed limb with one key row
-// (lagrangehalfc_impl_fma.s:96-107), bk already in registers.
-template <int PPL>
+// (lagrangehalfc_impl_fma.s:96-107), bk already in registers.  FIRST: the accumulator is still the
+// +0 of tLweFFTClear (tgsw_functions.cpp:438) -- fma(a, b, -(+0)) and fma(a, b, +0) are a*b up to the
+// sign of a zero result (the one tolerated difference), so the row needs no zeroed input.
+template <int PPL, bool FIRST>
 TFHE_DEVICE void mac_row(double (&fr)[2][PPL], double (&fi)[2][PPL], const double (&xr)[PPL],
                          const double (&xi)[PPL], const double2 (&bk)[2][PPL]) {
 #pragma unroll
@@ -525,9 +434,9 @@ TFHE_DEVICE void mac_row(double (&fr)[2][PPL], double (&fi)[2][PPL], const doubl
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
             const double ar = xr[m], ai = xi[m], br = bk[q][m].x, bi = bk[q][m].y;
-            const double tneg = __builtin_fma(ai, bi, -fr[q][m]);
+            const double tneg = FIRST ? ai * bi : __builtin_fma(ai, bi, -fr[q][m]);
             fr[q][m] = __builtin_fma(ar, br, -tneg);
-            const double u = __builtin_fma(ar, bi, fi[q][m]);
+            const double u = FIRST ? ar * bi : __builtin_fma(ar, bi, fi[q][m]);
             fi[q][m] = __builtin_fma(ai, br, u);
         }
     }
@@ -536,69 +445,129 @@ TFHE_DEVICE void mac_row(double (&fr)[2][PPL], double (&fi)[2][PPL], const doubl
 // ND consecutive gadget digits (d .. d+ND-1) of one accumulator polynomial: extract, transform
 // together, multiply-accumulate with their key rows in digit order (the MAC chain is sequential in
 // the row index: lagrangehalfc AddMul accumulates in place, tgsw_functions.cpp:441-443).
-template <typename T, int LOGN, int ND, class TW>
-TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN, TW> &w, const double2 *__restrict__ bkrow, int row0, int d0,
+// BGC: Bgbit when it is known at compile time (0: read gd.Bgbit) -- one v_bfe_i32 per digit.
+template <typename T, int LOGN, int ND, int BGC, bool FIRST>
+TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int row0, int d0,
                                  const typename Torus<T>::U (&lo)[Geom<LOGN>::PPL],
                                  const typename Torus<T>::U (&hi)[Geom<LOGN>::PPL], const Gadget &gd,
                                  double (&fr)[2][Geom<LOGN>::PPL], double (&fi)[2][Geom<LOGN>::PPL], int t) {
     using U = typename Torus<T>::U;
     constexpr int PPL = Geom<LOGN>::PPL;
-    const U mask = ((U)1 << gd.Bgbit) - 1;
-    const int32_t halfBg = 1 << (gd.Bgbit - 1);
+    const int Bgbit = BGC ? BGC : gd.Bgbit;
+    const U mask = ((U)1 << Bgbit) - 1;
+    const int32_t halfBg = 1 << (Bgbit - 1);
     double2 bk[2][PPL];  // key row of the first digit, fetched underneath the transform
-#ifdef TFHE_ABLATE
-    const bool abl_bk = TFHE_ABL(ABL_NO_BK_LOADS);
-#define TFHE_BK(idx, fake) (abl_bk ? (fake) : bkrow[idx])
-#else
-#define TFHE_BK(idx, fake) bkrow[idx]
-#endif
+    // wave-uniform row pointer + 32-bit lane offset: one address register for the whole row
+    const unsigned char *kb = reinterpret_cast<const unsigned char *>(bkrow);
+    const uint32_t lane16 = (uint32_t)t * 16u;
+#define TFHE_BK(row, qq, m) \
+    (*reinterpret_cast<const double2 *>(kb + (lane16 + (uint32_t)((((row) * 2 + (qq)) * PPL + (m)) * 64) * 16u)))
 #pragma unroll
     for (int qq = 0; qq < 2; qq++)
 #pragma unroll
-        for (int m = 0; m < PPL; m++) bk[qq][m] = TFHE_BK(((row0 * 2 + qq) * PPL + m) * 64 + t, make_double2(1.0 + m, 0.5 * t));
+        for (int m = 0; m < PPL; m++) bk[qq][m] = TFHE_BK(row0, qq, m);
     double xr[ND][PPL], xi[ND][PPL];
 #pragma unroll
     for (int e = 0; e < ND; e++) {
-        const int decal = Torus<T>::BITS - (d0 + e + 1) * gd.Bgbit;
+        const int decal = Torus<T>::BITS - (d0 + e + 1) * Bgbit;
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
             if (Torus<T>::BITS == 32) {
                 // lo/hi arrive with the top bit of every digit field flipped (Gadget::flip), so the
                 // field read as a signed Bgbit-bit number IS (field - Bg/2): one v_bfe_i32 per digit
-                xr[e][m] = (double)(((int32_t)((uint32_t)lo[m] << (32 - decal - gd.Bgbit))) >> (32 - gd.Bgbit));
-                xi[e][m] = (double)(((int32_t)((uint32_t)hi[m] << (32 - decal - gd.Bgbit))) >> (32 - gd.Bgbit));
+                xr[e][m] = (double)(((int32_t)((uint32_t)lo[m] << (32 - decal - Bgbit))) >> (32 - Bgbit));
+                xi[e][m] = (double)(((int32_t)((uint32_t)hi[m] << (32 - decal - Bgbit))) >> (32 - Bgbit));
             } else {
                 xr[e][m] = (double)((int32_t)((lo[m] >> decal) & mask) - halfBg);
                 xi[e][m] = (double)((int32_t)((hi[m] >> decal) & mask) - halfBg);
             }
         }
     }
-    WaveFFT<LOGN>::template ifft<ND, TW>(xr, xi, w.tw, w.xch, t);
+    WaveFFT<LOGN>::template ifft<ND, TwLds<LOGN>>(xr, xi, w.tw, w.xch, t);
 #pragma unroll
     for (int e = 0; e < ND; e++) {
         if (e > 0) {
 #pragma unroll
             for (int qq = 0; qq < 2; qq++)
 #pragma unroll
-                for (int m = 0; m < PPL; m++)
-                    bk[qq][m] = TFHE_BK((((row0 + e) * 2 + qq) * PPL + m) * 64 + t, make_double2(2.0 + m, 0.25 * t));
+                for (int m = 0; m < PPL; m++) bk[qq][m] = TFHE_BK(row0 + e, qq, m);
         }
-        mac_row<PPL>(fr, fi, xr[e], xi[e], bk);
+        if (FIRST && e == 0)
+            mac_row<PPL, true>(fr, fi, xr[e], xi[e], bk);
+        else
+            mac_row<PPL, false>(fr, fi, xr[e], xi[e], bk);
     }
 #undef TFHE_BK
+}
+
+// The 2*PPL coefficients (j = t + 64m and j + N/2) of polynomial q of (X^a - 1) * acc, gadget offset
+// added and digit-field tops flipped  (torusPolynomialMulByXaiMinusOne, numeric_functions.cpp:304-323).
+// Source index (j - a) mod 2N: its low LOGN bits address the coefficient, bit LOGN negates it.  The
+// lane's byte offset of the K = 0 source, B = ((t - a) mod 2N) * sizeof(T), is formed once; per
+// coefficient (Torus32): one add (x = B + 4K), one AND-OR (wrap inside the polynomial | its LDS
+// offset), one signed bit-field extract (s = the sign as 0 / -1), then ((src ^ s) + (offset - acc[j]))
+// as one XOR-ADD, - s, ^ flip: 7 VALU operations, where the plain expression compiles to 10.
+template <typename T, int LOGN>
+TFHE_DEVICE void rotated_minus_one(const WaveLds<T, LOGN> &w, int q, int a, typename Torus<T>::U offset,
+                                   typename Torus<T>::U flip, typename Torus<T>::U (&lo)[Geom<LOGN>::PPL],
+                                   typename Torus<T>::U (&hi)[Geom<LOGN>::PPL], int t) {
+    using G = Geom<LOGN>;
+    using U = typename Torus<T>::U;
+    constexpr int PPL = G::PPL, N = G::N, NC = G::NC;
+    const T *p = w.acc + q * N;
+    if (sizeof(T) == 4) {
+        constexpr uint32_t PB = N * 4;  // polynomial size in bytes; bit LOGN + 2 of a byte offset = the sign
+        const uint32_t poly_lds = w.acc_lds + (uint32_t)q * PB;
+        const uint32_t B = ((uint32_t)(t - a) & (2 * N - 1)) * 4;
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int K = 64 * m + h * NC;
+                const uint32_t x = B + (uint32_t)K * 4;
+                const uint32_t src = tfhe_lds_load32(w.smem, tfhe_and_or(x, PB - 4, poly_lds));
+                const uint32_t s = tfhe_sign_mask<LOGN + 2>(x);
+                const uint32_t v = (tfhe_xad(src, s, (uint32_t)offset - (uint32_t)p[t + K]) - s) ^ (uint32_t)flip;
+                if (h == 0)
+                    lo[m] = (U)v;
+                else
+                    hi[m] = (U)v;
+            }
+        }
+    } else {
+        int base = (t - a) & (2 * N - 1);
+        TFHE_OPAQUE(base);  // one add per coefficient; expanded, the index terms outlive the transforms and spill
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int K = 64 * m + h * NC;
+                const int idx = base + K;
+                const U src = (U)p[idx & (N - 1)];
+                const U rot = (idx & N) ? (U)(0 - src) : src;
+                const U v = ((rot - (U)p[t + K]) + offset) ^ flip;
+                if (h == 0)
+                    lo[m] = v;
+                else
+                    hi[m] = v;
+            }
+        }
+    }
 }
 
 // One CMux step on the wave's accumulator:
 //   rotate:  acc <- bk_row (x) ((X^a - 1) * acc) + acc   (tfhe_MuxRotate_FFT, a != 0)
 //   !rotate: acc <- bk_row (x) acc                       (tGswFFTExternMulToTLwe)
 // `rotate` is wave-uniform.  bkrow: device layout [2l][2][PPL][64] complex, pre-scaled by 2/N.
-// The 2l inverse transforms run one at a time (their key row is prefetched into registers
+// The inverse transforms run PAIR digits at a time (their key row is prefetched into registers
 // under the transform); the two forward transforms run together, in place on the Fourier
 // accumulator, sharing every twiddle read.
-// LC: the gadget length when it is known at compile time (0: read gd.l) -- the gate set's l = 2 with
-// digits in pairs then has one transform group per polynomial and no odd-digit path in the loop body.
-template <typename T, int LOGN, int PAIR, class TW, int LC = 0>
-TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
+// LC: the gadget length when it is known at compile time (0: read gd.l); BGC: likewise Bgbit.  With
+// LC == PAIR (the gate set: l = 2 in one pair) each polynomial is one transform group and the two
+// groups are unrolled: no loop-carried Fourier accumulator (its zero-initialisation disappears into the
+// first multiply), key-row addresses become immediates.
+template <typename T, int LOGN, int PAIR, int LC = 0, int BGC = 0>
+TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
                            const Gadget &gd, int t) {
     using G = Geom<LOGN>;
     using U = typename Torus<T>::U;
@@ -606,38 +575,23 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
     const U offset = (U)gd.offset, flip = (U)gd.flip;
 
     double fr[2][PPL], fi[2][PPL];  // Fourier accumulator (tLweFFTClear)
-#pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int m = 0; m < PPL; m++) fr[q][m] = fi[q][m] = 0.0;
-
-    // one iteration per group of PAIR digits of one accumulator polynomial.  The (rotated)
-    // coefficients are re-read from LDS for every group instead of being kept across groups:
-    // they then die at the digit extraction, which is what lets the transform pair + key row +
-    // Fourier accumulator fit the register file; for l == PAIR (the gate set) nothing is read twice.
+    constexpr bool UNROLLED = (LC > 0 && LC == PAIR);
     const int l = LC ? LC : gd.l;
     const int groups = (l + PAIR - 1) / PAIR;
-#pragma unroll 1
-    for (int g = 0; g < 2 * groups; g++) {
+
+    // one group = PAIR digits of one accumulator polynomial.  The (rotated) coefficients are re-read
+    // from LDS for every group instead of being kept across groups: they then die at the digit
+    // extraction, which is what lets the transform pair + key row + Fourier accumulator fit the
+    // register file; for l == PAIR (the gate set) nothing is read twice.
+    auto group = [&](int g, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
         const int q = (g >= groups) ? 1 : 0;
         const int d = (g - q * groups) * PAIR;
-        const T *p = w.acc + q * N;
         U lo[PPL], hi[PPL];  // coefficients j and j+N/2 of the (rotated) polynomial, offset added
-#ifdef TFHE_ABLATE
-        if (rotate && !TFHE_ABL(ABL_NO_ROTATE_READS)) {
-#else
         if (rotate) {
-#endif
-            int base = (t - a) & (2 * N - 1);
-            // recomputed in every group on purpose: hoisted out of the loop, the 4*PPL source indices
-            // and sign masks outlive the transforms and are spilled
-            TFHE_OPAQUE(base);
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                lo[m] = (rot_minus_one_hoisted<T, LOGN>(p, base, 64 * m, t) + offset) ^ flip;
-                hi[m] = (rot_minus_one_hoisted<T, LOGN>(p, base, 64 * m + NC, t) + offset) ^ flip;
-            }
+            rotated_minus_one<T, LOGN>(w, q, a, offset, flip, lo, hi, t);
         } else {
+            const T *p = w.acc + q * N;
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 const int j = G::jA(t, m);
@@ -647,14 +601,25 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
         }
         // p = bloc*l + i  (tgsw_functions.cpp:435-443); a trailing odd digit goes alone
         if (PAIR == 2 && ((LC && LC % 2 == 0) || d + 1 < l)) {
-            ifft_mac_digits<T, LOGN, 2, TW>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
+            ifft_mac_digits<T, LOGN, 2, BGC, FIRST>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         } else {
-            ifft_mac_digits<T, LOGN, 1, TW>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
+            ifft_mac_digits<T, LOGN, 1, BGC, FIRST>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         }
+    };
+    if (UNROLLED) {
+        group(0, std::true_type{});
+        group(1, std::false_type{});
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int m = 0; m < PPL; m++) fr[q][m] = fi[q][m] = 0.0;
+#pragma unroll 1
+        for (int g = 0; g < 2 * groups; g++) group(g, std::false_type{});
     }
     // back to coefficients (both polynomials together), round, accumulate into acc
     // (tLweFromFFTConvert + tLweAddTo)
-    WaveFFT<LOGN>::template fft<2, TW>(fr, fi, w.tw, w.xch, t);
+    WaveFFT<LOGN>::template fft<2, TwLds<LOGN>>(fr, fi, w.tw, w.xch, t);
     U r0[2][PPL], r1[2][PPL];
     bool exact_path = true;
     if (Torus<T>::HAS_FAST) {  // Torus32: short rounding sequence, valid while every |x| < 2^51
@@ -683,14 +648,16 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
     // (the wave-uniform `rotate` test sits outside the unrolled loops: inside them hipcc keeps one
     // scalar branch pair per store)
     if (rotate) {
+        // acc += result, in place in LDS: one DS add per coefficient (no read, no VALU add); every lane
+        // owns its coefficients, and the wave's DS operations execute in order
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            T *p = w.acc + q * N;
+            U *p = reinterpret_cast<U *>(w.acc + q * N);
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 const int j = G::jA(t, m);
-                p[j] = (T)((U)p[j] + r0[q][m]);
-                p[j + NC] = (T)((U)p[j + NC] + r1[q][m]);
+                TFHE_LDS_ADD(&p[j], r0[q][m]);
+                TFHE_LDS_ADD(&p[j + NC], r1[q][m]);
             }
         }
     } else {
@@ -706,16 +673,6 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN, TW> &w, const double2 *__restr
         }
     }
     TFHE_WAVE_FENCE();
-}
-
-template <int LOGN>
-TFHE_DEVICE void init_twiddles(TwLds<LOGN> &tw, const double2 *lds_table, const double2 *, int t) {
-    tw.tw = lds_table;
-    tw.t = t;
-}
-template <int LOGN>
-TFHE_DEVICE void init_twiddles(TwRegs<LOGN> &tw, const double2 *, const double2 *global_table, int t) {
-    tw.load(global_table, t);
 }
 
 // ----------------------------------------------------- blind-rotation kernel
@@ -764,13 +721,18 @@ TFHE_DEVICE int modswitch_2N(int32_t phase) {
     return (int)((((uint64_t)(uint32_t)phase << 32) + half) >> sh);
 }
 
-template <typename T, int LOGN, int WAVES, bool TWREG = false>
+template <typename T, int LOGN, int WAVES>
 struct BlindRotateLds {
     using G = Geom<LOGN>;
-    static constexpr size_t tw_bytes = TWREG ? 0 : sizeof(double2) * G::TW;
+    static constexpr size_t tw_bytes = sizeof(double2) * G::TW;
     static constexpr size_t acc_bytes = sizeof(T) * 2 * G::N;
     static constexpr size_t xch_bytes = sizeof(double) * G::XCH;
     static constexpr size_t wave_bytes = acc_bytes + xch_bytes;
+    // accumulators first (each polynomial then sits at a multiple of its own size, see WaveLds),
+    // then the twiddle table, then the transpose buffers
+    static constexpr size_t acc_at(int wave) { return (size_t)wave * acc_bytes; }
+    static constexpr size_t tw_at = WAVES * acc_bytes;
+    static constexpr size_t xch_at(int wave) { return tw_at + tw_bytes + (size_t)wave * xch_bytes; }
     static constexpr size_t total = tw_bytes + WAVES * wave_bytes;
 };
 
@@ -780,16 +742,15 @@ struct BlindRotateLds {
 #define TFHE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
 
-template <typename T, int LOGN, int WAVES, int PAIR, bool TWREG, int LC = 0>
+template <typename T, int LOGN, int WAVES, int PAIR, int LC = 0, int BGC = 0>
 TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T> A) {
     using G = Geom<LOGN>;
     using U = typename Torus<T>::U;
-    using Lds = BlindRotateLds<T, LOGN, WAVES, TWREG>;
-    using TW = typename std::conditional<TWREG, TwRegs<LOGN>, TwLds<LOGN>>::type;
+    using Lds = BlindRotateLds<T, LOGN, WAVES>;
     constexpr int N = G::N, PPL = G::PPL;
     TFHE_DYN_LDS(smem);
-    if (!TWREG) {
-        double2 *tw = reinterpret_cast<double2 *>(smem);
+    {
+        double2 *tw = reinterpret_cast<double2 *>(smem + Lds::tw_at);
         for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = A.tw[i];
         __syncthreads();
     }
@@ -799,11 +760,14 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
     const int ct = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
     if (ct >= A.batch) return;
 
-    WaveLds<T, LOGN, TW> w;
-    unsigned char *mine = smem + Lds::tw_bytes + (size_t)wave * Lds::wave_bytes;
-    w.acc = reinterpret_cast<T *>(mine);
-    w.xch = reinterpret_cast<double *>(mine + Lds::acc_bytes);
-    init_twiddles(w.tw, reinterpret_cast<const double2 *>(smem), A.tw, t);
+    WaveLds<T, LOGN> w;
+    w.smem = smem;
+    w.acc = reinterpret_cast<T *>(smem + Lds::acc_at(wave));
+    w.acc_lds = tfhe_lds_offset(w.acc);
+    if (w.acc_lds & (uint32_t)(sizeof(T) * N - 1)) TFHE_TRAP();  // rotated_minus_one relies on it: fail loudly
+    w.xch = WaveFFT<LOGN>::make_xch(reinterpret_cast<double *>(smem + Lds::xch_at(wave)), t);
+    w.tw.tw = reinterpret_cast<const double2 *>(smem + Lds::tw_at);
+    w.tw.t = t;
 
     const int32_t *rot = A.rot + (size_t)ct * A.rot_stride;
     // ---- accumulator initialisation
@@ -865,7 +829,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             a = TFHE_UNIFORM(a);
             if (a == 0) continue;  // :348-350
         }
-        cmux_step<T, LOGN, PAIR, TW, LC>(w, bkrow, a, rotate, A.gd, t);
+        cmux_step<T, LOGN, PAIR, LC, BGC>(w, bkrow, a, rotate, A.gd, t);
     }
 
     // ---- output
@@ -944,7 +908,8 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = twg[i];
     __syncthreads();
     if (!live) return;
-    double *xch = reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH;
+    const typename WaveFFT<LOGN>::Xch xch = WaveFFT<LOGN>::make_xch(
+        reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH, t);
     double xr[1][PPL], xi[1][PPL];
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
@@ -963,10 +928,8 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     // The reference's order has lane t holding PPL CONSECUTIVE outputs (jC): stored from there, every
     // store instruction would touch 64 different 128-byte lines.  One more pass through the wave's LDS
     // buffer turns it into the lane-contiguous order jA, 512 contiguous bytes per store instruction.
-    auto wC = [&](int m) { return G::idx2(G::jC(t, m)); };
-    auto rA = [&](int m) { return G::idx2(G::jA(t, m)); };
-    WaveFFT<LOGN>::template transpose<G::RD_A2>(xr[0], xch, wC, rA);
-    WaveFFT<LOGN>::template transpose<G::RD_A2>(xi[0], xch, wC, rA);
+    WaveFFT<LOGN>::template transpose<G::RD_C2, G::RD_A2>(xr[0], xch);
+    WaveFFT<LOGN>::template transpose<G::RD_C2, G::RD_A2>(xi[0], xch);
     double *o = out + (size_t)b * N;
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
@@ -1000,17 +963,16 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = twg[i];
     __syncthreads();
     if (!live) return;
-    double *xch = reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH;
+    const typename WaveFFT<LOGN>::Xch xch = WaveFFT<LOGN>::make_xch(
+        reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH, t);
 #pragma unroll
     for (int m = 0; m < PPL; m++) {
         xr[0][m] *= scale;
         xi[0][m] *= scale;
     }
     // into the transform's input order (lane t holds the PPL consecutive points jC) through LDS
-    auto wA = [&](int m) { return G::idx2(G::jA(t, m)); };
-    auto rC = [&](int m) { return G::idx2(G::jC(t, m)); };
-    WaveFFT<LOGN>::template transpose<G::RD_C2>(xr[0], xch, wA, rC);
-    WaveFFT<LOGN>::template transpose<G::RD_C2>(xi[0], xch, wA, rC);
+    WaveFFT<LOGN>::template transpose<G::RD_A2, G::RD_C2>(xr[0], xch);
+    WaveFFT<LOGN>::template transpose<G::RD_A2, G::RD_C2>(xi[0], xch);
     const TwLds<LOGN> twp{tw, t};
     WaveFFT<LOGN>::template fft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
     TOUT *o = out + (size_t)b * N;

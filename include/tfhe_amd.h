@@ -76,20 +76,15 @@ int tfhe_amd_device_info(int device, char *buf, size_t len);
 /* use an existing hipStream_t (passed as void*); NULL = the context's own stream */
 int tfhe_amd_set_stream(tfhe_amd_ctx *ctx, void *hip_stream);
 int tfhe_amd_sync(tfhe_amd_ctx *ctx);
-/* Scheduling options.  They select among kernels that compute the SAME results bit for bit; they
- * exist so the alternatives can be measured against each other on the hardware.
- *   TFHE_AMD_OPT_BR_VARIANT  blind-rotation kernel for N=1024/Torus32:
- *        0 (default) 8 waves per workgroup (2 per SIMD), twiddles in LDS, gadget digits in pairs
- *        1           4 waves per workgroup (1 per SIMD), twiddles held in registers, digits in pairs
- *        2           8 waves per workgroup, twiddles in LDS, digits one at a time
- *   TFHE_AMD_OPT_KS_GATHER   != 0: per-sample gather key switch instead of the batch-tiled kernel
- *   TFHE_AMD_OPT_KS_STREAM   != 0: key switch by the streaming kernel of the private key switch: 32-sample tiles
- *        (the key is read once per 32 samples instead of once per 16), partial sums through global atomics
+/* Scheduling options.  They select among kernels that compute the SAME results bit for bit.  (The
+ * blind-rotation schedule variants and the streamed key switch of round 1 were measured on MI355X and
+ * removed: profiles/r02_variants.txt.)
+ *   TFHE_AMD_OPT_KS_GATHER   != 0: per-sample gather key switch (the kernel for shapes the batch-tiled one
+ *        does not cover) even where the tiled kernel applies
  *   TFHE_AMD_OPT_FFT_WAVES   waves (= polynomials) per workgroup of the standalone transforms: 4 (default), 8, 12
  *   TFHE_AMD_OPT_STREAMED_GRAPH  != 0: tfhe_amd_bootstrap_streamed captures its n+3 launches into a hipGraph
  *        (after one plain call per schedule) and replays it while (x_d, out_d, mu, batch) repeat */
-enum { TFHE_AMD_OPT_BR_VARIANT = 1, TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_FFT_WAVES = 3, TFHE_AMD_OPT_STREAMED_GRAPH = 4,
-       TFHE_AMD_OPT_KS_STREAM = 5 };
+enum { TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_FFT_WAVES = 3, TFHE_AMD_OPT_STREAMED_GRAPH = 4 };
 int tfhe_amd_set_option(tfhe_amd_ctx *ctx, int option, int value);
 /* HIP events on the context's stream, for timing kernels without a HIP binding in the host
  * language: create, record (asynchronous), elapsed milliseconds between two recorded events

@@ -34,13 +34,17 @@ def gpu_present():
         return False
     top = "/sys/class/kfd/kfd/topology/nodes"
     try:
-        for node in os.listdir(top):
+        nodes = os.listdir(top)
+    except OSError:
+        return False
+    for node in nodes:  # the nodes of GPUs this container may not use are unreadable: skip them one by one
+        try:
             with open(os.path.join(top, node, "properties")) as f:
                 for line in f:
                     if line.startswith("simd_count") and int(line.split()[1]) > 0:
                         return True
-    except OSError:
-        pass
+        except (OSError, ValueError, IndexError):
+            continue
     return False
 
 

@@ -11,6 +11,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -48,6 +49,19 @@ using dim3 = emu::Dim3;
 #define TFHE_KEEP_BRANCH() ((void)0)
 #define TFHE_OPAQUE(x) ((void)0)
 #define TFHE_READLANE(v, lane) emu::readlane((v), (lane))
+#define TFHE_LDS_ADD(p, v) ((void)(*(p) += (v)))
+static inline uint32_t tfhe_and_or(uint32_t x, uint32_t m, uint32_t o) { return (x & m) | o; }
+template <int BIT>
+static inline uint32_t tfhe_sign_mask(uint32_t x) { return (uint32_t)0 - ((x >> BIT) & 1u); }
+static inline uint32_t tfhe_xad(uint32_t a, uint32_t b, uint32_t c) { return (a ^ b) + c; }
+// "LDS offsets" of the emulation are offsets from the workgroup's dynamic block
+static inline uint32_t tfhe_lds_offset(const void *p) { return (uint32_t)((const unsigned char *)p - emu::dyn_smem()); }
+static inline uint32_t tfhe_lds_load32(const void *, uint32_t off) {
+    uint32_t v;
+    memcpy(&v, emu::dyn_smem() + off, 4);
+    return v;
+}
+#define TFHE_TRAP() abort()
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu::launch([=]() { kernel(__VA_ARGS__); }, grid, block, smem)
 #define TFHE_LAUNCH_FLAT(kernel, grid, block, stream, ...) \

@@ -14,7 +14,7 @@ import oracle_py as O  # noqa: E402
 
 O.lib()
 T = importlib.import_module("experimental-tfhe_amd")
-if os.environ.get("TFHE_AMD_TEST_LIB"):  # check an experiment build (e.g. build.py --asm-lds) instead
+if os.environ.get("TFHE_AMD_TEST_LIB"):  # check an experiment build (tools/ab.py) instead
     T.DEFAULT_LIB = os.path.abspath(os.environ["TFHE_AMD_TEST_LIB"])
 import parity_checks as P  # noqa: E402
 
@@ -56,11 +56,10 @@ if max_stage >= 6:
     P.check_keyswitch_shapes(T.DEFAULT_LIB, 1024, 500, 6, 2, 9)
     say("   ok")
 if max_stage >= 7:
-    say("stage 7: schedule variants 1, 2 and rounding extremes")
-    for v in (1, 2):
-        P.check_gate_path(T.DEFAULT_LIB, N=1024, n=8, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=9, check_export=False, br_variant=v)
-    for v in (0, 1, 2):
-        P.check_rounding_extremes(T.DEFAULT_LIB, v)
+    say("stage 7: run-time gadget instantiations and rounding extremes")
+    P.check_gate_path(T.DEFAULT_LIB, N=1024, n=8, l=2, Bgbit=9, ks_t=8, ks_bb=2, B=9, check_export=False)
+    P.check_gate_path(T.DEFAULT_LIB, N=1024, n=5, l=4, Bgbit=6, ks_t=8, ks_bb=2, B=5, check_export=False)
+    P.check_rounding_extremes(T.DEFAULT_LIB)
     say("   ok")
 if max_stage >= 8:
     say("stage 8: circuit bootstrap pipeline (private key switch), N2=2048")

@@ -30,8 +30,7 @@ class GateSetup:
     """keys + engine for one Torus32 parameter set; keys come from the ORACLE's generator and
     are cross-checked against the library's own generator (same PRNG specification)."""
 
-    def __init__(self, lib_path, N, n, l, Bgbit, ks_t, ks_bb, bk_stdev=2.0 ** -25, ks_stdev=2.0 ** -15, seed=SEED,
-                 br_variant=0):
+    def __init__(self, lib_path, N, n, l, Bgbit, ks_t, ks_bb, bk_stdev=2.0 ** -25, ks_stdev=2.0 ** -15, seed=SEED):
         self.N, self.n, self.l, self.Bgbit, self.ks_t, self.ks_bb = N, n, l, Bgbit, ks_t, ks_bb
         self.lib_path, self.seed = lib_path, seed
         self.lwe_key = O.keygen_binary(n, seed, 1)
@@ -40,7 +39,6 @@ class GateSetup:
         self.ks = O.ks_create32(self.tkey, self.lwe_key, ks_t, ks_bb, ks_stdev, seed, 100000)
         self.bk_stdev, self.ks_stdev = bk_stdev, ks_stdev
         self.eng = T.Engine(torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=ks_t, ks_basebit=ks_bb, lib_path=lib_path)
-        self.eng.set_option(T.OPT_BR_VARIANT, br_variant)  # same arithmetic, different schedule
         self.gsw = self.eng.gsw_from_fft(self.bk)
         self.eng.set_bootstrap_key(self.gsw)
         self.eng.load_keyswitch_key(self.ks)
@@ -101,9 +99,9 @@ def check_fft_plugin(lib_path, N, count=4, seed=11, fft_waves=4):
 
 
 # ------------------------------------------------------------ Torus32 path
-def check_gate_path(lib_path, N, n, l, Bgbit, ks_t, ks_bb, B, seed=21, check_export=True, br_variant=0):
+def check_gate_path(lib_path, N, n, l, Bgbit, ks_t, ks_bb, B, seed=21, check_export=True):
     rs = np.random.RandomState(seed)
-    s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb, br_variant=br_variant)
+    s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb)
     e = s.eng
     try:
         # harness parity: the library's key generator == the oracle's (same PRNG spec)
@@ -328,7 +326,7 @@ def check_exact_extprod(lib_path, torus_bits=32, N=1024, l=2, Bgbit=10, B=3, see
 
 
 # ------------------------------------------------------- rounding range extremes
-def check_rounding_extremes(lib_path, br_variant=0):
+def check_rounding_extremes(lib_path):
     """Torus32 rounding has a short sequence valid for |x| < 2^51 and an exact fallback (DESIGN.md,
     bit-exactness rules).  Drive the external product to its worst-case magnitude 2*l*N*(Bg/2)*2^31 =
     2^52: all digits -Bg/2, all key coefficients -2^31, which no random input
@@ -339,7 +337,6 @@ def check_rounding_extremes(lib_path, br_variant=0):
     rs = np.random.RandomState(77)
     e = T.Engine(torus_bits=32, n=3, N=N, l=l, Bgbit=Bgbit, ks_t=0, lib_path=lib_path)
     try:
-        e.set_option(T.OPT_BR_VARIANT, br_variant)
         coef = np.full((3, 2 * l, 2, N), -2 ** 31, np.int64)
         coef[1] = rs.randint(-2 ** 31, 2 ** 31, size=(2 * l, 2, N))           # ordinary key
         coef[2, :, :, ::2] = 2 ** 31 - 1                                        # alternating extremes
@@ -415,8 +412,6 @@ def check_keyswitch_shapes(lib_path, N, n_out, ks_t, ks_bb, B, seed=51):
             e.set_option(T.OPT_KS_GATHER, force_gather)
             assert np.array_equal(e.keyswitch(x), want), f"key switch (gather={force_gather})"
         e.set_option(T.OPT_KS_GATHER, 0)
-        e.set_option(T.OPT_KS_STREAM, 1)   # 64-sample tiles through the private-key-switch kernel
-        assert np.array_equal(e.keyswitch(x), want), "key switch (stream)"
-        assert np.array_equal(e.keyswitch(x[:1]), want[:1]), "key switch (stream), one sample"
+        assert np.array_equal(e.keyswitch(x[:1]), want[:1]), "key switch, one sample"
     finally:
         e.close()

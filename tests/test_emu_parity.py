@@ -22,18 +22,14 @@ def test_gate_path_emu_n1024(emu_lib):
     P.check_gate_path(emu_lib, N=1024, n=6, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=3)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-def test_gate_path_emu_schedule_variants(emu_lib, variant):
-    """TFHE_AMD_OPT_BR_VARIANT: register-resident twiddles / unpaired digits give the same bits"""
-    P.check_gate_path(emu_lib, N=1024, n=4, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=5, check_export=False,
-                      br_variant=variant)
-    P.check_gate_path(emu_lib, N=1024, n=2, l=3, Bgbit=7, ks_t=8, ks_bb=2, B=2, check_export=False, seed=9,
-                      br_variant=variant)
+def test_rounding_extremes_emu(emu_lib):
+    P.check_rounding_extremes(emu_lib)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
-def test_rounding_extremes_emu(emu_lib, variant):
-    P.check_rounding_extremes(emu_lib, variant)
+def test_gate_path_emu_runtime_gadget(emu_lib):
+    """l = 2 with a Bgbit the kernel has no compile-time instantiation for, and l = 4 (two digit pairs per polynomial)"""
+    P.check_gate_path(emu_lib, N=1024, n=3, l=2, Bgbit=9, ks_t=8, ks_bb=2, B=3, check_export=False, seed=12)
+    P.check_gate_path(emu_lib, N=1024, n=2, l=4, Bgbit=6, ks_t=8, ks_bb=2, B=2, check_export=False, seed=13)
 
 
 def test_gate_path_emu_other_gadgets(emu_lib):

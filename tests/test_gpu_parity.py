@@ -63,19 +63,17 @@ def test_gate_path_other_gadgets(gpu_lib):
     P.check_gate_path(gpu_lib, N=2048, n=5, l=2, Bgbit=9, ks_t=4, ks_bb=3, B=7, seed=7)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-def test_gate_path_schedule_variants(gpu_lib, variant):
-    """the alternative blind-rotation schedules (TFHE_AMD_OPT_BR_VARIANT) are bit-identical too"""
-    P.check_gate_path(gpu_lib, N=1024, n=630, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=9, check_export=False,
-                      br_variant=variant)
-    P.check_gate_path(gpu_lib, N=1024, n=6, l=3, Bgbit=7, ks_t=8, ks_bb=2, B=5, check_export=False, seed=9,
-                      br_variant=variant)
+def test_gate_path_runtime_gadget(gpu_lib):
+    """the instantiations that read the gadget at run time: l = 2 with another Bgbit, l = 4 (two digit pairs
+    per polynomial), and the circuit bootstrap's output gadget (l = 2, Bgbit = 8: compile-time too)"""
+    P.check_gate_path(gpu_lib, N=1024, n=6, l=2, Bgbit=9, ks_t=8, ks_bb=2, B=9, check_export=False, seed=12)
+    P.check_gate_path(gpu_lib, N=1024, n=5, l=4, Bgbit=6, ks_t=8, ks_bb=2, B=5, check_export=False, seed=13)
+    P.check_gate_path(gpu_lib, N=1024, n=7, l=2, Bgbit=8, ks_t=8, ks_bb=2, B=9, check_export=False, seed=14)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
-def test_rounding_extremes(gpu_lib, variant):
+def test_rounding_extremes(gpu_lib):
     """worst-case magnitude 2^52 of the external product: exact fallback of the Torus32 rounding"""
-    P.check_rounding_extremes(gpu_lib, variant)
+    P.check_rounding_extremes(gpu_lib)
 
 
 def test_gate_path_full_parameters(gpu_lib):

@@ -21,7 +21,7 @@ struct Stamp { unsigned long long cyc, real; };
 
 enum Op { FMA64, ADD64, MUL64, FMA64NEG, FMA32, ADDU32, SUBU32, XOR32, AND32, LSHL32, ASHR32, BFEI32, BFEU32, CNDMASK, LSHLADD,
           CVT64I32, TRUNC64, CVTI32F64, DPPMOV, PERM32SWAP, PERM16SWAP, MIX_F64_INT, MIX_F64_2INT, DSW64, DSW2_64, DSR64, DSR2_64, DSR128,
-          DSW64_FMA2, DSR64_FMA2, NOPS };
+          DSW64_FMA2, DSR64_FMA2, NOPS, DEP1, DEP2, DEP4, BFLY, BFLY_LDS };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_issue(Stamp *out, int iters, double seed) {
@@ -171,6 +171,41 @@ __global__ void __launch_bounds__(256) k_issue(Stamp *out, int iters, double see
 #undef X
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             a0 += q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;
+        } else if (OP == DEP1) {   // every fma depends on the previous one
+#define X(k) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a0) : "v"(b), "v"(c));
+            REP128(X)
+#undef X
+        } else if (OP == DEP2) {   // two interleaved chains
+#define X(k) asm volatile("v_fma_f64 %0, %0, %2, %3\n\tv_fma_f64 %1, %1, %2, %3" : "+v"(a0), "+v"(a1) : "v"(b), "v"(c));
+            REP64(X)
+#undef X
+        } else if (OP == DEP4) {   // four interleaved chains
+#define X(k) asm volatile("v_fma_f64 %0, %0, %4, %5\n\tv_fma_f64 %1, %1, %4, %5\n\tv_fma_f64 %2, %2, %4, %5\n\tv_fma_f64 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));
+            REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+        } else if (OP == BFLY || OP == BFLY_LDS) {
+            // compiler-scheduled radix-2 DIF butterflies on 8 complex values (3 stages = 12 butterflies
+            // = 96 fp64 instructions), as the kernel's register passes; BFLY_LDS adds 8 LDS twiddle reads
+            double xr[8] = {a0, a1, a2, a3, a4, a5, a6, a7}, xi[8] = {a7, a6, a5, a4, a3, a2, a1, a0};
+            const double2 *twl = reinterpret_cast<const double2 *>(smem);
+#pragma unroll
+            for (int rep = 0; rep < 4; rep++) {
+#pragma unroll
+                for (int s_ = 4; s_ >= 1; s_ >>= 1)
+#pragma unroll
+                    for (int m = 0; m < 8; m++) {
+                        if (m & s_) continue;
+                        double cw = b, sw = c;
+                        if (OP == BFLY_LDS) { const double2 w2 = twl[(t & 63) + 64 * ((m + s_ + rep) & 7)]; cw = w2.x; sw = w2.y; }
+                        const double sr = xr[m] + xr[m + s_], si = xi[m] + xi[m + s_];
+                        const double dr = xr[m] - xr[m + s_], di = xi[m] - xi[m + s_];
+                        xr[m] = sr; xi[m] = si;
+                        xr[m + s_] = __builtin_fma(-di, sw, dr * cw);
+                        xi[m + s_] = __builtin_fma(di, cw, dr * sw);
+                    }
+            }
+            a0 = xr[0]; a1 = xr[1]; a2 = xr[2]; a3 = xr[3]; a4 = xr[4]; a5 = xr[5]; a6 = xr[6]; a7 = xr[7];
+            i0 += (int)(xi[0] + xi[1] + xi[2] + xi[3] + xi[4] + xi[5] + xi[6] + xi[7]);
         } else if (OP == NOPS) {
 #define X(k) asm volatile("s_nop 0");
             REP128(X)
@@ -215,12 +250,13 @@ int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 2000;
     Stamp *d_out;
     CHECK(hipMalloc(&d_out, sizeof(Stamp) * 256 * 8 * 4));
-    for (int k : {1, 2, 3, 4}) {
+    for (int k : {1, 2}) {
 #define R(OP, n) run<OP>(#OP, n, k, d_out, iters);
         R(FMA64, 128) R(FMA64NEG, 128) R(ADD64, 128) R(MUL64, 128) R(CVT64I32, 128) R(CVTI32F64, 128) R(TRUNC64, 128)
         R(FMA32, 128) R(ADDU32, 128) R(SUBU32, 128) R(XOR32, 128) R(AND32, 128) R(LSHL32, 128) R(ASHR32, 128) R(BFEI32, 128) R(BFEU32, 128)
         R(CNDMASK, 128) R(LSHLADD, 128) R(DPPMOV, 128) R(PERM32SWAP, 128) R(PERM16SWAP, 128) R(NOPS, 128)
         R(MIX_F64_INT, 64) R(MIX_F64_2INT, 64)
+        R(DEP1, 128) R(DEP2, 128) R(DEP4, 128) R(BFLY, 384) R(BFLY_LDS, 384)
         R(DSW64, 128) R(DSW2_64, 128) R(DSR64, 128) R(DSR2_64, 128) R(DSR128, 128) R(DSW64_FMA2, 64) R(DSR64_FMA2, 64)
         printf("\n");
     }
