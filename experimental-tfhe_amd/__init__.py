@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libtfhe_amd.so")
 
 OK, ERR_PARAM, ERR_DEVICE, ERR_STATE, ERR_ALLOC = range(5)
-OPT_KS_GATHER, OPT_FFT_WAVES, OPT_STREAMED_GRAPH = 2, 3, 4
+OPT_KS_GATHER, OPT_STREAMED_GRAPH = 2, 4
 
 # every symbol include/tfhe_amd.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -229,7 +229,7 @@ class Engine:
         return self.alloc(max(arr.nbytes, 1)).upload(arr)
 
     def set_option(self, option, value):
-        """TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_FFT_WAVES = 3, TFHE_AMD_OPT_STREAMED_GRAPH = 4 (include/tfhe_amd.h)"""
+        """TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_STREAMED_GRAPH = 4 (include/tfhe_amd.h)"""
         self._chk(self.lib.tfhe_amd_set_option(self.ctx, option, value))
 
     def sync(self):

@@ -70,6 +70,10 @@ __device__ __forceinline__ uint32_t tfhe_lds_load32(const void *, uint32_t off) 
     return *(lds_u32 *)(uintptr_t)off;
 }
 #define TFHE_TRAP() __builtin_trap()
+// D = A(32x32 int8) * B(32x32 int8) + C(32x32 int32) on the matrix cores, one wave.  Lane l holds
+// A[row l & 31][k = 16 * (l >> 5) + 0..15] and B[k = 16 * (l >> 5) + 0..15][col l & 31] as 16 bytes each;
+// C/D: column l & 31, row (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).
+#define TFHE_MFMA_I8(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8((a), (b), (c), 0, 0, 0)
 // value of `v` held by lane `lane` (wave-uniform lane index) -> scalar register
 #define TFHE_READLANE(v, lane) __builtin_amdgcn_readlane((v), (lane))
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \

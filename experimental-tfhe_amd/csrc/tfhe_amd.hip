@@ -36,6 +36,7 @@ struct tfhe_amd_ctx {
     const tfhe_amd_gsw *bk;
     int32_t *ks_d;   // reference layout [N][t][base][n_out+1]
     int32_t *ksd_d;  // tiled-kernel layout [N][t][base-1][rowp] (null: shape not covered, use the gather kernel)
+    int8_t *ksm_d;   // matrix-core layout [hblocks][N*KPI][4][64][16] int8 (null: shape not covered)
     // growable scratch
     void *ws_lwe;
     size_t ws_lwe_bytes;
@@ -43,8 +44,7 @@ struct tfhe_amd_ctx {
     size_t ws_acc_bytes;
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
-    bool ks_force_gather;  // TFHE_AMD_OPT_KS_GATHER: per-sample gather kernel even when the tiled one applies
-    int fft_waves;         // TFHE_AMD_OPT_FFT_WAVES
+    int ks_force_gather;   // TFHE_AMD_OPT_KS_GATHER: 0 matrix-core kernel, 1 per-sample gather kernel, 2 batch-tiled kernel
     // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
     // hipGraph and replayed while the call's arguments stay the same
     bool streamed_graph;
@@ -54,7 +54,7 @@ struct tfhe_amd_ctx {
         const void *x, *out;
         int32_t mu;
         int batch;
-        bool ks_gather;
+        int ks_gather;
     } sg;
     std::vector<const void *> lds_configured;  // kernels whose dynamic-LDS limit is raised on this device
 };
@@ -199,15 +199,12 @@ int launch_ifft_w(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
-// waves per workgroup of the standalone transforms (TFHE_AMD_OPT_FFT_WAVES): the twiddle table is
-// staged once per workgroup, so more waves amortise it and raise the resident-wave count per CU
+// 4 waves (= polynomials) per workgroup: measured against 8 and 12 on MI355X (profiles/r02_config4_fft.jsonl),
+// 4 is fastest at N=2048 (0.55-0.64 of 8 TB/s vs 0.40-0.56) and within 4 % of the best at N=1024
+constexpr int FFT_WAVES = 4;
 template <typename TIN, int LOGN, bool PACK = false>
 int launch_ifft_t(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
-    switch (c->fft_waves) {
-        case 8: return launch_ifft_w<TIN, LOGN, PACK, 8>(c, out_d, in_d, batch);
-        case 12: return launch_ifft_w<TIN, LOGN, PACK, 12>(c, out_d, in_d, batch);
-        default: return launch_ifft_w<TIN, LOGN, PACK, 4>(c, out_d, in_d, batch);
-    }
+    return launch_ifft_w<TIN, LOGN, PACK, FFT_WAVES>(c, out_d, in_d, batch);
 }
 template <typename TOUT, int LOGN, int WAVES>
 int launch_fft_w(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
@@ -221,11 +218,7 @@ int launch_fft_w(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
 }
 template <typename TOUT, int LOGN>
 int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
-    switch (c->fft_waves) {
-        case 8: return launch_fft_w<TOUT, LOGN, 8>(c, out_d, in_d, batch);
-        case 12: return launch_fft_w<TOUT, LOGN, 12>(c, out_d, in_d, batch);
-        default: return launch_fft_w<TOUT, LOGN, 4>(c, out_d, in_d, batch);
-    }
+    return launch_fft_w<TOUT, LOGN, FFT_WAVES>(c, out_d, in_d, batch);
 }
 
 void drop_streamed_graph(tfhe_amd_ctx *c) {
@@ -294,6 +287,42 @@ int launch_ks_tiled(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int ba
         case 1: return launch_ks_tiled_n<1>(c, out_d, in_d, batch);
         case 4: return launch_ks_tiled_n<4>(c, out_d, in_d, batch);
         default: return launch_ks_tiled_n<5>(c, out_d, in_d, batch);
+    }
+}
+
+// ---- key switch on the matrix cores (k_ks_mfma): any row length, basebit 1..3, t * basebit <= 32,
+// t * base <= 96
+bool ks_mfma_supported(int t, int bb) { return bb >= 1 && bb <= 3 && t * bb <= 32 && ks_mfma_kpi(t, bb) <= 3; }
+size_t ks_mfma_bytes(int n_in, int t, int bb, int row_ints) {
+    return (size_t)((row_ints + 31) / 32) * ks_mfma_steps(n_in, ks_mfma_kpi(t, bb)) * 4096;
+}
+// tab_d: reference layout [n_in][t][base][row_ints] on the device
+int ks_mfma_pack(hipStream_t stream, int8_t *dst_d, const int32_t *tab_d, int n_in, int t, int bb, int row_ints) {
+    const int hblocks = (row_ints + 31) / 32;
+    const long long frags = (long long)hblocks * ks_mfma_steps(n_in, ks_mfma_kpi(t, bb)) * 256;
+    TFHE_LAUNCH_FLAT(k_ks_mfma_pack, dim3((unsigned)((frags + 255) / 256)), dim3(256), stream, dst_d, tab_d, n_in, t, bb,
+                     row_ints, hblocks, frags);
+    return hipGetLastError() == hipSuccess ? TFHE_AMD_OK : TFHE_AMD_ERR_DEVICE;
+}
+template <typename XT, int BB>
+int launch_ks_mfma_b(hipStream_t stream, const KsMfmaArgs &a, int kpi, unsigned grid) {
+    switch (kpi) {
+        case 1: TFHE_LAUNCH((k_ks_mfma<XT, BB, 1>), dim3(grid), dim3(256), 2 * 8 * 4096, stream, a); break;
+        case 2: TFHE_LAUNCH((k_ks_mfma<XT, BB, 2>), dim3(grid), dim3(256), 2 * 8 * 4096, stream, a); break;
+        default: TFHE_LAUNCH((k_ks_mfma<XT, BB, 3>), dim3(grid), dim3(256), 2 * 6 * 4096, stream, a); break;
+    }
+    return hipGetLastError() == hipSuccess ? TFHE_AMD_OK : TFHE_AMD_ERR_DEVICE;
+}
+template <typename XT>
+int launch_ks_mfma(hipStream_t stream, KsMfmaArgs a, int bb) {
+    a.hblocks = (a.row_ints + 31) / 32;
+    const int mtiles = (a.count + 255) / 256;
+    const unsigned grid = 8u * (unsigned)mtiles * (unsigned)((a.hblocks + 7) / 8);
+    const int kpi = ks_mfma_kpi(a.t, bb);
+    switch (bb) {
+        case 1: return launch_ks_mfma_b<XT, 1>(stream, a, kpi, grid);
+        case 2: return launch_ks_mfma_b<XT, 2>(stream, a, kpi, grid);
+        default: return launch_ks_mfma_b<XT, 3>(stream, a, kpi, grid);
     }
 }
 
@@ -456,8 +485,8 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->bk = nullptr;
     c->ks_d = nullptr;
     c->ksd_d = nullptr;
-    c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") != nullptr;
-    c->fft_waves = 4;
+    c->ksm_d = nullptr;
+    c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") ? atoi(getenv("TFHE_AMD_KS_GATHER")) : 0;
     c->streamed_graph = false;
     c->streamed_warm = 0;
     memset(&c->sg, 0, sizeof(c->sg));
@@ -511,6 +540,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     if (c->tw_d) (void)hipFree(c->tw_d);
     if (c->ks_d) (void)hipFree(c->ks_d);
     if (c->ksd_d) (void)hipFree(c->ksd_d);
+    if (c->ksm_d) (void)hipFree(c->ksm_d);
     if (c->ws_lwe) (void)hipFree(c->ws_lwe);
     if (c->ws_acc) (void)hipFree(c->ws_acc);
     if (c->vp_rot_d) (void)hipFree(c->vp_rot_d);
@@ -548,14 +578,10 @@ int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
     if (!c) return TFHE_AMD_ERR_PARAM;
     switch (option) {
         case TFHE_AMD_OPT_KS_GATHER:
-            c->ks_force_gather = value != 0;
+            c->ks_force_gather = value;
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_STREAMED_GRAPH:
             c->streamed_graph = value != 0;
-            return TFHE_AMD_OK;
-        case TFHE_AMD_OPT_FFT_WAVES:
-            REQUIRE(c, value == 4 || value == 8 || value == 12, "transform kernels are built for 4, 8 or 12 waves per workgroup");
-            c->fft_waves = value;
             return TFHE_AMD_OK;
         default:
             return fail(c, TFHE_AMD_ERR_PARAM, "unknown option");
@@ -767,6 +793,11 @@ int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *c, const int32_t *ks) {
                     (const int32_t *)c->ks_d, rows_out, base, c->p.ks_n_out + 1, rowp);
         HIPCHECK(c, hipGetLastError());
     }
+    if (ks_mfma_supported(c->p.ks_t, c->p.ks_basebit)) {
+        if (!c->ksm_d) HIPCHECK(c, hipMalloc((void **)&c->ksm_d, ks_mfma_bytes(c->p.N, c->p.ks_t, c->p.ks_basebit, c->p.ks_n_out + 1)));
+        if (int rc = ks_mfma_pack(c->stream, c->ksm_d, c->ks_d, c->p.N, c->p.ks_t, c->p.ks_basebit, c->p.ks_n_out + 1))
+            return fail(c, rc, "k_ks_mfma_pack launch");
+    }
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     return TFHE_AMD_OK;
 }
@@ -926,7 +957,25 @@ int tfhe_amd_keyswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int
     ENTER(c);
     if (!c->ks_d) return fail(c, TFHE_AMD_ERR_STATE, "no key-switch key");
     if (batch == 0) return TFHE_AMD_OK;
-    if (c->ksd_d && !c->ks_force_gather) return launch_ks_tiled(c, out_d, in_d, batch);
+    if (c->ksm_d && c->ks_force_gather == 0) {
+        KsMfmaArgs a;
+        memset(&a, 0, sizeof(a));
+        a.out = out_d;
+        a.stride_in_group = c->p.ks_n_out + 1;
+        a.group = batch;
+        a.x = in_d;
+        a.bm = c->ksm_d;
+        a.x_stride = c->p.N + 1;
+        a.n_in = c->p.N;
+        a.t = c->p.ks_t;
+        a.row_ints = c->p.ks_n_out + 1;
+        a.count = batch;
+        a.b_index = c->p.N;
+        a.b_col = c->p.ks_n_out;
+        if (int rc = launch_ks_mfma<int32_t>(c->stream, a, c->p.ks_basebit)) return fail(c, rc, "k_ks_mfma launch");
+        return TFHE_AMD_OK;
+    }
+    if (c->ksd_d && c->ks_force_gather != 1) return launch_ks_tiled(c, out_d, in_d, batch);
     TFHE_LAUNCH_FLAT(k_keyswitch32, dim3(batch), dim3(256), c->stream, out_d, in_d, (const int32_t *)c->ks_d, c->p.N,
                 c->p.ks_n_out, c->p.ks_t, c->p.ks_basebit, batch);
     HIPCHECK(c, hipGetLastError());
@@ -994,7 +1043,7 @@ int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, con
         // and let the first call of each schedule variant run as plain launches
         if (int rc = grow(c, &c->ws_lwe, &c->ws_lwe_bytes, (size_t)batch * (c->p.N + 1) * 4)) return rc;
         if (int rc = grow(c, &c->ws_acc, &c->ws_acc_bytes, (size_t)batch * 2 * c->p.N * 4)) return rc;
-        const unsigned vbit = 1u << (c->ks_force_gather ? 1 : 0);
+        const unsigned vbit = 1u << c->ks_force_gather;
         if (!(c->streamed_warm & vbit)) {
             c->streamed_warm |= vbit;
             return streamed_plain(c, out_d, mu, x_d, batch);
@@ -1140,7 +1189,8 @@ struct tfhe_amd_cb {
     tfhe_amd_ctx *c10;  // Torus32, ring N1: preKeySwitch (n_in = N1 -> n_out = n0)
     tfhe_amd_ctx *c2;   // Torus64, ring N2, n = n0: modswitch to 2*N2, blind rotation
     tfhe_amd_gsw *bk;
-    int32_t *privks_d[2];
+    int32_t *privks_d[2];  // reference layout (kept only where the matrix-core kernel does not cover the shape)
+    int8_t *privksm_d[2];  // matrix-core layout (k_ks_mfma)
     void *ws_pre, *ws_abar, *ws_boot;
     size_t ws_pre_bytes, ws_abar_bytes, ws_boot_bytes;
     std::string err;
@@ -1180,6 +1230,25 @@ int launch_privks_t(tfhe_amd_cb *cb, int32_t *out_d, long long stride_in_group, 
 }
 int launch_privks(tfhe_amd_cb *cb, int32_t *out_d, long long stride_in_group, long long stride_of_group, int group, int u,
                   const int64_t *x_d, int count) {
+    if (cb->privksm_d[u]) {  // one dense int8 contraction on the matrix cores (tfhe_kernels.h, k_ks_mfma)
+        KsMfmaArgs a;
+        memset(&a, 0, sizeof(a));
+        a.out = out_d;
+        a.stride_in_group = stride_in_group;
+        a.stride_of_group = stride_of_group;
+        a.group = group;
+        a.x = x_d;
+        a.bm = cb->privksm_d[u];
+        a.x_stride = cb->p.N2 + 1;
+        a.n_in = cb->p.N2 + 1;  // the b coefficient is input n2 of the digit loop (poc:676-680)
+        a.t = cb->p.t21;
+        a.row_ints = 2 * cb->p.N1;
+        a.count = count;
+        a.b_index = 0;
+        a.b_col = -1;
+        if (launch_ks_mfma<int64_t>(cb->c2->stream, a, cb->p.bb21)) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "k_ks_mfma launch");
+        return TFHE_AMD_OK;
+    }
     const int32_t *tab = cb->privks_d[u];
     switch (cb->p.bb21) {
         case 1: return launch_privks_t<1>(cb, out_d, stride_in_group, stride_of_group, group, x_d, tab, count);
@@ -1203,6 +1272,7 @@ int tfhe_amd_cb_create(const tfhe_amd_cb_params *p, int device, tfhe_amd_cb **ou
     cb->p = *p;
     cb->bk = nullptr;
     cb->privks_d[0] = cb->privks_d[1] = nullptr;
+    cb->privksm_d[0] = cb->privksm_d[1] = nullptr;
     cb->ws_pre = cb->ws_abar = cb->ws_boot = nullptr;
     cb->ws_pre_bytes = cb->ws_abar_bytes = cb->ws_boot_bytes = 0;
     cb->c10 = cb->c2 = nullptr;
@@ -1221,8 +1291,10 @@ void tfhe_amd_cb_destroy(tfhe_amd_cb *cb) {
     if (!cb) return;
     if (cb->c2) (void)hipStreamSynchronize(cb->c2->stream);
     if (cb->bk) tfhe_amd_gsw_free(cb->bk);
-    for (int u = 0; u < 2; u++)
+    for (int u = 0; u < 2; u++) {
         if (cb->privks_d[u]) (void)hipFree(cb->privks_d[u]);
+        if (cb->privksm_d[u]) (void)hipFree(cb->privksm_d[u]);
+    }
     if (cb->ws_pre) (void)hipFree(cb->ws_pre);
     if (cb->ws_abar) (void)hipFree(cb->ws_abar);
     if (cb->ws_boot) (void)hipFree(cb->ws_boot);
@@ -1274,16 +1346,29 @@ int tfhe_amd_cb_load_privks_plane(tfhe_amd_cb *cb, int u, const int32_t *plane) 
     tfhe_amd_ctx *c = cb->c2;
     if (!cb->privks_d[u] && hipMalloc((void **)&cb->privks_d[u], bytes) != hipSuccess)
         return cb_fail(cb, TFHE_AMD_ERR_ALLOC, "hipMalloc(privKS plane)");
-    if (hipMemcpyAsync(cb->privks_d[u], plane, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess)
+    if (hipMemcpyAsync(cb->privks_d[u], plane, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
         return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "upload privKS plane");
+    if (ks_mfma_supported(cb->p.t21, cb->p.bb21)) {
+        // re-layout for the matrix-core kernel, then drop the reference-layout copy
+        const int n_in = cb->p.N2 + 1, row = 2 * cb->p.N1;
+        if (!cb->privksm_d[u] &&
+            hipMalloc((void **)&cb->privksm_d[u], ks_mfma_bytes(n_in, cb->p.t21, cb->p.bb21, row)) != hipSuccess)
+            return cb_fail(cb, TFHE_AMD_ERR_ALLOC, "hipMalloc(privKS plane, matrix-core layout)");
+        if (ks_mfma_pack(c->stream, cb->privksm_d[u], cb->privks_d[u], n_in, cb->p.t21, cb->p.bb21, row))
+            return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "k_ks_mfma_pack launch");
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "pack privKS plane");
+        (void)hipFree(cb->privks_d[u]);
+        cb->privks_d[u] = nullptr;
+        return TFHE_AMD_OK;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "upload privKS plane");
     return TFHE_AMD_OK;
 }
 
 int tfhe_amd_privks(tfhe_amd_cb *cb, int32_t *out_d, int u, const int64_t *x_d, int batch) {
     if (!cb || !out_d || !x_d || u < 0 || u > 1 || batch < 0) return TFHE_AMD_ERR_PARAM;
     if (hipSetDevice(cb->c2->device) != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "hipSetDevice");
-    if (!cb->privks_d[u]) return cb_fail(cb, TFHE_AMD_ERR_STATE, "privKS plane not loaded");
+    if (!cb->privks_d[u] && !cb->privksm_d[u]) return cb_fail(cb, TFHE_AMD_ERR_STATE, "privKS plane not loaded");
     if (batch == 0) return TFHE_AMD_OK;
     const long long row = 2LL * cb->p.N1;
     if (hipMemsetAsync(out_d, 0, (size_t)batch * row * 4, cb->c2->stream) != hipSuccess)
@@ -1294,7 +1379,7 @@ int tfhe_amd_privks(tfhe_amd_cb *cb, int32_t *out_d, int u, const int64_t *x_d, 
 int tfhe_amd_circuit_bootstrap(tfhe_amd_cb *cb, int32_t *out_d, const int32_t *x_d, int batch) {
     if (!cb || !out_d || !x_d || batch < 0) return TFHE_AMD_ERR_PARAM;
     if (hipSetDevice(cb->c2->device) != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "hipSetDevice");
-    if (!cb->bk || !cb->privks_d[0] || !cb->privks_d[1] || !cb->c10->ks_d)
+    if (!cb->bk || !(cb->privks_d[0] || cb->privksm_d[0]) || !(cb->privks_d[1] || cb->privksm_d[1]) || !cb->c10->ks_d)
         return cb_fail(cb, TFHE_AMD_ERR_STATE, "preKS, bk and both privKS planes must be loaded");
     if (batch == 0) return TFHE_AMD_OK;
     const tfhe_amd_cb_params &p = cb->p;

@@ -1481,13 +1481,233 @@ TFHE_GLOBAL void __launch_bounds__(THREADS)
         }
     }
 }
-// seeds the output of the streamed LWE key switch: (0, ..., 0, b)   (lweNoiselessTrivial, lwe_functions.cpp:141)
-TFHE_GLOBAL void k_ks_seed(int32_t *__restrict__ out, const int32_t *__restrict__ in, int n_in, int n_out, long long total) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const long long b = gid / (n_out + 1);
-    const int h = (int)(gid - b * (n_out + 1));
-    out[gid] = (h == n_out) ? in[b * (n_in + 1) + n_in] : 0;
+// ------------------------------------------------ key switch on the matrix cores
+// lweKeySwitch (lwe_functions.cpp:136-171), preKeySwitch (poc:437-465) and circuitPrivKS (poc:667-698)
+// are one dense contraction over exact integers:
+//     out[s][h] = seed[s][h] - sum_{i,j} tab[i][j][dig(s,i,j)][h]        (digit 0 contributes nothing)
+//               = seed[s][h] - sum_k A[s][k] * tab[k][h],   k = (i, j, d),  A[s][(i,j,d)] = [dig(s,i,j) == d]
+// A is a one-hot matrix generated in registers from the input words; tab is split into its four byte
+// limbs, each stored as (limb - 128) so that it is a signed int8 -- the digit-0 rows (value 0) as -128
+// too, so that EVERY (i,j) position contributes exactly one row and the bias is the constant
+// 128 * n_in * t per limb.  v_mfma_i32_32x32x32_i8 accumulates the limb sums exactly (|sum| <= 2^7 *
+// n_in * t < 2^31), the epilogue recombines them modulo 2^32: bit-identical to the reference's loop.
+// The key is read once per 256-sample tile instead of once per 16 (k_keyswitch_tiled) or 32 (k_privks).
+//
+// Key layout (built once at upload by k_ks_mfma_pack): Bm[hblock][kstep][limb][lane][16] int8 --
+// a 1 KB block is exactly the B operand of one MFMA (lane l: column h = 32*hblock + (l & 31), rows
+// k = 16*(l >> 5) + 0..15), so a workgroup streams its key slice with fully coalesced 16-byte loads.
+// K is laid out per input coefficient i in KPI = ceil(t * base / 32) steps of 32 (positions j >= t
+// are zero rows: the one-hot entries generated there multiply zeros).
+typedef int v4i __attribute__((vector_size(16)));
+typedef int v16i __attribute__((vector_size(64)));
+
+TFHE_HOST_DEVICE int ks_mfma_kpi(int t, int bb) { return (t * (1 << bb) + 31) / 32; }
+// K-steps per LDS buffer (a multiple of KPI) and the padded number of K-steps of a key slice (whole chunks;
+// the padding steps are zero blocks)
+TFHE_HOST_DEVICE int ks_mfma_chunk(int kpi) { return kpi == 3 ? 6 : 8; }
+TFHE_HOST_DEVICE int ks_mfma_steps(int n_in, int kpi) {
+    const int ch = ks_mfma_chunk(kpi);
+    return (n_in * kpi + ch - 1) / ch * ch;
+}
+
+TFHE_GLOBAL void k_ks_mfma_pack(int8_t *__restrict__ dst, const int32_t *__restrict__ tab, int n_in, int t, int bb,
+                                int row_ints, int hblocks, long long total_frags) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-byte fragment each
+    if (gid >= total_frags) return;
+    const int base = 1 << bb, kpi = ks_mfma_kpi(t, bb);
+    const int l = (int)(gid & 63), limb = (int)((gid >> 6) & 3);
+    const long long ksg = gid >> 8;  // hblock * steps + kstep
+    const long long steps = ks_mfma_steps(n_in, kpi);
+    const int hb = (int)(ksg / steps), ks = (int)(ksg - (long long)hb * steps);
+    const int i = ks / kpi, sub = ks - i * kpi;
+    const int h = hb * 32 + (l & 31);
+    int8_t bytes[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int kk = 32 * sub + 16 * (l >> 5) + j;
+        const int jj = kk >> bb, d = kk & (base - 1);
+        int v = 0;
+        if (i < n_in && jj < t && h < row_ints) {
+            const uint32_t w = d ? (uint32_t)tab[(((size_t)i * t + jj) * base + d) * row_ints + h] : 0u;
+            v = (int)((w >> (8 * limb)) & 255u) - 128;
+        }
+        bytes[j] = (int8_t)v;
+    }
+    int8_t *o = dst + gid * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j++) o[j] = bytes[j];
+}
+
+struct KsMfmaArgs {
+    int32_t *out;             // sample s -> out + (s % group) * stride_in_group + (s / group) * stride_of_group + h
+    long long stride_in_group, stride_of_group;
+    const void *x;            // [count][x_stride] input words (int32 or int64)
+    const int8_t *bm;         // packed key
+    int32_t group, x_stride, n_in, t, row_ints, hblocks, count;
+    int32_t b_index, b_col;   // seed: out[s][b_col] starts from x[s][b_index] (LWE key switch); b_col < 0: all zero (privKS)
+};
+
+// KPI = ks_mfma_kpi(t, BB) as a template parameter: a chunk of CH K-steps then covers CH / KPI whole input
+// coefficients, and which word and which digits a K-step needs is known at compile time.
+template <typename XT, int BB, int KPI>
+TFHE_GLOBAL void __launch_bounds__(256) k_ks_mfma(KsMfmaArgs A) {
+    using UX = typename std::make_unsigned<XT>::type;
+    constexpr int W = 8 * (int)sizeof(XT);
+    constexpr int CH = (KPI == 3) ? 6 : 8;  // K-steps per LDS buffer, a multiple of KPI (= ks_mfma_chunk)
+    constexpr int WPC = CH / KPI;           // input coefficients (words) per chunk
+    constexpr int TILE = 256;               // samples per workgroup: 4 waves x 2 row blocks x 32
+    TFHE_DYN_LDS(smem);                                               // 2 x CH x 4 KB
+    const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, r = lane & 31, hl = lane >> 5;
+    // workgroups that share a key slice (same hblock) get consecutive ids of one XCD (ids b, b+8, ...
+    // run on the same XCD): the slice is then served by that XCD's L2
+    const int mtiles = (A.count + TILE - 1) / TILE;
+    const int bid = blockIdx.x, y = bid >> 3;
+    const int hb = (bid & 7) + 8 * (y / mtiles), mt = y % mtiles;
+    if (hb >= A.hblocks) return;
+    const int steps = ks_mfma_steps(A.n_in, KPI), chunks = steps / CH;
+    const int s0 = mt * TILE + wave * 64;
+    const bool live = s0 < A.count;  // wave-uniform: a wave without samples only helps staging the key
+    const UX prec = (UX)1 << (W - (1 + BB * A.t));
+    const XT *xrow[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+        const int s = s0 + rb * 32 + r;
+        xrow[rb] = reinterpret_cast<const XT *>(A.x) + (size_t)(s < A.count ? s : A.count - 1) * A.x_stride;
+    }
+    // input words of one chunk: the WPC coefficients i its K-steps belong to.  Loaded raw (nothing may
+    // touch them until the chunk they are for: arithmetic here would wait for the loads, and with them for
+    // the key loads issued before); finish_words adds the rounding offset and keeps the 32 bits that carry
+    // the digits (t * BB <= 32)
+    auto load_words = [&](int c, UX (&w)[2][WPC]) {
+        const int i0 = c * WPC;
+#pragma unroll
+        for (int e = 0; e < WPC; e++) {
+            const int i = i0 + e;
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) w[rb][e] = (UX)xrow[rb][i < A.n_in ? i : A.n_in - 1];
+        }
+    };
+    auto finish_words = [&](uint32_t (&w)[2][WPC], const UX (&raw)[2][WPC]) {
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int e = 0; e < WPC; e++) w[rb][e] = (uint32_t)((UX)(raw[rb][e] + prec) >> (W - 32));
+    };
+    const v4i *gsrc = reinterpret_cast<const v4i *>(A.bm) + (size_t)hb * steps * 256;
+    auto load_key = [&](int c, v4i (&stage)[CH]) {
+#pragma unroll
+        for (int e = 0; e < CH; e++) stage[e] = gsrc[(size_t)(c * CH + e) * 256 + threadIdx.x];
+    };
+    auto store_key = [&](int buf, const v4i (&stage)[CH]) {
+        v4i *dst = reinterpret_cast<v4i *>(smem) + buf * (CH * 256);
+#pragma unroll
+        for (int e = 0; e < CH; e++) dst[e * 256 + threadIdx.x] = stage[e];
+    };
+    v16i acc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[rb][l][e] = 0;
+
+    uint32_t wcur[2][WPC];
+    UX wraw[2][WPC];
+    const int lane_shift = hl * ((16 >> BB) * BB);  // digit bits covered by the lower lane half's 16 k's
+    v4i stage[CH];
+    load_key(0, stage);
+    load_words(0, wraw);
+    finish_words(wcur, wraw);
+    store_key(0, stage);
+    __syncthreads();
+    // Two copies of the K loop, chosen once per wave: a wave without samples only stages the key.  (One
+    // loop with the MFMAs under a wave-uniform `if` makes hipcc move all 128 accumulators between the VGPR
+    // and AGPR halves of the register file on every chunk.)
+    auto k_loop = [&](auto compute_tag) {
+      constexpr bool COMPUTE = decltype(compute_tag)::value;
+#pragma unroll 1
+      for (int c = 0; c < chunks; c++) {
+        const bool more = c + 1 < chunks;
+        if (more) {  // next chunk's key slice and input words: in flight underneath this chunk's MFMAs
+            load_key(c + 1, stage);
+            load_words(c + 1, wraw);
+        }
+        const v4i *kb = reinterpret_cast<const v4i *>(smem) + (c & 1) * (CH * 256) + lane;
+        if (COMPUTE) {
+            // the B fragments (one ds_read_b128 per limb) of K-step e+1 are requested before the MFMAs of
+            // step e: their LDS latency runs under 8 MFMAs
+            v4i bf[2][4];
+#pragma unroll
+            for (int l = 0; l < 4; l++) bf[0][l] = kb[l * 64];
+#pragma unroll
+            for (int e = 0; e < CH; e++) {
+                if (e + 1 < CH) {
+#pragma unroll
+                    for (int l = 0; l < 4; l++) bf[(e + 1) & 1][l] = kb[((e + 1) * 4 + l) * 64];
+                }
+                const int sub = e % KPI;  // K-step inside its coefficient: first digit position ((32 * sub) >> BB) + (16 >> BB) * hl
+                v4i a[2];
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) {
+                    // first needed digit moved to the top of the word; digits at positions >= t select zero rows
+                    const uint32_t ws = wcur[rb][e / KPI] << ((((32 * sub) >> BB) * BB + lane_shift) & 31);
+                    if (BB == 2) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) a[rb][u] = (int)(1u << (((ws >> (27 - 2 * u)) & 0x18u)));
+                    } else if (BB == 3) {
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            const uint64_t one = 1ull << (((ws >> (29 - 3 * u)) & 7u) * 8u);
+                            a[rb][2 * u] = (int)(uint32_t)one;
+                            a[rb][2 * u + 1] = (int)(uint32_t)(one >> 32);
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const uint32_t d0 = (ws >> (31 - 2 * u)) & 1u, d1 = (ws >> (30 - 2 * u)) & 1u;
+                            a[rb][u] = (int)((1u << (8 * d0)) | (1u << (16 + 8 * d1)));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    acc[0][l] = TFHE_MFMA_I8(a[0], bf[e & 1][l], acc[0][l]);
+                    acc[1][l] = TFHE_MFMA_I8(a[1], bf[e & 1][l], acc[1][l]);
+                }
+            }
+        }
+        if (more) {
+            store_key((c + 1) & 1, stage);
+            finish_words(wcur, wraw);
+        }
+        __syncthreads();
+      }
+    };
+    if (live)
+        k_loop(std::true_type{});
+    else
+        k_loop(std::false_type{});
+    // epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int h = hb * 32 + r;
+    if (h >= A.row_ints) return;
+    const uint32_t bias = 128u * (uint32_t)A.n_in * (uint32_t)A.t;
+    if (!live) return;
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int s = s0 + rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+            if (s >= A.count) continue;
+            uint32_t sum = 0;
+#pragma unroll
+            for (int l = 0; l < 4; l++) sum += ((uint32_t)acc[rb][l][e] + bias) << (8 * l);
+            uint32_t seed = 0;
+            if (h == A.b_col) seed = (uint32_t)reinterpret_cast<const XT *>(A.x)[(size_t)s * A.x_stride + A.b_index];
+            A.out[(size_t)(s % A.group) * A.stride_in_group + (size_t)(s / A.group) * A.stride_of_group + h] =
+                (int32_t)(seed - sum);
+        }
+    }
 }
 
 }  // namespace tfhe

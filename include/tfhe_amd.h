@@ -77,14 +77,13 @@ int tfhe_amd_device_info(int device, char *buf, size_t len);
 int tfhe_amd_set_stream(tfhe_amd_ctx *ctx, void *hip_stream);
 int tfhe_amd_sync(tfhe_amd_ctx *ctx);
 /* Scheduling options.  They select among kernels that compute the SAME results bit for bit.  (The
- * blind-rotation schedule variants and the streamed key switch of round 1 were measured on MI355X and
- * removed: profiles/r02_variants.txt.)
+ * blind-rotation schedule variants, the streamed key switch and the wider transform workgroups of round 1
+ * were measured on MI355X and removed: profiles/r02_variants.txt, profiles/r02_config4_fft.jsonl.)
  *   TFHE_AMD_OPT_KS_GATHER   != 0: per-sample gather key switch (the kernel for shapes the batch-tiled one
  *        does not cover) even where the tiled kernel applies
- *   TFHE_AMD_OPT_FFT_WAVES   waves (= polynomials) per workgroup of the standalone transforms: 4 (default), 8, 12
  *   TFHE_AMD_OPT_STREAMED_GRAPH  != 0: tfhe_amd_bootstrap_streamed captures its n+3 launches into a hipGraph
  *        (after one plain call per schedule) and replays it while (x_d, out_d, mu, batch) repeat */
-enum { TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_FFT_WAVES = 3, TFHE_AMD_OPT_STREAMED_GRAPH = 4 };
+enum { TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_STREAMED_GRAPH = 4 };
 int tfhe_amd_set_option(tfhe_amd_ctx *ctx, int option, int value);
 /* HIP events on the context's stream, for timing kernels without a HIP binding in the host
  * language: create, record (asynchronous), elapsed milliseconds between two recorded events

@@ -33,6 +33,7 @@ struct Block {
     std::vector<int> lane_xchg;  // readlane: two slots per work-item, used alternately (one fence per call)
     std::vector<unsigned char> rl_phase;
     std::vector<int> any_xchg;   // wave_any
+    std::vector<int> mfma_xchg;  // mfma: 8 ints (A then B fragment) per work-item
     std::vector<Fiber> fibers;
     Rendezvous all;
     std::vector<Rendezvous> waves;
@@ -80,6 +81,7 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
     b.lane_xchg.assign((size_t)2 * nt, 0);
     b.rl_phase.assign(nt, 0);
     b.any_xchg.assign(nt, 0);
+    b.mfma_xchg.assign((size_t)8 * nt, 0);
     b.all.expected = (int)nt;
     b.waves.resize((nt + 63) / 64);
     for (unsigned w = 0; w < b.waves.size(); w++) b.waves[w].expected = (int)std::min(64u, nt - 64 * w);
@@ -140,6 +142,32 @@ int readlane(int v, int lane) {
     t_blk->lane_xchg[buf + tid] = v;
     wave_fence();
     return t_blk->lane_xchg[buf + (tid & ~63u) + (unsigned)lane];
+}
+
+// v_mfma_i32_32x32x32_i8: every lane publishes its A and B fragments, then computes its 16 results
+// (column lane & 31, rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); the second fence frees the slots
+v16i_t mfma_i32_32x32x32_i8(const v4i_t &a, const v4i_t &b, const v16i_t &c_in) {
+    v16i_t c = c_in;
+    const unsigned tid = t_threadIdx.x, base = tid & ~63u, lane = tid & 63u;
+    int *slot = &t_blk->mfma_xchg[(size_t)8 * tid];
+    for (int e = 0; e < 4; e++) {
+        slot[e] = a[e];
+        slot[4 + e] = b[e];
+    }
+    wave_fence();
+    const unsigned col = lane & 31u;
+    for (int e = 0; e < 16; e++) {
+        const unsigned row = (unsigned)((e & 3) + 8 * (e >> 2)) + 4u * (lane >> 5);
+        int sum = 0;
+        for (unsigned kh = 0; kh < 2; kh++) {
+            const signed char *ap = reinterpret_cast<const signed char *>(&t_blk->mfma_xchg[(size_t)8 * (base + row + 32 * kh)]);
+            const signed char *bp = reinterpret_cast<const signed char *>(&t_blk->mfma_xchg[(size_t)8 * (base + col + 32 * kh) + 4]);
+            for (int j = 0; j < 16; j++) sum += (int)ap[j] * (int)bp[j];
+        }
+        c[e] += sum;
+    }
+    wave_fence();
+    return c;
 }
 
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes) {

@@ -62,6 +62,12 @@ static inline uint32_t tfhe_lds_load32(const void *, uint32_t off) {
     return v;
 }
 #define TFHE_TRAP() abort()
+namespace emu {
+typedef int v4i_t __attribute__((vector_size(16)));
+typedef int v16i_t __attribute__((vector_size(64)));
+v16i_t mfma_i32_32x32x32_i8(const v4i_t &a, const v4i_t &b, const v16i_t &c);  // wave-collective, same operand maps as the hardware's
+}
+#define TFHE_MFMA_I8(a, b, c) emu::mfma_i32_32x32x32_i8((a), (b), (c))
 #define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu::launch([=]() { kernel(__VA_ARGS__); }, grid, block, smem)
 #define TFHE_LAUNCH_FLAT(kernel, grid, block, stream, ...) \

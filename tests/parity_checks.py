@@ -52,11 +52,10 @@ class GateSetup:
 
 
 # ---------------------------------------------------------------- L1 plugin
-def check_fft_plugin(lib_path, N, count=4, seed=11, fft_waves=4):
+def check_fft_plugin(lib_path, N, count=4, seed=11):
     rs = np.random.RandomState(seed)
     e = T.Engine(torus_bits=32, n=1, N=N, l=2, Bgbit=10, ks_t=0, lib_path=lib_path)
     try:
-        e.set_option(T.OPT_FFT_WAVES, fft_waves)
         f, r = e.tables()
         fo, ro = O.table_arrays(N)
         assert np.array_equal(f.view(np.uint64), fo.view(np.uint64)), "fft twiddle table"

@@ -12,10 +12,10 @@ def test_fft_plugin_emu(emu_lib, N):
     P.check_fft_plugin(emu_lib, N, count=3)
 
 
-@pytest.mark.parametrize("N,waves", [(1024, 8), (2048, 12)])
-def test_fft_plugin_wider_workgroups_emu(emu_lib, N, waves):
-    """TFHE_AMD_OPT_FFT_WAVES: more polynomials per workgroup, ragged last workgroup (count % waves != 0)"""
-    P.check_fft_plugin(emu_lib, N, count=waves + 1, fft_waves=waves)
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_fft_plugin_ragged_emu(emu_lib, N):
+    """ragged last workgroup (count % waves per workgroup != 0)"""
+    P.check_fft_plugin(emu_lib, N, count=5)
 
 
 def test_gate_path_emu_n1024(emu_lib):

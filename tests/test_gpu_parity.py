@@ -26,8 +26,6 @@ def golden():
 @pytest.mark.parametrize("N", [1024, 2048])
 def test_fft_plugin_vs_oracle(gpu_lib, N):
     P.check_fft_plugin(gpu_lib, N, count=37)  # ragged against 4 waves per workgroup
-    for waves in (8, 12):                     # TFHE_AMD_OPT_FFT_WAVES
-        P.check_fft_plugin(gpu_lib, N, count=37, fft_waves=waves)
 
 
 @pytest.mark.parametrize("N", [1024, 2048])

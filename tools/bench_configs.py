@@ -78,7 +78,6 @@ def bench_fft(T, a):
         if a.small:
             batch = 8
         eng = T.Engine(torus_bits=64 if N == 2048 else 32, n=1, N=N, l=2, Bgbit=8, ks_t=0, lib_path=a.lib)
-        eng.set_option(T.OPT_FFT_WAVES, a.fft_waves)
         lib = eng.lib
         i64 = eng.to_device(rand_bits(rs, (batch, N), np.int64))
         i32 = eng.to_device(rs.randint(-256, 256, size=(batch, N)).astype(np.int32))      # digits in [-256, 256)
@@ -94,7 +93,7 @@ def bench_fft(T, a):
                 eng._chk(lib.tfhe_amd_ifft_int32(eng.ctx, lag.ptr, i32.ptr, batch))
             best, mean = timed(eng, a.reps, fn)
             algo = batch * N * bytes_per_coef
-            lines.append({"workload": f"{name} N={N} batch={batch}", "waves_per_workgroup": a.fft_waves, "ms_min": best, "ms_mean": mean,
+            lines.append({"workload": f"{name} N={N} batch={batch}", "ms_min": best, "ms_mean": mean,
                           "polynomials_per_s": batch / (best * 1e-3),
                           "roofline": {"bound": "hbm", "achieved": algo / (best * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                        "unit": "GB/s", "frac": algo / (best * 1e-3) / HBM_PEAK,
@@ -184,7 +183,6 @@ def main():
                     help="LWE inputs per circuit-bootstrap launch (default 768 = one Torus64 N=2048 accumulator per wave, "
                          "3 waves per CU, 256 CUs: the smallest batch that fills the chip)")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--fft-waves", type=int, default=4, choices=[4, 8, 12], help="TFHE_AMD_OPT_FFT_WAVES")
     ap.add_argument("--lib", default=None)
     ap.add_argument("--small", action="store_true")
     a = ap.parse_args()
