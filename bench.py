@@ -112,7 +112,7 @@ def main():
                          "--gpus > 1: 2^20 (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--ks-gather", action="store_true", help="per-sample gather key switch instead of the tiled one")
+    ap.add_argument("--ks-gather", action="store_true", help="per-sample gather key switch instead of the matrix-core one")
     ap.add_argument("--lib", default=None,
                     help="alternative build of the engine library to time (A/B experiments, tools/ab.py); "
                          "default: the shipped libtfhe_amd.so")
@@ -292,7 +292,7 @@ def main():
                                    "blind-rotation kernel + key-switch kernel, inputs resident in HBM",
                        "batch_per_gpu": B, "total_per_step": total_per_step,
                        "parallelism": f"batch-sharded x{world} (contiguous slices), keys replicated, no data-path collective",
-                       "ks_kernel": "gather" if a.ks_gather else "tiled",
+                       "ks_kernel": "gather" if a.ks_gather else "matrix-core (k_ks_mfma)",
                        "library": os.path.basename(a.lib) if a.lib else "libtfhe_amd.so"},
             "roofline": {"bound": "hbm", "kernel": "k_blind_rotate<int32,N=1024>", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,

@@ -35,7 +35,6 @@ struct tfhe_amd_ctx {
     Gadget gd;
     const tfhe_amd_gsw *bk;
     int32_t *ks_d;   // reference layout [N][t][base][n_out+1]
-    int32_t *ksd_d;  // tiled-kernel layout [N][t][base-1][rowp] (null: shape not covered, use the gather kernel)
     int8_t *ksm_d;   // matrix-core layout [hblocks][N*KPI][4][64][16] int8 (null: shape not covered)
     // growable scratch
     void *ws_lwe;
@@ -44,7 +43,7 @@ struct tfhe_amd_ctx {
     size_t ws_acc_bytes;
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
-    int ks_force_gather;   // TFHE_AMD_OPT_KS_GATHER: 0 matrix-core kernel, 1 per-sample gather kernel, 2 batch-tiled kernel
+    int ks_force_gather;   // TFHE_AMD_OPT_KS_GATHER: != 0 per-sample gather kernel even where the matrix-core kernel applies
     // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
     // hipGraph and replayed while the call's arguments stay the same
     bool streamed_graph;
@@ -256,40 +255,6 @@ int pack_rows(tfhe_amd_ctx *c, double2 *dst_d, const double *src_d, long long ro
     return TFHE_AMD_OK;
 }
 
-// ---- batch-tiled key switch dispatch (k_keyswitch_tiled): shapes with an instantiation
-constexpr int KS_SPLIT = 8;
-int ks_nch(int n_out) { return (n_out + 1 + 127) / 128; }
-bool ks_tiled_supported(int n_out, int basebit) {
-    const int nch = ks_nch(n_out);
-    return (nch == 1 || nch == 4 || nch == 5) && basebit >= 1 && basebit <= 3;
-}
-template <int TB, int NCH, int BB>
-int launch_ks_tiled_t(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
-    using Lds = KsTiledLds<TB, NCH, BB, KS_SPLIT>;
-    const int tiles = (batch + TB - 1) / TB;
-    TFHE_LAUNCH((k_keyswitch_tiled<TB, NCH, BB, KS_SPLIT>), dim3(tiles), dim3(KS_SPLIT * 64), Lds::total, c->stream,
-                out_d, in_d, (const int32_t *)c->ksd_d, c->p.N, c->p.ks_n_out, c->p.ks_t, batch);
-    HIPCHECK(c, hipGetLastError());
-    return TFHE_AMD_OK;
-}
-template <int NCH>
-int launch_ks_tiled_n(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
-    // samples per tile: as many as keep accumulators + candidate rows in 256 VGPRs without spilling
-    constexpr int TB12 = 16, TB3 = 8;
-    switch (c->p.ks_basebit) {
-        case 1: return launch_ks_tiled_t<TB12, NCH, 1>(c, out_d, in_d, batch);
-        case 2: return launch_ks_tiled_t<TB12, NCH, 2>(c, out_d, in_d, batch);
-        default: return launch_ks_tiled_t<TB3, NCH, 3>(c, out_d, in_d, batch);
-    }
-}
-int launch_ks_tiled(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int batch) {
-    switch (ks_nch(c->p.ks_n_out)) {
-        case 1: return launch_ks_tiled_n<1>(c, out_d, in_d, batch);
-        case 4: return launch_ks_tiled_n<4>(c, out_d, in_d, batch);
-        default: return launch_ks_tiled_n<5>(c, out_d, in_d, batch);
-    }
-}
-
 // ---- key switch on the matrix cores (k_ks_mfma): any row length, basebit 1..3, t * basebit <= 32,
 // t * base <= 96
 bool ks_mfma_supported(int t, int bb) { return bb >= 1 && bb <= 3 && t * bb <= 32 && ks_mfma_kpi(t, bb) <= 3; }
@@ -484,7 +449,6 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->tw_d = nullptr;
     c->bk = nullptr;
     c->ks_d = nullptr;
-    c->ksd_d = nullptr;
     c->ksm_d = nullptr;
     c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") ? atoi(getenv("TFHE_AMD_KS_GATHER")) : 0;
     c->streamed_graph = false;
@@ -539,7 +503,6 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->tw_d) (void)hipFree(c->tw_d);
     if (c->ks_d) (void)hipFree(c->ks_d);
-    if (c->ksd_d) (void)hipFree(c->ksd_d);
     if (c->ksm_d) (void)hipFree(c->ksm_d);
     if (c->ws_lwe) (void)hipFree(c->ws_lwe);
     if (c->ws_acc) (void)hipFree(c->ws_acc);
@@ -783,16 +746,6 @@ int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *c, const int32_t *ks) {
     const size_t bytes = (size_t)c->p.N * c->p.ks_t * ((size_t)1 << c->p.ks_basebit) * (c->p.ks_n_out + 1) * 4;
     if (!c->ks_d) HIPCHECK(c, hipMalloc((void **)&c->ks_d, bytes));
     HIPCHECK(c, hipMemcpyAsync(c->ks_d, ks, bytes, hipMemcpyHostToDevice, c->stream));
-    if (ks_tiled_supported(c->p.ks_n_out, c->p.ks_basebit)) {
-        // re-layout for the batch-tiled kernel: drop the digit-0 rows, pad rows to 128-int chunks
-        const int base = 1 << c->p.ks_basebit, rowp = ks_nch(c->p.ks_n_out) * 128;
-        const long long rows_out = (long long)c->p.N * c->p.ks_t * (base - 1);
-        if (!c->ksd_d) HIPCHECK(c, hipMalloc((void **)&c->ksd_d, (size_t)rows_out * rowp * 4));
-        const long long total = rows_out * rowp;
-        TFHE_LAUNCH_FLAT(k_pack_ks, dim3((unsigned)((total + 255) / 256)), dim3(256), c->stream, c->ksd_d,
-                    (const int32_t *)c->ks_d, rows_out, base, c->p.ks_n_out + 1, rowp);
-        HIPCHECK(c, hipGetLastError());
-    }
     if (ks_mfma_supported(c->p.ks_t, c->p.ks_basebit)) {
         if (!c->ksm_d) HIPCHECK(c, hipMalloc((void **)&c->ksm_d, ks_mfma_bytes(c->p.N, c->p.ks_t, c->p.ks_basebit, c->p.ks_n_out + 1)));
         if (int rc = ks_mfma_pack(c->stream, c->ksm_d, c->ks_d, c->p.N, c->p.ks_t, c->p.ks_basebit, c->p.ks_n_out + 1))
@@ -975,7 +928,6 @@ int tfhe_amd_keyswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int
         if (int rc = launch_ks_mfma<int32_t>(c->stream, a, c->p.ks_basebit)) return fail(c, rc, "k_ks_mfma launch");
         return TFHE_AMD_OK;
     }
-    if (c->ksd_d && c->ks_force_gather != 1) return launch_ks_tiled(c, out_d, in_d, batch);
     TFHE_LAUNCH_FLAT(k_keyswitch32, dim3(batch), dim3(256), c->stream, out_d, in_d, (const int32_t *)c->ks_d, c->p.N,
                 c->p.ks_n_out, c->p.ks_t, c->p.ks_basebit, batch);
     HIPCHECK(c, hipGetLastError());

@@ -1216,157 +1216,6 @@ TFHE_GLOBAL void k_keyswitch32(int32_t *__restrict__ out, const int32_t *__restr
     }
 }
 
-// Batch-tiled key switch.  The gather above reads one 2.5 KB key row per non-zero digit per
-// sample (15.5 MB per gate bootstrap).  Here a workgroup owns a tile of TB samples and walks
-// the (i, j) digit positions once for all of them: the base-1 candidate rows of a position
-// are loaded once (coalesced 8-byte loads, rows padded to NCH*128 ints at upload), and each
-// sample of the tile subtracts the row its (wave-uniform, scalar) digit selects.  Key bytes
-// per sample drop by TB*(base-1)/base (12x for TB=16, base 4); the SPLIT waves of the
-// workgroup take disjoint i-ranges and are summed through LDS at the end.
-//   ksd: device layout [n_in][t][base-1][NCH*128] (digit 0 rows dropped, rows zero-padded)
-template <int TB, int NCH, int BB, int SPLIT>
-struct KsTiledLds {
-    static constexpr int ROWP = NCH * 128;
-    static constexpr size_t total = sizeof(int32_t) * (size_t)TB * ROWP;
-};
-
-template <int TB, int NCH, int BB, int SPLIT>
-TFHE_GLOBAL void __launch_bounds__(SPLIT * 64)
-    k_keyswitch_tiled(int32_t *__restrict__ out, const int32_t *__restrict__ in, const int32_t *__restrict__ ksd,
-                      int n_in, int n_out, int t, int batch) {
-    constexpr int ROWP = NCH * 128, NR = (1 << BB) - 1;
-    constexpr uint32_t mask = (1u << BB) - 1;
-    TFHE_DYN_LDS(smem);
-    uint32_t *red = reinterpret_cast<uint32_t *>(smem);  // [TB][ROWP] partial sums
-    const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const int tile0 = blockIdx.x * TB;
-    const uint32_t prec_offset = 1u << (32 - (1 + BB * t));
-    // the b-term (lweNoiselessTrivial(result, sample->b)) seeds the reduction buffer
-    for (int e = threadIdx.x; e < TB * ROWP; e += SPLIT * 64) {
-        const int b = e / ROWP, h = e - b * ROWP;
-        uint32_t v = 0;
-        if (h == n_out && tile0 + b < batch) v = (uint32_t)in[(size_t)(tile0 + b) * (n_in + 1) + n_in];
-        red[e] = v;
-    }
-    uint32_t acc[TB][NCH][2];
-#pragma unroll
-    for (int b = 0; b < TB; b++)
-#pragma unroll
-        for (int c = 0; c < NCH; c++) acc[b][c][0] = acc[b][c][1] = 0u;
-
-    // my slice of the input dimension, in chunks of 64 (one a-value per lane per sample)
-    const int per_wave = ((n_in + SPLIT * 64 - 1) / (SPLIT * 64)) * 64;
-    const int i_begin = wave * per_wave;
-    const int i_end = (i_begin + per_wave < n_in) ? i_begin + per_wave : n_in;
-#pragma unroll 1
-    for (int i0 = i_begin; i0 < i_end; i0 += 64) {
-        int avec[TB];  // lane L: a[i0+L] + prec_offset of sample b (0 => all digits 0)
-#pragma unroll
-        for (int b = 0; b < TB; b++) {  // unconditional loads from clamped addresses, all issued ...
-            const int bs = (tile0 + b < batch) ? tile0 + b : batch - 1, li = (i0 + lane < n_in) ? i0 + lane : n_in - 1;
-            avec[b] = in[(size_t)bs * (n_in + 1) + li];
-        }
-#pragma unroll
-        for (int b = 0; b < TB; b++) TFHE_OPAQUE(avec[b]);  // ... before the first one is waited for
-#pragma unroll
-        for (int b = 0; b < TB; b++) {
-            const bool ok = (tile0 + b < batch) && (i0 + lane < n_in);
-            avec[b] = ok ? (int)((uint32_t)avec[b] + prec_offset) : 0;
-        }
-        const int cnt = (i_end - i0 < 64) ? (i_end - i0) : 64;
-        // one flat loop over (ii, j): the key blocks of consecutive (i, j) are contiguous, and the rows
-        // of step q+1 are requested before the rows of step q are consumed, so that their L2 latency
-        // runs under the digit tests instead of in front of them
-        const int32_t *blk = ksd + (size_t)i0 * t * NR * ROWP;
-        uint32_t rn[NR][NCH][2];
-#pragma unroll
-        for (int d = 0; d < NR; d++)
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const int32_t *src = blk + d * ROWP + c * 128 + 2 * lane;
-                rn[d][c][0] = (uint32_t)src[0];
-                rn[d][c][1] = (uint32_t)src[1];
-            }
-        uint32_t ab[TB];
-        const int steps = cnt * t;
-        int ii = 0, j = 0;
-#pragma unroll 1
-        for (int q = 0; q < steps; q++) {
-            if (j == 0) {
-#pragma unroll
-                for (int b = 0; b < TB; b++) ab[b] = (uint32_t)TFHE_READLANE(avec[b], ii);
-            }
-            uint32_t r[NR][NCH][2];
-#pragma unroll
-            for (int d = 0; d < NR; d++)
-#pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    r[d][c][0] = rn[d][c][0];
-                    r[d][c][1] = rn[d][c][1];
-                }
-            if (q + 1 < steps) {
-                const int32_t *rows = blk + (size_t)(q + 1) * NR * ROWP;
-#pragma unroll
-                for (int d = 0; d < NR; d++)
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) {
-                        const int32_t *src = rows + d * ROWP + c * 128 + 2 * lane;
-                        rn[d][c][0] = (uint32_t)src[0];
-                        rn[d][c][1] = (uint32_t)src[1];
-                    }
-            }
-            const int sh = 32 - (j + 1) * BB;
-#pragma unroll
-            for (int b = 0; b < TB; b++) {
-                const uint32_t dig = (ab[b] >> sh) & mask;  // wave-uniform (scalar registers)
-                if (dig == 0) continue;
-#pragma unroll
-                for (int d = 0; d < NR; d++) {
-                    if (dig == (uint32_t)(d + 1)) {
-                        TFHE_KEEP_BRANCH();
-#pragma unroll
-                        for (int c = 0; c < NCH; c++) {
-                            acc[b][c][0] -= r[d][c][0];
-                            acc[b][c][1] -= r[d][c][1];
-                        }
-                    }
-                }
-            }
-            if (++j == t) {
-                j = 0;
-                ii++;
-            }
-        }
-    }
-    __syncthreads();  // red[] seeded
-#pragma unroll
-    for (int b = 0; b < TB; b++)
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            atomicAdd(&red[b * ROWP + c * 128 + 2 * lane], acc[b][c][0]);
-            atomicAdd(&red[b * ROWP + c * 128 + 2 * lane + 1], acc[b][c][1]);
-        }
-    __syncthreads();
-    const int row = n_out + 1;
-    for (int e = threadIdx.x; e < TB * row; e += SPLIT * 64) {
-        const int b = e / row, h = e - b * row;
-        if (tile0 + b < batch) out[(size_t)(tile0 + b) * row + h] = (int32_t)red[b * ROWP + h];
-    }
-}
-
-// host/upload helper: [n_in][t][base][n_out+1] -> [n_in][t][base-1][rowp] (zero padded)
-TFHE_GLOBAL void k_pack_ks(int32_t *__restrict__ dst, const int32_t *__restrict__ src, long long rows_out, int base,
-                           int row, int rowp) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= rows_out * rowp) return;
-    const long long ro = gid / rowp;
-    const int h = (int)(gid - ro * rowp);
-    const long long ij = ro / (base - 1);
-    const int d = (int)(ro - ij * (base - 1)) + 1;
-    dst[gid] = (h < row) ? src[(ij * base + d) * row + h] : 0;
-}
-
 // ------------------------------------------------ private key switch (circuit bootstrap)
 // circuitPrivKS (poc:667-698): LWE64 sample of dimension n2 -> TLWE32 sample, through the key
 // privKS[u][i][j][d] (TLWE32 rows of 2*N1 ints, poc:405-419).  Same digit loop as the LWE key
@@ -1381,10 +1230,8 @@ TFHE_GLOBAL void k_pack_ks(int32_t *__restrict__ dst, const int32_t *__restrict_
 //   tab: plane u, reference layout [n2+1][t][base][2*N1]; x: [count][x_stride], inputs 0..n2 of each row used;
 //   out: sample s at out + (s % group) * stride_in_group + (s / group) * stride_of_group, 2*N1 ints
 //        (the circuit bootstrap runs its l1 gadget levels as l1 groups of one launch)
-// The same kernel serves the LWE key switch of the gate bootstrap (XT = int32_t, PACKED: the tiled
-// key layout [n_in][t][base-1][640] without the digit-0 rows, zero-padded rows) as its "stream"
-// variant: 32-sample tiles, one pass of 5 waves x 2 ints over the 640-int row (each wave repeats the
-// scalar digit work for its 128-int chunk: less key traffic than k_keyswitch_tiled, more scalar work).
+// FALLBACK for shapes the matrix-core kernel (k_ks_mfma below) does not cover (t * basebit > 32); the
+// PoC's 10 x 3 goes through k_ks_mfma.
 // HI_ONLY (64-bit inputs): every digit lies in the upper 32 bits (t * basebit <= 32, as at the PoC's 10 x 3),
 // so only that word of each input is kept and broadcast: half the scalar registers.
 template <typename XT, int TB, int BB, int EPT, int THREADS, bool PACKED, bool HI_ONLY = false>
@@ -1442,8 +1289,6 @@ TFHE_GLOBAL void __launch_bounds__(THREADS)
                     if (TWO_WORDS) v |= (uint64_t)(uint32_t)TFHE_READLANE(a1[TWO_WORDS ? b : 0], ii) << 32;
                     ab[b] = (AB)v;
                 }
-                // (no software prefetch of the next rows here, unlike k_keyswitch_tiled: it costs this
-                // kernel its third wave per SIMD, which hides the same latency)
 #pragma unroll 1
                 for (int j = 0; j < t; j++) {
                     const int sh = WA - (j + 1) * BB;
@@ -1491,7 +1336,8 @@ TFHE_GLOBAL void __launch_bounds__(THREADS)
 // too, so that EVERY (i,j) position contributes exactly one row and the bias is the constant
 // 128 * n_in * t per limb.  v_mfma_i32_32x32x32_i8 accumulates the limb sums exactly (|sum| <= 2^7 *
 // n_in * t < 2^31), the epilogue recombines them modulo 2^32: bit-identical to the reference's loop.
-// The key is read once per 256-sample tile instead of once per 16 (k_keyswitch_tiled) or 32 (k_privks).
+// The key is read once per 256-sample tile (the VALU kernels of round 1 read it once per 16 or 32 samples:
+// 1.31 -> 0.77 ms for 4096 gate key switches, 7.1 -> 1.4 ms per privKS plane of 768 samples on MI355X).
 //
 // Key layout (built once at upload by k_ks_mfma_pack): Bm[hblock][kstep][limb][lane][16] int8 --
 // a 1 KB block is exactly the B operand of one MFMA (lane l: column h = 32*hblock + (l & 31), rows

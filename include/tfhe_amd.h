@@ -79,8 +79,8 @@ int tfhe_amd_sync(tfhe_amd_ctx *ctx);
 /* Scheduling options.  They select among kernels that compute the SAME results bit for bit.  (The
  * blind-rotation schedule variants, the streamed key switch and the wider transform workgroups of round 1
  * were measured on MI355X and removed: profiles/r02_variants.txt, profiles/r02_config4_fft.jsonl.)
- *   TFHE_AMD_OPT_KS_GATHER   != 0: per-sample gather key switch (the kernel for shapes the batch-tiled one
- *        does not cover) even where the tiled kernel applies
+ *   TFHE_AMD_OPT_KS_GATHER   != 0: per-sample gather key switch (the kernel for shapes the matrix-core one
+ *        does not cover: basebit > 3 or t * basebit > 32) even where the matrix-core kernel applies
  *   TFHE_AMD_OPT_STREAMED_GRAPH  != 0: tfhe_amd_bootstrap_streamed captures its n+3 launches into a hipGraph
  *        (after one plain call per schedule) and replays it while (x_d, out_d, mu, batch) repeat */
 enum { TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_STREAMED_GRAPH = 4 };

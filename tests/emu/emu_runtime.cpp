@@ -28,12 +28,15 @@ struct Fiber {
     void *stack = nullptr;
     bool done = false;
     unsigned tid = 0;
+    const Rendezvous *wait_on = nullptr;  // blocked until wait_on->gen != wait_gen: the scheduler skips it
+    unsigned wait_gen = 0;
 };
 struct Block {
     std::vector<int> lane_xchg;  // readlane: two slots per work-item, used alternately (one fence per call)
     std::vector<unsigned char> rl_phase;
     std::vector<int> any_xchg;   // wave_any
-    std::vector<int> mfma_xchg;  // mfma: 8 ints (A then B fragment) per work-item
+    std::vector<int> mfma_xchg;  // mfma: two alternating sets of 8 ints (A then B fragment) per work-item
+    std::vector<unsigned char> mfma_phase;
     std::vector<Fiber> fibers;
     Rendezvous all;
     std::vector<Rendezvous> waves;
@@ -53,7 +56,11 @@ void arrive(Rendezvous &r) {
         r.gen++;
         return;
     }
+    Fiber &f = t_blk->fibers[t_blk->current];
+    f.wait_on = &r;
+    f.wait_gen = g;
     while (r.gen == g) yield();
+    f.wait_on = nullptr;
 }
 void retire(Rendezvous &r) {  // a work-item that returned no longer takes part
     r.expected--;
@@ -81,7 +88,8 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
     b.lane_xchg.assign((size_t)2 * nt, 0);
     b.rl_phase.assign(nt, 0);
     b.any_xchg.assign(nt, 0);
-    b.mfma_xchg.assign((size_t)8 * nt, 0);
+    b.mfma_xchg.assign((size_t)16 * nt, 0);
+    b.mfma_phase.assign(nt, 0);
     b.all.expected = (int)nt;
     b.waves.resize((nt + 63) / 64);
     for (unsigned w = 0; w < b.waves.size(); w++) b.waves[w].expected = (int)std::min(64u, nt - 64 * w);
@@ -109,6 +117,10 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
         for (unsigned t = 0; t < nt; t++) {
             Fiber &f = b.fibers[t];
             if (f.done) continue;
+            if (f.wait_on && f.wait_on->gen == f.wait_gen) {  // still blocked: no context switch
+                alive++;
+                continue;
+            }
             b.current = (int)t;
             t_threadIdx = Dim3(t);
             swapcontext(&b.sched, &f.ctx);
@@ -145,11 +157,13 @@ int readlane(int v, int lane) {
 }
 
 // v_mfma_i32_32x32x32_i8: every lane publishes its A and B fragments, then computes its 16 results
-// (column lane & 31, rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); the second fence frees the slots
+// (column lane & 31, rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)).  Two slot sets used alternately,
+// one fence per call (same argument as readlane).
 v16i_t mfma_i32_32x32x32_i8(const v4i_t &a, const v4i_t &b, const v16i_t &c_in) {
     v16i_t c = c_in;
     const unsigned tid = t_threadIdx.x, base = tid & ~63u, lane = tid & 63u;
-    int *slot = &t_blk->mfma_xchg[(size_t)8 * tid];
+    const size_t nt = t_blk->mfma_phase.size(), set = (t_blk->mfma_phase[tid]++ & 1u) * 8 * nt;
+    int *slot = &t_blk->mfma_xchg[set + (size_t)8 * tid];
     for (int e = 0; e < 4; e++) {
         slot[e] = a[e];
         slot[4 + e] = b[e];
@@ -160,13 +174,12 @@ v16i_t mfma_i32_32x32x32_i8(const v4i_t &a, const v4i_t &b, const v16i_t &c_in) 
         const unsigned row = (unsigned)((e & 3) + 8 * (e >> 2)) + 4u * (lane >> 5);
         int sum = 0;
         for (unsigned kh = 0; kh < 2; kh++) {
-            const signed char *ap = reinterpret_cast<const signed char *>(&t_blk->mfma_xchg[(size_t)8 * (base + row + 32 * kh)]);
-            const signed char *bp = reinterpret_cast<const signed char *>(&t_blk->mfma_xchg[(size_t)8 * (base + col + 32 * kh) + 4]);
+            const signed char *ap = reinterpret_cast<const signed char *>(&t_blk->mfma_xchg[set + (size_t)8 * (base + row + 32 * kh)]);
+            const signed char *bp = reinterpret_cast<const signed char *>(&t_blk->mfma_xchg[set + (size_t)8 * (base + col + 32 * kh) + 4]);
             for (int j = 0; j < 16; j++) sum += (int)ap[j] * (int)bp[j];
         }
         c[e] += sum;
     }
-    wave_fence();
     return c;
 }
 

@@ -16,7 +16,7 @@ for B in (1, 256, 4096, 16384):
     x = e.to_device(rs.randint(-2**31, 2**31, size=(B, 1025)).astype(np.int32)); o = e.alloc(B*631*4)
     e0, e1 = e.event(), e.event()
     outs = {}
-    for mode, name in ((0, "mfma"), (2, "tiled"), (1, "gather")):
+    for mode, name in ((0, "mfma"), (1, "gather")):
         if mode == 1 and B > 4096: continue
         e.set_option(T.OPT_KS_GATHER, mode)
         ts = []
