@@ -13,6 +13,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtfhe_amd.so")
+OUT_DROPIN = os.path.join(HERE, "libtfhe_amd_dropin.so")  # global-scope reference entry points (csrc/dropin_library.cpp)
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SOURCES = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp"), os.path.join(CSRC, "hp_twiddles.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "devport.h"),
                   os.path.join(os.path.dirname(HERE), "include", "tfhe_amd.h")]
@@ -34,6 +36,24 @@ def stale():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+def build_dropin(engine_lib=None, out=None, force=False):
+    """libtfhe_amd_dropin.so: host C++ (g++) forwarding object with the reference's extern "C" names, linked
+    against the engine library (default: the shipped one; tests link it against the emulation build)"""
+    engine_lib = engine_lib or OUT
+    out = out or OUT_DROPIN
+    src = os.path.join(CSRC, "dropin_library.cpp")
+    deps = [src, engine_lib, os.path.join(INCLUDE, "tfhe_amd_dropin.h"), os.path.join(INCLUDE, "tfhe_amd_compat.hpp")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    libdir, libname = os.path.dirname(engine_lib), os.path.basename(engine_lib)
+    res = subprocess.run(["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-I" + INCLUDE, src, "-o", out, "-L" + libdir,
+                          "-l:" + libname, "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("g++ failed (dropin library)")
+    return out
+
+
 def build(force=False, verbose=False, out=None, defines=()):
     """default: the shipped library.  `out` + `defines`: an experiment build for A/B timing (tools/ab.py),
     never loaded by default"""
@@ -44,6 +64,7 @@ def build(force=False, verbose=False, out=None, defines=()):
             raise RuntimeError("hipcc failed")
         return out
     if not force and not stale():
+        build_dropin()
         return OUT
     cmd = [hipcc()] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + SOURCES + ["-o", OUT]
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -51,6 +72,7 @@ def build(force=False, verbose=False, out=None, defines=()):
         sys.stderr.write(res.stdout + res.stderr)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed")
+    build_dropin(force=True)
     return OUT
 
 

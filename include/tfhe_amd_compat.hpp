@@ -122,15 +122,30 @@ struct LweBootstrappingKeyFFT {  // lwe_functions.cpp:272-281
 };
 #endif
 
-// ---- one resident engine per key object ------------------------------------------------------
+// ---- one resident engine per (key object, shape) -----------------------------------------------
+// The reference's own call chain reaches the same TGswSampleFFT array through entry points that use
+// different prefixes of it (tGswFFTExternMulToTLwe: 1 sample, tfhe_blindRotate_FFT: n samples) and with
+// or without the key-switch key, so the registry is keyed on the pointer AND the shape it was attached with.
 struct Resident {
     tfhe_amd_ctx *ctx = nullptr;
     tfhe_amd_gsw *gsw = nullptr;
     int n = 0, N = 0, l = 0;
     void *d_in = nullptr, *d_out = nullptr, *d_aux = nullptr;  // one-sample staging buffers
 };
-inline std::map<const void *, Resident> &registry() {
-    static std::map<const void *, Resident> r;
+struct ResidentKey {
+    const void *obj, *ks;
+    int n, N, l, Bgbit;
+    bool operator<(const ResidentKey &o) const {
+        if (obj != o.obj) return obj < o.obj;
+        if (ks != o.ks) return ks < o.ks;
+        if (n != o.n) return n < o.n;
+        if (N != o.N) return N < o.N;
+        if (l != o.l) return l < o.l;
+        return Bgbit < o.Bgbit;
+    }
+};
+inline std::map<ResidentKey, Resident> &registry() {
+    static std::map<ResidentKey, Resident> r;
     return r;
 }
 inline int &device_ordinal() {
@@ -150,7 +165,8 @@ inline void staging(Resident &R, size_t bytes) {
 template <class GswT>
 inline Resident &attach_gsw(const GswT *bkFFT, int n, int N, int l, int Bgbit, const LweKeySwitchKey *ks = nullptr) {
     auto &reg = registry();
-    auto it = reg.find((const void *)bkFFT);
+    const ResidentKey key{(const void *)bkFFT, (const void *)ks, n, N, l, Bgbit};
+    auto it = reg.find(key);
     if (it != reg.end()) return it->second;
     Resident R;
     R.n = n;
@@ -191,22 +207,27 @@ inline Resident &attach_gsw(const GswT *bkFFT, int n, int N, int l, int Bgbit, c
         check(tfhe_amd_load_keyswitch_key(R.ctx, kflat.data()), R.ctx, "tfhe_amd_load_keyswitch_key");
     }
     staging(R, sizeof(int32_t) * (size_t)(2 * N + n + 2));
-    return reg.emplace((const void *)bkFFT, R).first->second;
+    return reg.emplace(key, R).first->second;
 }
-inline void release(const void *key_object) {
-    auto &reg = registry();
-    auto it = reg.find(key_object);
-    if (it == reg.end()) return;
+inline void release_entry(std::map<ResidentKey, Resident>::iterator it) {
     Resident &R = it->second;
     tfhe_amd_free(R.ctx, R.d_in);
     tfhe_amd_free(R.ctx, R.d_out);
     tfhe_amd_free(R.ctx, R.d_aux);
-    tfhe_amd_gsw_free(R.gsw);
+    if (R.gsw) tfhe_amd_gsw_free(R.gsw);
     tfhe_amd_ctx_destroy(R.ctx);
-    reg.erase(it);
+    registry().erase(it);
+}
+// every resident engine attached through this key object (whatever shape it was attached with)
+inline void release(const void *key_object) {
+    auto &reg = registry();
+    for (auto it = reg.begin(); it != reg.end();) {
+        auto cur = it++;
+        if (cur->first.obj == key_object) release_entry(cur);
+    }
 }
 inline void release_all() {
-    while (!registry().empty()) release(registry().begin()->first);
+    while (!registry().empty()) release_entry(registry().begin());
 }
 
 inline Resident &attach(const LweBootstrappingKeyFFT *bk) {
@@ -279,7 +300,8 @@ inline void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, 
 // (input dimension ks->n must be a ring degree the engine supports: 1024 or 2048)
 inline void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample) {
     auto &reg = registry();
-    auto it = reg.find((const void *)ks);
+    const ResidentKey key{(const void *)ks, (const void *)ks, ks->out_params->n, ks->n, 0, 0};
+    auto it = reg.find(key);
     if (it == reg.end()) {
         Resident R;
         R.n = ks->out_params->n;
@@ -307,7 +329,7 @@ inline void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const Lwe
                 }
         check(tfhe_amd_load_keyswitch_key(R.ctx, kflat.data()), R.ctx, "tfhe_amd_load_keyswitch_key");
         staging(R, sizeof(int32_t) * (size_t)(2 * R.N + R.n + 2));
-        it = reg.emplace((const void *)ks, R).first;
+        it = reg.emplace(key, R).first;
     }
     Resident &R = it->second;
     put_lwe(R, R.d_in, sample, R.N);

@@ -1,0 +1,118 @@
+// tfhe_amd_dropin.h -- the reference's entry points at GLOBAL scope, with the reference's full
+// signatures: what an existing driver declares (or would get from the upstream headers the reference
+// ships without) and links against libtfhe_amd_dropin.so instead of the CPU objects.
+//
+// Library form (declared EXPORT = extern "C" upstream):
+//     tfhe_blindRotate_FFT            CB/lwe_functions.cpp:337-341
+//     tfhe_blindRotateAndExtract_FFT  CB/lwe_functions.cpp:366-372
+//     tfhe_bootstrap_woKS_FFT         CB/lwe_functions.cpp:399-402
+//     tfhe_bootstrap_FFT              CB/lwe_functions.cpp:434-437
+//     tGswFFTExternMulToTLwe          CB/tgsw_functions.cpp:424
+//     lweKeySwitch                    CB/lwe_functions.cpp:163
+//   The struct definitions below carry the fields those files use; a driver that has the
+//   upstream headers defines TFHE_AMD_DROPIN_NO_LIBRARY_TYPES before including this file.
+// PoC form (C++ linkage, types of CB/poc_types.h, `const Globals* env` kept):
+//     preKeySwitch :437   preModSwitch :472   circuitBootstrapWoKS :530   circuitPrivKS :667
+//     tfhe_CircuitBootstrapFFT :823
+//   Declared here when TFHE_AMD_DROPIN_POC is defined AFTER poc_types.h has been included; they are
+//   defined by experimental-tfhe_amd/csrc/dropin_poc.cpp, which a PoC build compiles next to its own
+//   poc_types.h (C++ linkage on user types cannot be pre-built).  The engine behind an `env` is created
+//   on first use (keys uploaded once) and kept until tfhe_amd_dropin_release(env).
+#ifndef TFHE_AMD_DROPIN_H
+#define TFHE_AMD_DROPIN_H
+
+#include <stdint.h>
+
+#ifndef TFHE_AMD_DROPIN_POC
+#ifndef TFHE_AMD_DROPIN_NO_LIBRARY_TYPES
+typedef int32_t Torus32;
+typedef int64_t Torus64;
+struct LweParams {
+    int n;
+    double alpha_min, alpha_max;
+};
+struct LweSample {  // lwe_functions.cpp:20-24
+    Torus32 *a;
+    Torus32 b;
+    double current_variance;
+};
+struct TorusPolynomial {  // numeric_functions.cpp:199-223
+    int N;
+    Torus32 *coefsT;
+};
+struct LagrangeHalfCPolynomial {  // N doubles re|im
+    double *values;
+};
+struct TLweParams {
+    int N, k;
+    double alpha_min, alpha_max;
+    LweParams extracted_lweparams;
+};
+struct TLweSample {  // tlwe_functions.cpp:27-31
+    TorusPolynomial *a;
+    TorusPolynomial *b;
+    double current_variance;
+    int k;
+};
+struct TLweSampleFFT {  // tlwe_functions.cpp:34-38
+    LagrangeHalfCPolynomial *a;
+    LagrangeHalfCPolynomial *b;
+    double current_variance;
+    int k;
+};
+struct TGswParams {  // tgsw_functions.cpp:15-38
+    int l, Bgbit, Bg;
+    int32_t halfBg;
+    uint32_t maskMod;
+    const TLweParams *tlwe_params;
+    int kpl;
+    Torus32 *h;
+    uint32_t offset;
+};
+struct TGswSampleFFT {  // tgsw_functions.cpp:47-53
+    TLweSampleFFT *all_samples;
+    TLweSampleFFT **sample;
+    int k, l;
+};
+struct LweKeySwitchKey {  // lwe_functions.cpp:96-110
+    int n, t, basebit, base;
+    const LweParams *out_params;
+    LweSample *ks0_raw;
+    LweSample **ks1_raw;
+    LweSample ***ks;
+};
+struct LweBootstrappingKeyFFT {  // lwe_functions.cpp:272-281
+    const LweParams *in_out_params;
+    const TGswParams *bk_params;
+    const TLweParams *accum_params;
+    const LweParams *extract_params;
+    const TGswSampleFFT *bkFFT;
+    const LweKeySwitchKey *ks;
+};
+#endif
+
+extern "C" {
+void tfhe_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bkFFT, const int *bara, const int n,
+                          const TGswParams *bk_params);
+void tfhe_blindRotateAndExtract_FFT(LweSample *result, const TorusPolynomial *v, const TGswSampleFFT *bk, const int barb,
+                                    const int *bara, const int n, const TGswParams *bk_params);
+void tfhe_bootstrap_woKS_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x);
+void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x);
+void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, const TGswParams *params);
+void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample);
+/* frees every GPU-resident copy made for this key object (bk, bkFFT array or ks); NULL: all of them */
+void tfhe_amd_dropin_release(const void *key_object);
+/* GPU ordinal used by engines created from now on (default 0) */
+void tfhe_amd_dropin_set_device(int device);
+}
+#else  /* TFHE_AMD_DROPIN_POC: poc_types.h has been included */
+void preKeySwitch(LweSample32 *result, const LweSample32 *x, const Globals *env);
+void preModSwitch(int *result, const LweSample32 *x, const Globals *env);
+void circuitBootstrapWoKS(LweSample64 *result, const Torus64 mu, const int *abar, const Globals *env);
+void circuitPrivKS(TLweSample32 *result, const int u, const LweSample64 *x, const Globals *env);
+void tfhe_CircuitBootstrapFFT(TGswSample32 *result, const LweSample32 *sample, const Globals *env);
+/* the reference declares CMux and leaves its body empty (poc:877-879): out = c ? in1 : in0 */
+void CMux(TLweSample32 *out, const TGswSample32 *c, const TLweSample32 *in0, const TLweSample32 *in1, const Globals *env);
+void tfhe_amd_dropin_release(const Globals *env);
+#endif
+#endif

@@ -12,9 +12,16 @@
 #include <string>
 #include <vector>
 
+// -DDROPIN: the LITERAL drop-in form -- only the global-scope declarations of include/tfhe_amd_dropin.h
+// (what a driver written against the reference declares), no namespace, linked against
+// libtfhe_amd_dropin.so; the library-form section below is otherwise the same source.
+#ifdef DROPIN
+#include "tfhe_amd_dropin.h"
+#else
 #include "tfhe_amd_compat.hpp"
 
 using namespace tfhe_amd_compat;
+#endif
 
 static std::vector<uint8_t> slurp(const char *path) {
     FILE *f = fopen(path, "rb");
@@ -132,6 +139,11 @@ static int run_lib(const char *inp, const char *outp) {
         tGswFFTExternMulToTLwe(&as2, &gsw[n - 1], &gp);
         out.put(acc2.data(), 4 * (size_t)2 * N);
     }
+#ifdef DROPIN
+    tfhe_amd_dropin_release(nullptr);
+    out.save(outp);
+    return 0;
+#else
     // FFT plugin look-alike on the first accumulator polynomial
     {
         FFT_Processor_AMD P(N);
@@ -154,8 +166,10 @@ static int run_lib(const char *inp, const char *outp) {
     release_all();
     out.save(outp);
     return 0;
+#endif
 }
 
+#ifndef DROPIN
 // ---------------------------------------------------------------- PoC form
 // mirrors of the member names of CB/poc_types.h (the real header works the same way)
 struct PLwe32 { int32_t *a; int32_t *b; };
@@ -263,10 +277,16 @@ static int run_poc(const char *inp, const char *outp) {
     return 0;
 }
 
+#endif
+
 int main(int argc, char **argv) {
     if (argc != 4) {
         fprintf(stderr, "usage: %s lib|poc in.bin out.bin\n", argv[0]);
         return 2;
     }
+#ifdef DROPIN
+    return run_lib(argv[2], argv[3]);
+#else
     return std::string(argv[1]) == "lib" ? run_lib(argv[2], argv[3]) : run_poc(argv[2], argv[3]);
+#endif
 }

@@ -140,6 +140,14 @@ def test_circuit_bootstrap_pipeline(gpu_lib):
                               bb21=2, B=3, seed=62)
 
 
+def test_circuit_bootstrap_full_poc_block(gpu_lib):
+    """BASELINE config 3 at the PoC's FULL parameter block (poc:70-85): n0=500, N1=1024, N2=2048, l2=4,
+    Bgbit2=9, l1=2, Bgbit1=8, preKS 6x2, privKS 10x3 (2.69 GB table, synthetic).  Every stage and the whole
+    tfhe_CircuitBootstrapFFT bit-compared with the oracle on 3 samples."""
+    P.check_circuit_bootstrap(gpu_lib, n0=500, N1=1024, N2=2048, l1=2, bg1=8, l2=4, bg2=9, t10=6, bb10=2, t21=10,
+                              bb21=3, B=3, seed=63)
+
+
 def test_batch_4096_properties(gpu_lib):
     """BASELINE config 2 at full size: 4096 gate bootstraps.  Checked by (i) decrypt-sign of every
     output, (ii) bit-equality with the oracle on a subset, (iii) persistent schedule == one launch
