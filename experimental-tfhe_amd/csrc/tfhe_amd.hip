@@ -469,14 +469,15 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     }
     c->own_stream = true;
 #endif
+    // from here on the context owns device objects: failures go through tfhe_amd_ctx_destroy
     std::vector<double2> tw;
     if (!build_tables(p->N, c->fft_trig, c->ifft_trig, tw)) {
-        delete c;
+        tfhe_amd_ctx_destroy(c);
         return TFHE_AMD_ERR_PARAM;  // libm broke the conjugate symmetry the kernels rely on
     }
     if (hipMalloc((void **)&c->tw_d, tw.size() * sizeof(double2)) != hipSuccess ||
         hipMemcpy(c->tw_d, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) {
-        delete c;
+        tfhe_amd_ctx_destroy(c);
         return TFHE_AMD_ERR_DEVICE;
     }
     // gadget offset: Torus32 per TGswParams ctor (tgsw_functions.cpp:29-35), Torus64 per poc:349-350
@@ -553,6 +554,7 @@ int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
 
 int tfhe_amd_sync(tfhe_amd_ctx *c) {
     if (!c) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     return TFHE_AMD_OK;
 }
@@ -567,6 +569,7 @@ int tfhe_amd_event_create(tfhe_amd_ctx *c, void **event) {
 }
 int tfhe_amd_event_record(tfhe_amd_ctx *c, void *event) {
     if (!c || !event) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     HIPCHECK(c, hipEventRecord((hipEvent_t)event, c->stream));
     return TFHE_AMD_OK;
 }
@@ -704,6 +707,7 @@ void tfhe_amd_gsw_free(tfhe_amd_gsw *g) {
         drop_streamed_graph(g->ctx);
     }
     if (g->data_d) {
+        if (g->ctx) (void)hipSetDevice(g->ctx->device);
         (void)hipStreamSynchronize(g->ctx->stream);
         (void)hipFree(g->data_d);
     }

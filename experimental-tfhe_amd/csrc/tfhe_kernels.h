@@ -150,10 +150,39 @@ struct WaveFFT {
         TFHE_WAVE_FENCE();
     }
 
+    // The same transpose on COMPLEX points (16-byte elements: re and im of a point side by side), for a
+    // buffer of XCH double2: one ds_write_b128 / ds_read_b128 per point instead of two 8-byte accesses per
+    // plane -- the reads cost half the LDS cycles of the paired 8-byte form (MI355X_MICROARCH.md, LDS
+    // table).  The padded maps are conflict-free in 16-byte units too (tools/lds_conflicts.py).
+    template <int WMAP, int RMAP>
+    TFHE_DEVICE static void transpose_cplx(double (&xr)[PPL], double (&xi)[PPL], const Xch &X) {
+        double2 *w = reinterpret_cast<double2 *>(X.buf) + X.lane[WMAP], *r = reinterpret_cast<double2 *>(X.buf) + X.lane[RMAP];
+#pragma unroll
+        for (int m = 0; m < PPL; m++) w[G::roff(WMAP, m)] = make_double2(xr[m], xi[m]);
+        TFHE_WAVE_FENCE();
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            const double2 v = r[G::roff(RMAP, m)];
+            xr[m] = v.x;
+            xi[m] = v.y;
+        }
+        TFHE_WAVE_FENCE();
+    }
+    // CPLX: the caller's buffer holds XCH double2 (the blind-rotation kernel at N = 1024, where LDS has room)
+    template <int WMAP, int RMAP, bool CPLX>
+    TFHE_DEVICE static void transpose_point(double (&xr)[PPL], double (&xi)[PPL], const Xch &X) {
+        if (CPLX) {
+            transpose_cplx<WMAP, RMAP>(xr, xi, X);
+        } else {
+            transpose<WMAP, RMAP>(xr, X);
+            transpose<WMAP, RMAP>(xi, X);
+        }
+    }
+
     // coefficient -> Lagrange for NP polynomials at once (every twiddle is read from LDS once
     // and used by all NP).  In: lane t register m = point jA(t,m) (re = coef j, im = coef j+N/2).
     // Out: register m = position jC(t,m) of the reference's output order.
-    template <int NP, class TW>
+    template <int NP, class TW, bool CPLX = false>
     TFHE_DEVICE static void ifft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, const Xch &X, int t) {
         // Every twiddle is requested one step before the step that uses it (wn), so that its LDS
         // latency runs under the previous step's arithmetic instead of in front of its own.
@@ -190,10 +219,7 @@ struct WaveFFT {
             }
         }
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            transpose<G::RD_A1, G::RD_B1>(xr[p], X);
-            transpose<G::RD_A1, G::RD_B1>(xi[p], X);
-        }
+        for (int p = 0; p < NP; p++) transpose_point<G::RD_A1, G::RD_B1, CPLX>(xr[p], xi[p], X);
         // pass B: strides s<<CB
 #pragma unroll
         for (int s = PPL / 2; s >= 1; s >>= 1) {
@@ -206,10 +232,7 @@ struct WaveFFT {
             }
         }
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            transpose<G::RD_B2, G::RD_C2>(xr[p], X);
-            transpose<G::RD_B2, G::RD_C2>(xi[p], X);
-        }
+        for (int p = 0; p < NP; p++) transpose_point<G::RD_B2, G::RD_C2, CPLX>(xr[p], xi[p], X);
         // pass C: (N=1024 only) stride 4 general stage, then size-4 and size-2 steps
         if (G::CB == 3) {
 #pragma unroll
@@ -248,7 +271,7 @@ struct WaveFFT {
 
     // Lagrange -> coefficient for NP polynomials (caller has applied the 2/N scale).
     // In: register m = position jC(t,m).  Out: register m = point jA(t,m).
-    template <int NP, class TW>
+    template <int NP, class TW, bool CPLX = false>
     TFHE_DEVICE static void fft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, const Xch &X, int t) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
@@ -285,10 +308,7 @@ struct WaveFFT {
             }
         }
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            transpose<G::RD_C2, G::RD_B2>(xr[p], X);
-            transpose<G::RD_C2, G::RD_B2>(xi[p], X);
-        }
+        for (int p = 0; p < NP; p++) transpose_point<G::RD_C2, G::RD_B2, CPLX>(xr[p], xi[p], X);
         const int c = t & ((1 << G::CB) - 1);
 #pragma unroll
         for (int s = 1; s <= PPL / 2; s <<= 1) {
@@ -305,10 +325,7 @@ struct WaveFFT {
             }
         }
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            transpose<G::RD_B1, G::RD_A1>(xr[p], X);
-            transpose<G::RD_B1, G::RD_A1>(xi[p], X);
-        }
+        for (int p = 0; p < NP; p++) transpose_point<G::RD_B1, G::RD_A1, CPLX>(xr[p], xi[p], X);
 #pragma unroll
         for (int s = 1; s <= PPL / 2; s <<= 1) {
 #pragma unroll
@@ -446,7 +463,7 @@ TFHE_DEVICE void mac_row(double (&fr)[2][PPL], double (&fi)[2][PPL], const doubl
 // together, multiply-accumulate with their key rows in digit order (the MAC chain is sequential in
 // the row index: lagrangehalfc AddMul accumulates in place, tgsw_functions.cpp:441-443).
 // BGC: Bgbit when it is known at compile time (0: read gd.Bgbit) -- one v_bfe_i32 per digit.
-template <typename T, int LOGN, int ND, int BGC, bool FIRST>
+template <typename T, int LOGN, int ND, int BGC, bool FIRST, bool CPLX>
 TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int row0, int d0,
                                  const typename Torus<T>::U (&lo)[Geom<LOGN>::PPL],
                                  const typename Torus<T>::U (&hi)[Geom<LOGN>::PPL], const Gadget &gd,
@@ -483,7 +500,7 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
             }
         }
     }
-    WaveFFT<LOGN>::template ifft<ND, TwLds<LOGN>>(xr, xi, w.tw, w.xch, t);
+    WaveFFT<LOGN>::template ifft<ND, TwLds<LOGN>, CPLX>(xr, xi, w.tw, w.xch, t);
 #pragma unroll
     for (int e = 0; e < ND; e++) {
         if (e > 0) {
@@ -566,7 +583,7 @@ TFHE_DEVICE void rotated_minus_one(const WaveLds<T, LOGN> &w, int q, int a, type
 // LC == PAIR (the gate set: l = 2 in one pair) each polynomial is one transform group and the two
 // groups are unrolled: no loop-carried Fourier accumulator (its zero-initialisation disappears into the
 // first multiply), key-row addresses become immediates.
-template <typename T, int LOGN, int PAIR, int LC = 0, int BGC = 0>
+template <typename T, int LOGN, int PAIR, int LC = 0, int BGC = 0, bool CPLX = false>
 TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
                            const Gadget &gd, int t) {
     using G = Geom<LOGN>;
@@ -601,9 +618,9 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
         }
         // p = bloc*l + i  (tgsw_functions.cpp:435-443); a trailing odd digit goes alone
         if (PAIR == 2 && ((LC && LC % 2 == 0) || d + 1 < l)) {
-            ifft_mac_digits<T, LOGN, 2, BGC, FIRST>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
+            ifft_mac_digits<T, LOGN, 2, BGC, FIRST, CPLX>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         } else {
-            ifft_mac_digits<T, LOGN, 1, BGC, FIRST>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
+            ifft_mac_digits<T, LOGN, 1, BGC, FIRST, CPLX>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         }
     };
     if (UNROLLED) {
@@ -619,7 +636,7 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
     }
     // back to coefficients (both polynomials together), round, accumulate into acc
     // (tLweFromFFTConvert + tLweAddTo)
-    WaveFFT<LOGN>::template fft<2, TwLds<LOGN>>(fr, fi, w.tw, w.xch, t);
+    WaveFFT<LOGN>::template fft<2, TwLds<LOGN>, CPLX>(fr, fi, w.tw, w.xch, t);
     U r0[2][PPL], r1[2][PPL];
     bool exact_path = true;
     if (Torus<T>::HAS_FAST) {  // Torus32: short rounding sequence, valid while every |x| < 2^51
@@ -726,7 +743,10 @@ struct BlindRotateLds {
     using G = Geom<LOGN>;
     static constexpr size_t tw_bytes = sizeof(double2) * G::TW;
     static constexpr size_t acc_bytes = sizeof(T) * 2 * G::N;
-    static constexpr size_t xch_bytes = sizeof(double) * G::XCH;
+    // complex-point transposes (16-byte elements) where the workgroup's LDS has room for the larger buffer:
+    // N = 1024 / Torus32 (155,648 B for 8 waves); the other shapes keep one 8-byte plane at a time
+    static constexpr bool CPLX_XCH = (LOGN == 10 && sizeof(T) == 4);
+    static constexpr size_t xch_bytes = (CPLX_XCH ? sizeof(double2) : sizeof(double)) * G::XCH;
     static constexpr size_t wave_bytes = acc_bytes + xch_bytes;
     // accumulators first (each polynomial then sits at a multiple of its own size, see WaveLds),
     // then the twiddle table, then the transpose buffers
@@ -829,7 +849,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             a = TFHE_UNIFORM(a);
             if (a == 0) continue;  // :348-350
         }
-        cmux_step<T, LOGN, PAIR, LC, BGC>(w, bkrow, a, rotate, A.gd, t);
+        cmux_step<T, LOGN, PAIR, LC, BGC, Lds::CPLX_XCH>(w, bkrow, a, rotate, A.gd, t);
     }
 
     // ---- output
