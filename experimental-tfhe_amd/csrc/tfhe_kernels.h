@@ -1416,7 +1416,7 @@ struct KsMfmaArgs {
 // KPI = ks_mfma_kpi(t, BB) as a template parameter: a chunk of CH K-steps then covers CH / KPI whole input
 // coefficients, and which word and which digits a K-step needs is known at compile time.
 template <typename XT, int BB, int KPI>
-TFHE_GLOBAL void __launch_bounds__(256) k_ks_mfma(KsMfmaArgs A) {
+TFHE_GLOBAL void __launch_bounds__(256, 2) k_ks_mfma(KsMfmaArgs A) {
     using UX = typename std::make_unsigned<XT>::type;
     constexpr int W = 8 * (int)sizeof(XT);
     constexpr int CH = (KPI == 3) ? 6 : 8;  // K-steps per LDS buffer, a multiple of KPI (= ks_mfma_chunk)
