@@ -35,6 +35,21 @@ def test_exports_every_declared_symbol(hip_lib):
     assert sorted(T.ABI_SYMBOLS) == syms, "binding's symbol list out of date with the header"
 
 
+def test_dropin_library_exports_the_reference_names(hip_lib):
+    """libtfhe_amd_dropin.so: the reference's library-form entry points as global extern "C" symbols
+    (include/tfhe_amd_dropin.h; CB/lwe_functions.cpp:163,337,366,399,434, CB/tgsw_functions.cpp:424)"""
+    build = importlib.import_module("experimental-tfhe_amd.build")
+    lib = C.CDLL(build.build_dropin())
+    text = open(os.path.join(ROOT, "include", "tfhe_amd_dropin.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    block = text[text.index('extern "C" {'):text.index("#else")]
+    names = sorted(set(re.findall(r"\bvoid\s+([A-Za-z_0-9]+)\s*\(", block)))
+    assert names == sorted(["tfhe_blindRotate_FFT", "tfhe_blindRotateAndExtract_FFT", "tfhe_bootstrap_woKS_FFT", "tfhe_bootstrap_FFT",
+                            "tGswFFTExternMulToTLwe", "lweKeySwitch", "tfhe_amd_dropin_release", "tfhe_amd_dropin_set_device"])
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tfhe_amd_dropin.h but not exported"
+
+
 def test_version_and_params_struct(hip_lib):
     assert b"gfx950" in hip_lib.tfhe_amd_version()
     assert C.sizeof(T.Params) == 9 * 4
