@@ -583,7 +583,7 @@ TFHE_DEVICE void rotated_minus_one(const WaveLds<T, LOGN> &w, int q, int a, type
 // LC == PAIR (the gate set: l = 2 in one pair) each polynomial is one transform group and the two
 // groups are unrolled: no loop-carried Fourier accumulator (its zero-initialisation disappears into the
 // first multiply), key-row addresses become immediates.
-template <typename T, int LOGN, int PAIR, int LC = 0, int BGC = 0, bool CPLX = false>
+template <typename T, int LOGN, int PAIR, int LC = 0, int BGC = 0, bool CPLX = false, bool KEEP_ROT = false>
 TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
                            const Gadget &gd, int t) {
     using G = Geom<LOGN>;
@@ -596,15 +596,10 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
     const int l = LC ? LC : gd.l;
     const int groups = (l + PAIR - 1) / PAIR;
 
-    // one group = PAIR digits of one accumulator polynomial.  The (rotated) coefficients are re-read
-    // from LDS for every group instead of being kept across groups: they then die at the digit
-    // extraction, which is what lets the transform pair + key row + Fourier accumulator fit the
-    // register file; for l == PAIR (the gate set) nothing is read twice.
-    auto group = [&](int g, auto first) {
-        constexpr bool FIRST = decltype(first)::value;
-        const int q = (g >= groups) ? 1 : 0;
-        const int d = (g - q * groups) * PAIR;
-        U lo[PPL], hi[PPL];  // coefficients j and j+N/2 of the (rotated) polynomial, offset added
+    // one group = PAIR digits of one accumulator polynomial; for l == PAIR (the gate set) a polynomial is
+    // one group and nothing is read twice.
+    // the (rotated) coefficients j and j+N/2 of polynomial q, offset added, digit tops flipped
+    auto read_poly = [&](int q, U (&lo)[PPL], U (&hi)[PPL]) {
         if (rotate) {
             rotated_minus_one<T, LOGN>(w, q, a, offset, flip, lo, hi, t);
         } else {
@@ -616,7 +611,10 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
                 hi[m] = ((U)p[j + NC] + offset) ^ flip;
             }
         }
-        // p = bloc*l + i  (tgsw_functions.cpp:435-443); a trailing odd digit goes alone
+    };
+    // digits d .. of polynomial q: p = bloc*l + i  (tgsw_functions.cpp:435-443); a trailing odd digit goes alone
+    auto digits = [&](int q, int d, const U (&lo)[PPL], const U (&hi)[PPL], auto first) {
+        constexpr bool FIRST = decltype(first)::value;
         if (PAIR == 2 && ((LC && LC % 2 == 0) || d + 1 < l)) {
             ifft_mac_digits<T, LOGN, 2, BGC, FIRST, CPLX>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         } else {
@@ -624,15 +622,36 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
         }
     };
     if (UNROLLED) {
-        group(0, std::true_type{});
-        group(1, std::false_type{});
+        {
+            U lo[PPL], hi[PPL];
+            read_poly(0, lo, hi);
+            digits(0, 0, lo, hi, std::true_type{});
+        }
+        {
+            U lo[PPL], hi[PPL];
+            read_poly(1, lo, hi);
+            digits(1, 0, lo, hi, std::false_type{});
+        }
     } else {
 #pragma unroll
         for (int q = 0; q < 2; q++)
 #pragma unroll
             for (int m = 0; m < PPL; m++) fr[q][m] = fi[q][m] = 0.0;
+        // KEEP_ROT (kernels with one wave per SIMD, 512 registers): the rotated coefficients are formed
+        // ONCE per polynomial and kept across its digit groups -- at Torus64 the 64-bit rotation arithmetic
+        // of a group costs as many VALU instructions as its transform.  Otherwise (256 registers) they are
+        // re-read for every group: they then die at the digit extraction, which is what lets the transform
+        // pair + key row + Fourier accumulator fit the register file.
 #pragma unroll 1
-        for (int g = 0; g < 2 * groups; g++) group(g, std::false_type{});
+        for (int q = 0; q < 2; q++) {
+            U lo[PPL], hi[PPL];
+            if (KEEP_ROT) read_poly(q, lo, hi);
+#pragma unroll 1
+            for (int gi = 0; gi < groups; gi++) {
+                if (!KEEP_ROT) read_poly(q, lo, hi);
+                digits(q, gi * PAIR, lo, hi, std::false_type{});
+            }
+        }
     }
     // back to coefficients (both polynomials together), round, accumulate into acc
     // (tLweFromFFTConvert + tLweAddTo)
@@ -849,7 +868,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             a = TFHE_UNIFORM(a);
             if (a == 0) continue;  // :348-350
         }
-        cmux_step<T, LOGN, PAIR, LC, BGC, Lds::CPLX_XCH>(w, bkrow, a, rotate, A.gd, t);
+        cmux_step<T, LOGN, PAIR, LC, BGC, Lds::CPLX_XCH, (WAVES <= 4)>(w, bkrow, a, rotate, A.gd, t);
     }
 
     // ---- output
