@@ -185,7 +185,8 @@ int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
     return launch_br_t<int32_t, 10, 8, 2>(c, a);
 }
 int launch_br64(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
-    return c->logn == 10 ? launch_br_t<int64_t, 10, 4, 2>(c, a) : launch_br_t<int64_t, 11, 3, 1>(c, a);
+    // N=2048: accumulator in registers, 4 waves per workgroup (one per SIMD); tfhe_kernels.h, BlindRotateLds::ACCREG
+    return c->logn == 10 ? launch_br_t<int64_t, 10, 4, 2>(c, a) : launch_br_t<int64_t, 11, 4, 1>(c, a);
 }
 
 template <typename TIN, int LOGN, bool PACK, int WAVES>

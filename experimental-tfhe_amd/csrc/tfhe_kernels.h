@@ -463,7 +463,24 @@ TFHE_DEVICE void mac_row(double (&fr)[2][PPL], double (&fi)[2][PPL], const doubl
 // together, multiply-accumulate with their key rows in digit order (the MAC chain is sequential in
 // the row index: lagrangehalfc AddMul accumulates in place, tgsw_functions.cpp:441-443).
 // BGC: Bgbit when it is known at compile time (0: read gd.Bgbit) -- one v_bfe_i32 per digit.
-template <typename T, int LOGN, int ND, int BGC, bool FIRST, bool CPLX>
+// one output polynomial q of the same multiply-accumulate (key half-row in registers)
+template <int PPL>
+TFHE_DEVICE void mac_half_row(double (&fr)[PPL], double (&fi)[PPL], const double (&xr)[PPL], const double (&xi)[PPL],
+                              const double2 (&bk)[PPL]) {
+#pragma unroll
+    for (int m = 0; m < PPL; m++) {
+        const double ar = xr[m], ai = xi[m], br = bk[m].x, bi = bk[m].y;
+        const double tneg = __builtin_fma(ai, bi, -fr[m]);
+        fr[m] = __builtin_fma(ar, br, -tneg);
+        const double u = __builtin_fma(ar, bi, fi[m]);
+        fi[m] = __builtin_fma(ai, br, u);
+    }
+}
+
+// HALFROW (register-resident accumulator, PPL = 16): the key row is fetched in two halves of 64 registers
+// (the half for output polynomial 0 underneath the transform, the other half while the first is consumed)
+// instead of 128 at once.
+template <typename T, int LOGN, int ND, int BGC, bool FIRST, bool CPLX, bool HALFROW = false>
 TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int row0, int d0,
                                  const typename Torus<T>::U (&lo)[Geom<LOGN>::PPL],
                                  const typename Torus<T>::U (&hi)[Geom<LOGN>::PPL], const Gadget &gd,
@@ -473,14 +490,14 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
     const int Bgbit = BGC ? BGC : gd.Bgbit;
     const U mask = ((U)1 << Bgbit) - 1;
     const int32_t halfBg = 1 << (Bgbit - 1);
-    double2 bk[2][PPL];  // key row of the first digit, fetched underneath the transform
+    double2 bk[HALFROW ? 1 : 2][PPL];  // key row of the first digit, fetched underneath the transform
     // wave-uniform row pointer + 32-bit lane offset: one address register for the whole row
     const unsigned char *kb = reinterpret_cast<const unsigned char *>(bkrow);
     const uint32_t lane16 = (uint32_t)t * 16u;
 #define TFHE_BK(row, qq, m) \
     (*reinterpret_cast<const double2 *>(kb + (lane16 + (uint32_t)((((row) * 2 + (qq)) * PPL + (m)) * 64) * 16u)))
 #pragma unroll
-    for (int qq = 0; qq < 2; qq++)
+    for (int qq = 0; qq < (HALFROW ? 1 : 2); qq++)
 #pragma unroll
         for (int m = 0; m < PPL; m++) bk[qq][m] = TFHE_BK(row0, qq, m);
     double xr[ND][PPL], xi[ND][PPL];
@@ -501,18 +518,26 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
         }
     }
     WaveFFT<LOGN>::template ifft<ND, TwLds<LOGN>, CPLX>(xr, xi, w.tw, w.xch, t);
+    if constexpr (HALFROW) {
+        static_assert(!HALFROW || (ND == 1 && !FIRST), "half-row form: one digit at a time, accumulator pre-zeroed");
+        mac_half_row<PPL>(fr[0], fi[0], xr[0], xi[0], bk[0]);
 #pragma unroll
-    for (int e = 0; e < ND; e++) {
-        if (e > 0) {
+        for (int m = 0; m < PPL; m++) bk[0][m] = TFHE_BK(row0, 1, m);
+        mac_half_row<PPL>(fr[1], fi[1], xr[0], xi[0], bk[0]);
+    } else {
 #pragma unroll
-            for (int qq = 0; qq < 2; qq++)
+        for (int e = 0; e < ND; e++) {
+            if (e > 0) {
 #pragma unroll
-                for (int m = 0; m < PPL; m++) bk[qq][m] = TFHE_BK(row0 + e, qq, m);
+                for (int qq = 0; qq < 2; qq++)
+#pragma unroll
+                    for (int m = 0; m < PPL; m++) bk[qq][m] = TFHE_BK(row0 + e, qq, m);
+            }
+            if (FIRST && e == 0)
+                mac_row<PPL, true>(fr, fi, xr[e], xi[e], bk);
+            else
+                mac_row<PPL, false>(fr, fi, xr[e], xi[e], bk);
         }
-        if (FIRST && e == 0)
-            mac_row<PPL, true>(fr, fi, xr[e], xi[e], bk);
-        else
-            mac_row<PPL, false>(fr, fi, xr[e], xi[e], bk);
     }
 #undef TFHE_BK
 }
@@ -572,6 +597,44 @@ TFHE_DEVICE void rotated_minus_one(const WaveLds<T, LOGN> &w, int q, int a, type
     }
 }
 
+// The same for an accumulator held in registers (BlindRotateLds::ACCREG): own[h][m] = coefficient
+// t + 64m + h*N/2 of the polynomial.  The polynomial is written to the wave's LDS scratch (which the
+// transposes reuse afterwards: the wave's DS operations execute in order), the rotated source is read back.
+template <typename T, int LOGN>
+TFHE_DEVICE void rotated_minus_one_reg(const WaveLds<T, LOGN> &w, const typename Torus<T>::U (&own)[2][Geom<LOGN>::PPL], int a,
+                                       typename Torus<T>::U offset, typename Torus<T>::U flip,
+                                       typename Torus<T>::U (&lo)[Geom<LOGN>::PPL], typename Torus<T>::U (&hi)[Geom<LOGN>::PPL],
+                                       int t) {
+    using G = Geom<LOGN>;
+    using U = typename Torus<T>::U;
+    constexpr int PPL = G::PPL, N = G::N, NC = G::NC;
+    U *scratch = reinterpret_cast<U *>(w.acc);
+    TFHE_WAVE_FENCE();  // earlier reads of this region (transposes) are ordered before these writes
+#pragma unroll
+    for (int m = 0; m < PPL; m++) {
+        scratch[t + 64 * m] = own[0][m];
+        scratch[t + 64 * m + NC] = own[1][m];
+    }
+    TFHE_WAVE_FENCE();
+    int base = (t - a) & (2 * N - 1);
+    TFHE_OPAQUE(base);
+#pragma unroll
+    for (int m = 0; m < PPL; m++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int idx = base + 64 * m + h * NC;
+            const U src = scratch[idx & (N - 1)];
+            const U rot = (idx & N) ? (U)(0 - src) : src;
+            const U v = ((rot - own[h][m]) + offset) ^ flip;
+            if (h == 0)
+                lo[m] = v;
+            else
+                hi[m] = v;
+        }
+    }
+    TFHE_WAVE_FENCE();
+}
+
 // One CMux step on the wave's accumulator:
 //   rotate:  acc <- bk_row (x) ((X^a - 1) * acc) + acc   (tfhe_MuxRotate_FFT, a != 0)
 //   !rotate: acc <- bk_row (x) acc                       (tGswFFTExternMulToTLwe)
@@ -583,9 +646,10 @@ TFHE_DEVICE void rotated_minus_one(const WaveLds<T, LOGN> &w, int q, int a, type
 // LC == PAIR (the gate set: l = 2 in one pair) each polynomial is one transform group and the two
 // groups are unrolled: no loop-carried Fourier accumulator (its zero-initialisation disappears into the
 // first multiply), key-row addresses become immediates.
-template <typename T, int LOGN, int PAIR, int LC = 0, int BGC = 0, bool CPLX = false, bool KEEP_ROT = false>
+// ACCREG: the accumulator is accr[q][h][m] (registers) instead of w.acc (LDS); see BlindRotateLds.
+template <typename T, int LOGN, int PAIR, int LC = 0, int BGC = 0, bool CPLX = false, bool KEEP_ROT = false, bool ACCREG = false>
 TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
-                           const Gadget &gd, int t) {
+                           const Gadget &gd, int t, typename Torus<T>::U (&accr)[2][2][ACCREG ? Geom<LOGN>::PPL : 1]) {
     using G = Geom<LOGN>;
     using U = typename Torus<T>::U;
     constexpr int PPL = G::PPL, N = G::N, NC = G::NC;
@@ -598,12 +662,25 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
 
     // one group = PAIR digits of one accumulator polynomial; for l == PAIR (the gate set) a polynomial is
     // one group and nothing is read twice.
+    int qrt = 0;  // run-time polynomial index of the rolled loop below
     // the (rotated) coefficients j and j+N/2 of polynomial q, offset added, digit tops flipped
-    auto read_poly = [&](int q, U (&lo)[PPL], U (&hi)[PPL]) {
-        if (rotate) {
-            rotated_minus_one<T, LOGN>(w, q, a, offset, flip, lo, hi, t);
+    auto read_poly = [&](auto qc, U (&lo)[PPL], U (&hi)[PPL]) {
+        constexpr int q = decltype(qc)::value < 0 ? 0 : decltype(qc)::value;
+        const int qq = decltype(qc)::value < 0 ? qrt : q;  // run-time polynomial index (LDS accumulator only)
+        if constexpr (ACCREG) {
+            if (rotate) {
+                rotated_minus_one_reg<T, LOGN>(w, accr[q], a, offset, flip, lo, hi, t);
+            } else {
+#pragma unroll
+                for (int m = 0; m < PPL; m++) {
+                    lo[m] = (accr[q][0][m] + offset) ^ flip;
+                    hi[m] = (accr[q][1][m] + offset) ^ flip;
+                }
+            }
+        } else if (rotate) {
+            rotated_minus_one<T, LOGN>(w, qq, a, offset, flip, lo, hi, t);
         } else {
-            const T *p = w.acc + q * N;
+            const T *p = w.acc + qq * N;
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 const int j = G::jA(t, m);
@@ -618,19 +695,37 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
         if (PAIR == 2 && ((LC && LC % 2 == 0) || d + 1 < l)) {
             ifft_mac_digits<T, LOGN, 2, BGC, FIRST, CPLX>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         } else {
-            ifft_mac_digits<T, LOGN, 1, BGC, FIRST, CPLX>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
+            ifft_mac_digits<T, LOGN, 1, BGC, FIRST, CPLX, ACCREG && !FIRST>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         }
     };
     if (UNROLLED) {
         {
             U lo[PPL], hi[PPL];
-            read_poly(0, lo, hi);
+            read_poly(std::integral_constant<int, 0>{}, lo, hi);
             digits(0, 0, lo, hi, std::true_type{});
         }
         {
             U lo[PPL], hi[PPL];
-            read_poly(1, lo, hi);
+            read_poly(std::integral_constant<int, 1>{}, lo, hi);
             digits(1, 0, lo, hi, std::false_type{});
+        }
+    } else if (ACCREG) {
+        // the accumulator registers are indexed by q: the two polynomials are unrolled (the digit loop is not)
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int m = 0; m < PPL; m++) fr[q][m] = fi[q][m] = 0.0;
+        {
+            U lo[PPL], hi[PPL];
+            read_poly(std::integral_constant<int, 0>{}, lo, hi);
+#pragma unroll 1
+            for (int gi = 0; gi < groups; gi++) digits(0, gi * PAIR, lo, hi, std::false_type{});
+        }
+        {
+            U lo[PPL], hi[PPL];
+            read_poly(std::integral_constant<int, 1>{}, lo, hi);
+#pragma unroll 1
+            for (int gi = 0; gi < groups; gi++) digits(1, gi * PAIR, lo, hi, std::false_type{});
         }
     } else {
 #pragma unroll
@@ -645,10 +740,11 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
 #pragma unroll 1
         for (int q = 0; q < 2; q++) {
             U lo[PPL], hi[PPL];
-            if (KEEP_ROT) read_poly(q, lo, hi);
+            qrt = q;
+            if (KEEP_ROT) read_poly(std::integral_constant<int, -1>{}, lo, hi);
 #pragma unroll 1
             for (int gi = 0; gi < groups; gi++) {
-                if (!KEEP_ROT) read_poly(q, lo, hi);
+                if (!KEEP_ROT) read_poly(std::integral_constant<int, -1>{}, lo, hi);
                 digits(q, gi * PAIR, lo, hi, std::false_type{});
             }
         }
@@ -680,6 +776,16 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
                 r0[q][m] = (U)Torus<T>::from_double(fr[q][m]);
                 r1[q][m] = (U)Torus<T>::from_double(fi[q][m]);
             }
+    }
+    if constexpr (ACCREG) {  // acc (+)= result, in registers
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                accr[q][0][m] = rotate ? accr[q][0][m] + r0[q][m] : r0[q][m];
+                accr[q][1][m] = rotate ? accr[q][1][m] + r1[q][m] : r1[q][m];
+            }
+        return;
     }
     // (the wave-uniform `rotate` test sits outside the unrolled loops: inside them hipcc keeps one
     // scalar branch pair per store)
@@ -761,11 +867,16 @@ template <typename T, int LOGN, int WAVES>
 struct BlindRotateLds {
     using G = Geom<LOGN>;
     static constexpr size_t tw_bytes = sizeof(double2) * G::TW;
-    static constexpr size_t acc_bytes = sizeof(T) * 2 * G::N;
+    // ACCREG (Torus64, N = 2048): the 32 KB accumulator lives in the wave's REGISTERS (128 per lane; the
+    // kernel runs one wave per SIMD anyway) and LDS holds only one 16 KB scratch polynomial per wave, which
+    // the rotated read goes through and which the transposes reuse afterwards: 4 waves per CU instead of 3
+    static constexpr bool ACCREG = (LOGN == 11 && sizeof(T) == 8);
+    static constexpr size_t acc_bytes = ACCREG ? 0 : sizeof(T) * 2 * G::N;
     // complex-point transposes (16-byte elements) where the workgroup's LDS has room for the larger buffer:
     // N = 1024 / Torus32 (155,648 B for 8 waves); the other shapes keep one 8-byte plane at a time
     static constexpr bool CPLX_XCH = (LOGN == 10 && sizeof(T) == 4);
-    static constexpr size_t xch_bytes = (CPLX_XCH ? sizeof(double2) : sizeof(double)) * G::XCH;
+    static constexpr size_t xch_min = (CPLX_XCH ? sizeof(double2) : sizeof(double)) * G::XCH;
+    static constexpr size_t xch_bytes = (ACCREG && sizeof(T) * G::N > xch_min) ? sizeof(T) * G::N : xch_min;
     static constexpr size_t wave_bytes = acc_bytes + xch_bytes;
     // accumulators first (each polynomial then sits at a multiple of its own size, see WaveLds),
     // then the twiddle table, then the transpose buffers
@@ -801,14 +912,27 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
 
     WaveLds<T, LOGN> w;
     w.smem = smem;
-    w.acc = reinterpret_cast<T *>(smem + Lds::acc_at(wave));
+    w.acc = reinterpret_cast<T *>(smem + (Lds::ACCREG ? Lds::xch_at(wave) : Lds::acc_at(wave)));  // ACCREG: the scratch polynomial
     w.acc_lds = tfhe_lds_offset(w.acc);
-    if (w.acc_lds & (uint32_t)(sizeof(T) * N - 1)) TFHE_TRAP();  // rotated_minus_one relies on it: fail loudly
+    if (!Lds::ACCREG && (w.acc_lds & (uint32_t)(sizeof(T) * N - 1))) TFHE_TRAP();  // rotated_minus_one relies on it: fail loudly
     w.xch = WaveFFT<LOGN>::make_xch(reinterpret_cast<double *>(smem + Lds::xch_at(wave)), t);
     w.tw.tw = reinterpret_cast<const double2 *>(smem + Lds::tw_at);
     w.tw.t = t;
 
     const int32_t *rot = A.rot + (size_t)ct * A.rot_stride;
+    // The accumulator: [2][N] in the wave's LDS slice, or (ACCREG) accr[q][h][m] = coefficient
+    // t + 64m + h*N/2 of polynomial q in registers.  ACC_AT(m) = flat coefficient t + 64m, m < 4*PPL.
+    constexpr bool ACCREG = Lds::ACCREG;
+    U accr[2][2][ACCREG ? PPL : 1];
+#define ACC_REG(m) accr[(m) / (2 * PPL)][((m) / PPL) & 1][ACCREG ? (m) % PPL : 0]
+#define ACC_SET(m, v)                  \
+    do {                               \
+        if constexpr (ACCREG)          \
+            ACC_REG(m) = (U)(v);       \
+        else                           \
+            w.acc[t + 64 * (m)] = (T)(v); \
+    } while (0)
+#define ACC_GET(m) (ACCREG ? ACC_REG(m) : (U)w.acc[ACCREG ? 0 : t + 64 * (m)])
     // ---- accumulator initialisation
     if (A.flags & BR_INIT_TESTVEC) {
         int barb = rot[A.n_steps];
@@ -828,8 +952,8 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
                 v = (src < N / 2) ? (U)(0 - (U)A.tv_const) : (U)A.tv_const;
             else
                 v = (U)tv[src];
-            w.acc[j] = 0;
-            w.acc[N + j] = (T)((idx & N) ? (U)(0 - v) : v);
+            ACC_SET(m, (U)0);
+            ACC_SET(2 * PPL + m, (idx & N) ? (U)(0 - v) : v);
         }
     } else if (A.flags & BR_CMUX_DATA) {
         const size_t item = A.cmux_period ? (size_t)(ct % A.cmux_period) : (size_t)ct;
@@ -837,17 +961,17 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
         if (A.flags & BR_CMUX_TRIVIAL) {
 #pragma unroll
             for (int m = 0; m < 2 * PPL; m++) {
-                w.acc[t + 64 * m] = 0;
-                w.acc[N + t + 64 * m] = (T)((U)d1[t + 64 * m] - (U)d0[t + 64 * m]);
+                ACC_SET(m, (U)0);
+                ACC_SET(2 * PPL + m, (U)d1[t + 64 * m] - (U)d0[t + 64 * m]);
             }
         } else {
 #pragma unroll
-            for (int m = 0; m < 4 * PPL; m++) w.acc[t + 64 * m] = (T)((U)d1[t + 64 * m] - (U)d0[t + 64 * m]);
+            for (int m = 0; m < 4 * PPL; m++) ACC_SET(m, (U)d1[t + 64 * m] - (U)d0[t + 64 * m]);
         }
     } else {
         const T *src = A.acc_io + (size_t)ct * 2 * N;
 #pragma unroll
-        for (int m = 0; m < 4 * PPL; m++) w.acc[t + 64 * m] = src[t + 64 * m];
+        for (int m = 0; m < 4 * PPL; m++) ACC_SET(m, (U)src[t + 64 * m]);
     }
     TFHE_WAVE_FENCE();
     const double2 *bk0 = A.bk;
@@ -868,18 +992,24 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             a = TFHE_UNIFORM(a);
             if (a == 0) continue;  // :348-350
         }
-        cmux_step<T, LOGN, PAIR, LC, BGC, Lds::CPLX_XCH, (WAVES <= 4)>(w, bkrow, a, rotate, A.gd, t);
+        cmux_step<T, LOGN, PAIR, LC, BGC, Lds::CPLX_XCH, (WAVES <= 4), ACCREG>(w, bkrow, a, rotate, A.gd, t, accr);
     }
 
     // ---- output
     if (A.flags & BR_EXTRACT) {  // tLweExtractLweSampleIndex, index 0 (tlwe_functions.cpp:351-363)
         T *out = A.lwe_out + (size_t)ct * (N + 1);
+        if constexpr (ACCREG) {  // the mask polynomial through the LDS scratch: lane t needs coefficient N - j
+            TFHE_WAVE_FENCE();
+#pragma unroll
+            for (int m = 0; m < 2 * PPL; m++) w.acc[t + 64 * m] = (T)ACC_REG(m);
+            TFHE_WAVE_FENCE();
+        }
 #pragma unroll
         for (int m = 0; m < 2 * PPL; m++) {
             const int j = t + 64 * m;
             out[j] = (j == 0) ? w.acc[0] : (T)(0 - (U)w.acc[N - j]);
         }
-        if (t == 0) out[N] = (T)((U)w.acc[N] + (U)A.out_b_add);
+        if (t == 0) out[N] = (T)(ACC_GET(2 * PPL) + (U)A.out_b_add);  // lane 0: coefficient 0 of the body polynomial
     } else if (A.flags & BR_CMUX_DATA) {
         const size_t item = A.cmux_period ? (size_t)(ct % A.cmux_period) : (size_t)ct;
         const T *d0 = A.cmux_d0 + item * A.cmux_stride;
@@ -892,21 +1022,24 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             for (int m = 0; m < 2 * PPL; m++) v[m] = (U)d0[t + 64 * m];
 #pragma unroll
             for (int m = 0; m < 2 * PPL; m++) {
-                dst[t + 64 * m] = w.acc[t + 64 * m];
-                dst[N + t + 64 * m] = (T)((U)w.acc[N + t + 64 * m] + v[m]);
+                dst[t + 64 * m] = (T)ACC_GET(m);
+                dst[N + t + 64 * m] = (T)(ACC_GET(2 * PPL + m) + v[m]);
             }
         } else {
             U v[4 * PPL];
 #pragma unroll
             for (int m = 0; m < 4 * PPL; m++) v[m] = (U)d0[t + 64 * m];
 #pragma unroll
-            for (int m = 0; m < 4 * PPL; m++) dst[t + 64 * m] = (T)((U)w.acc[t + 64 * m] + v[m]);
+            for (int m = 0; m < 4 * PPL; m++) dst[t + 64 * m] = (T)(ACC_GET(m) + v[m]);
         }
     } else {
         T *dst = A.acc_io + (size_t)ct * 2 * N;
 #pragma unroll
-        for (int m = 0; m < 4 * PPL; m++) dst[t + 64 * m] = w.acc[t + 64 * m];
+        for (int m = 0; m < 4 * PPL; m++) dst[t + 64 * m] = (T)ACC_GET(m);
     }
+#undef ACC_REG
+#undef ACC_SET
+#undef ACC_GET
 }
 
 // ------------------------------------------- standalone batched transforms

@@ -179,9 +179,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["fft", "cb", "all"])
     ap.add_argument("--batch", type=int, default=8192, help="polynomials per launch (fft)")
-    ap.add_argument("--cb-batch", type=int, default=768,
-                    help="LWE inputs per circuit-bootstrap launch (default 768 = one Torus64 N=2048 accumulator per wave, "
-                         "3 waves per CU, 256 CUs: the smallest batch that fills the chip)")
+    ap.add_argument("--cb-batch", type=int, default=1024,
+                    help="LWE inputs per circuit-bootstrap launch (default 1024 = one Torus64 N=2048 ciphertext per wave, "
+                         "4 waves per CU, 256 CUs: the smallest batch that fills the chip)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--small", action="store_true")
