@@ -873,8 +873,9 @@ struct BlindRotateLds {
     static constexpr bool ACCREG = (LOGN == 11 && sizeof(T) == 8);
     static constexpr size_t acc_bytes = ACCREG ? 0 : sizeof(T) * 2 * G::N;
     // complex-point transposes (16-byte elements) where the workgroup's LDS has room for the larger buffer:
-    // N = 1024 / Torus32 (155,648 B for 8 waves); the other shapes keep one 8-byte plane at a time
-    static constexpr bool CPLX_XCH = (LOGN == 10 && sizeof(T) == 4);
+    // N = 1024 (Torus32: 155,648 B for 8 waves; Torus64: 119,808 B for 4) and the register-accumulator kernel;
+    // Torus32 at N = 2048 keeps one 8-byte plane at a time (4 x (16 KB + 17 KB) + 32 KB would not fit)
+    static constexpr bool CPLX_XCH = (LOGN == 10) || ACCREG;
     static constexpr size_t xch_min = (CPLX_XCH ? sizeof(double2) : sizeof(double)) * G::XCH;
     static constexpr size_t xch_bytes = (ACCREG && sizeof(T) * G::N > xch_min) ? sizeof(T) * G::N : xch_min;
     static constexpr size_t wave_bytes = acc_bytes + xch_bytes;

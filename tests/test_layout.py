@@ -1,6 +1,7 @@
 """Static properties of the kernels' LDS layout (no GPU): the padded transpose indices are
 permutations and, under the gfx950 banking rules of MI355X_MICROARCH.md, free of bank conflicts
-for every ds_write_b64 / ds_read_b64 of both transposes in both directions."""
+for every ds_write_b64 / ds_read_b64 (8-byte planes) and ds_write_b128 / ds_read_b128 (complex points,
+N=1024) of both transposes in both directions."""
 import os
 import subprocess
 import sys
@@ -15,13 +16,17 @@ def test_fft_transposes_are_conflict_free_permutations():
 
 
 def test_lds_budgets_fit_160k():
-    # mirrors BlindRotateLds / KsTiledLds of csrc/tfhe_kernels.h and the WAVES chosen in tfhe_amd.hip
-    def br(torus_bytes, N, waves, twreg=False):
+    # mirrors BlindRotateLds of csrc/tfhe_kernels.h and the WAVES chosen in tfhe_amd.hip
+    def br(torus_bytes, N, waves):
         NC = N // 2
-        return (0 if twreg else 16 * 2 * NC) + waves * (torus_bytes * 2 * N + 8 * (NC + 64))
-    assert br(4, 1024, 8) == 118784 <= 163840
-    assert br(4, 1024, 4, True) <= 163840
+        accreg = (N == 2048 and torus_bytes == 8)    # accumulator in registers, one scratch polynomial in LDS
+        cplx = (N == 1024) or accreg                 # complex-point transposes
+        xch = (16 if cplx else 8) * (NC + 64)
+        if accreg:
+            return 16 * 2 * NC + waves * max(torus_bytes * N, xch)
+        return 16 * 2 * NC + waves * (torus_bytes * 2 * N + xch)
+    assert br(4, 1024, 8) == 155648 <= 163840
     assert br(4, 2048, 4) <= 163840
     assert br(8, 1024, 4) <= 163840
-    assert br(8, 2048, 3) <= 163840
-    assert 16 * 5 * 128 * 4 <= 65536  # tiled key switch reduction buffer needs no raised limit
+    assert br(8, 2048, 4) == 32768 + 4 * 17408 <= 163840
+    assert 2 * (2 * 8 * 4096) <= 163840  # k_ks_mfma: two workgroups per CU, double-buffered key slices of 8 K-steps
