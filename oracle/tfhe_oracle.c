@@ -836,12 +836,19 @@ typedef unsigned __int128 u128;
 /* intmul_best == intmul_ref, HP:79-95,148-169: (a * b) >> 64 for a twiddle b in [-1, 1) whose high
  * word is its sign extension */
 static u128 hp_intmul(u128 a, u128 b) {
-    const uint64_t alo = (uint64_t)a, ahi = (uint64_t)(a >> 64), blo = (uint64_t)b, bhi = (uint64_t)(b >> 64);
-    u128 tab = (u128)blo * ahi;
-    const u128 tcd = (((u128)blo * alo) >> 64) | ((u128)((uint64_t)((int64_t)ahi >> 63) & (0 - blo)) << 64);
-    tab += tcd;
-    if (bhi >> 63) tab -= a;
-    return tab;
+    /* A = a as a signed 128-bit integer = ahi_s * 2^64 + alo (ahi_s signed, alo unsigned);
+     * B = the twiddle, |B| < 2^64, sign-extended: B = blo - 2^64 * bneg with blo its low word.
+     *   floor(A * blo / 2^64) = ahi_s * blo + floor(alo * blo / 2^64)
+     *                         = ahi_u * blo - 2^64 * [ahi_s < 0] * blo + hi64(alo * blo)      (ahi_s = ahi_u - 2^64 [ahi_s < 0])
+     * and modulo 2^128 the middle term is ((0 - blo) mod 2^64) << 64.  The bneg part is exact:
+     * (2^64 * bneg * A) / 2^64 = bneg * A.  Hence, modulo 2^128:                                          */
+    const uint64_t alo = (uint64_t)a, ahi_u = (uint64_t)(a >> 64), blo = (uint64_t)b;
+    const int a_negative = (int)(ahi_u >> 63), b_negative = (int)((uint64_t)(b >> 64) >> 63);
+    u128 r = (u128)blo * ahi_u;                  /* ahi_u * blo                  */
+    r += ((u128)blo * alo) >> 64;                /* + hi64(alo * blo)            */
+    if (a_negative) r += (u128)(0 - blo) << 64;  /* - 2^64 * blo  (mod 2^128)    */
+    if (b_negative) r -= a;                      /* - bneg * A                   */
+    return r;
 }
 /* std::complex<Real96> product as libstdc++ instantiates it for a class type:
  * re = a.re*b.re - a.im*b.im; im = a.re*b.im + a.im*b.re (data on the left, twiddle on the right) */
