@@ -51,7 +51,7 @@ if max_stage >= 5:
     P.check_torus64_path(T.DEFAULT_LIB, N=2048, n=5, l=4, Bgbit=9, B=4)
     say("   ok")
 if max_stage >= 6:
-    say("stage 6: key switch shapes (tiled + gather), n_out=630 8x2 and n_out=500 6x2")
+    say("stage 6: key switch shapes (matrix-core + gather), n_out=630 8x2 and n_out=500 6x2")
     P.check_keyswitch_shapes(T.DEFAULT_LIB, 1024, 630, 8, 2, 35)
     P.check_keyswitch_shapes(T.DEFAULT_LIB, 1024, 500, 6, 2, 9)
     say("   ok")

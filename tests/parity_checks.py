@@ -396,8 +396,8 @@ def check_circuit_bootstrap(lib_path, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t
 
 # --------------------------------------------------------------- key switch only
 def check_keyswitch_shapes(lib_path, N, n_out, ks_t, ks_bb, B, seed=51):
-    """lweKeySwitch / preKeySwitch on a synthetic (uniformly random) key: exercises the batch-tiled
-    kernel's row padding / tiling for the real output sizes, and the gather kernel beside it."""
+    """lweKeySwitch / preKeySwitch on a synthetic (uniformly random) key: exercises the
+    matrix-core kernel's column blocks / K padding for the real output sizes, and the gather kernel beside it."""
     import os
     rs = np.random.RandomState(seed)
     ks = rs.randint(-2 ** 31, 2 ** 31, size=(N, ks_t, 1 << ks_bb, n_out + 1)).astype(np.int32)

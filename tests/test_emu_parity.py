@@ -43,7 +43,7 @@ def test_gate_path_emu_n2048(emu_lib):
 
 @pytest.mark.parametrize("n_out,t,bb,B", [(630, 8, 2, 17), (500, 6, 2, 3), (630, 16, 1, 2)])
 def test_keyswitch_real_shapes_emu(emu_lib, n_out, t, bb, B):
-    """gate key switch 8x2 and 16x1 (n=630) and the PoC's preKeySwitch 6x2 (n0=500): tiled + gather kernels"""
+    """gate key switch 8x2 and 16x1 (n=630) and the PoC's preKeySwitch 6x2 (n0=500): matrix-core + gather kernels"""
     P.check_keyswitch_shapes(emu_lib, 1024, n_out, t, bb, B)
 
 

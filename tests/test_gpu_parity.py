@@ -84,10 +84,12 @@ def test_keyswitch_second_config(gpu_lib):
     P.check_gate_path(gpu_lib, N=1024, n=12, l=2, Bgbit=10, ks_t=16, ks_bb=1, B=5, seed=8, check_export=False)
 
 
-@pytest.mark.parametrize("n_out,t,bb,B", [(630, 8, 2, 67), (500, 6, 2, 33), (630, 16, 1, 16), (700, 4, 3, 5)])
+@pytest.mark.parametrize("n_out,t,bb,B", [(630, 8, 2, 67), (500, 6, 2, 33), (630, 16, 1, 16), (700, 4, 3, 5),
+                                          (500, 10, 3, 9), (300, 5, 3, 261), (33, 31, 1, 3)])
 def test_keyswitch_real_shapes(gpu_lib, n_out, t, bb, B):
-    """lweKeySwitch at the gate sizes, preKeySwitch at the PoC sizes (both through the batch-tiled
-    and the gather kernel) and one shape only the gather kernel covers"""
+    """lweKeySwitch at the gate sizes, preKeySwitch at the PoC sizes (both through the matrix-core
+    and the gather kernel), base-8 shapes with 1, 2 and 3 K-steps per input coefficient, a batch that spans two
+    256-sample tiles, and the longest base-2 decomposition"""
     P.check_keyswitch_shapes(gpu_lib, 1024, n_out, t, bb, B)
 
 
