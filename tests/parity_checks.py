@@ -394,6 +394,56 @@ def check_circuit_bootstrap(lib_path, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t
         cb.close()
 
 
+# ------------------------------------------------- empty batches, state and parameter errors
+def check_abi_edges(lib_path):
+    """Empty batches are no-ops that touch nothing; calls made in the wrong state or with bad arguments fail
+    with the documented status (include/tfhe_amd.h) instead of computing -- the reference asserts/aborts in
+    the same situations (lwe_functions.cpp:480-481)."""
+    import ctypes as C
+    N, n = 1024, 3
+    e = T.Engine(torus_bits=32, n=n, N=N, l=2, Bgbit=10, ks_t=8, ks_basebit=2, lib_path=lib_path)
+    lib = e.lib
+    try:
+        sentinel = np.full((2, n + 1), 0x5A5A5A5A, np.int32)
+        d_out, d_in = e.to_device(sentinel), e.to_device(np.zeros((2, N + 1), np.int32))
+        # nothing loaded yet: bootstrap and key switch must refuse
+        assert lib.tfhe_amd_bootstrap(e.ctx, d_out.ptr, 1 << 29, d_in.ptr, 1) == T.ERR_STATE
+        assert lib.tfhe_amd_keyswitch(e.ctx, d_out.ptr, d_in.ptr, 1) == T.ERR_STATE
+        assert b"key" in lib.tfhe_amd_last_error(e.ctx)
+        lk, tk = O.keygen_binary(n, SEED, 1), O.keygen_binary(N, SEED, 2)
+        bk = O.bk_create32(N, lk, tk, 2, 10, 2.0 ** -25, SEED, 1000)
+        g = e.gsw_from_fft(bk)
+        # a bootstrapping key of the wrong length is a parameter error
+        g1 = e.gsw_from_fft(bk[:1])
+        assert lib.tfhe_amd_set_bootstrap_key(e.ctx, g1) == T.ERR_PARAM
+        e.set_bootstrap_key(g)
+        e.load_keyswitch_key(O.ks_create32(tk, lk, 8, 2, 2.0 ** -15, SEED, 100000))
+        # empty batches: OK, outputs untouched
+        for call in (lambda: lib.tfhe_amd_bootstrap(e.ctx, d_out.ptr, 1 << 29, d_in.ptr, 0),
+                     lambda: lib.tfhe_amd_bootstrap_woks(e.ctx, d_out.ptr, 1 << 29, d_in.ptr, 0),
+                     lambda: lib.tfhe_amd_keyswitch(e.ctx, d_out.ptr, d_in.ptr, 0),
+                     lambda: lib.tfhe_amd_bootstrap_streamed(e.ctx, d_out.ptr, 1 << 29, d_in.ptr, 0),
+                     lambda: lib.tfhe_amd_extern_mul(e.ctx, d_in.ptr, g, 0, 0),
+                     lambda: lib.tfhe_amd_blind_rotate(e.ctx, d_in.ptr, d_out.ptr, 0),
+                     lambda: lib.tfhe_amd_modswitch(e.ctx, d_out.ptr, d_in.ptr, 0),
+                     lambda: lib.tfhe_amd_ifft_int32(e.ctx, d_in.ptr, d_out.ptr, 0),
+                     lambda: lib.tfhe_amd_fft_torus32(e.ctx, d_out.ptr, d_in.ptr, 0)):
+            assert call() == T.OK
+        e.sync()
+        assert np.array_equal(d_out.download(np.int32, sentinel.shape), sentinel), "an empty batch wrote to its output"
+        # bad arguments
+        assert lib.tfhe_amd_bootstrap(e.ctx, None, 1 << 29, d_in.ptr, 1) == T.ERR_PARAM
+        assert lib.tfhe_amd_bootstrap(e.ctx, d_out.ptr, 1 << 29, d_in.ptr, -1) == T.ERR_PARAM
+        assert lib.tfhe_amd_extern_mul(e.ctx, d_in.ptr, g, n, 1) == T.ERR_PARAM  # TGSW index out of range
+        assert lib.tfhe_amd_set_option(e.ctx, 99, 0) == T.ERR_PARAM
+        # a batch of one still works after all of that (state intact)
+        x = O.lwe_encrypt32(1 << 29, 2.0 ** -15, lk, O.rng(SEED, 77))
+        got = e.bootstrap(1 << 29, x[None, :])
+        assert np.array_equal(got[0], O.bootstrap32(N, bk, O.ks_create32(tk, lk, 8, 2, 2.0 ** -15, SEED, 100000), 1 << 29, x, 2, 10, 8, 2))
+    finally:
+        e.close()
+
+
 # --------------------------------------------------------------- key switch only
 def check_keyswitch_shapes(lib_path, N, n_out, ks_t, ks_bb, B, seed=51):
     """lweKeySwitch / preKeySwitch on a synthetic (uniformly random) key: exercises the

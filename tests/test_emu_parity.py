@@ -83,3 +83,8 @@ def test_circuit_bootstrap_emu(emu_lib):
 @pytest.mark.parametrize("N,l,Bgbit,B", [(2048, 4, 9, 4), (1024, 3, 10, 5)])
 def test_torus64_path_emu(emu_lib, N, l, Bgbit, B):
     P.check_torus64_path(emu_lib, N=N, n=3, l=l, Bgbit=Bgbit, B=B)
+
+
+def test_abi_edges_emu(emu_lib):
+    """empty batches, calls in the wrong state, bad arguments (status codes of include/tfhe_amd.h)"""
+    P.check_abi_edges(emu_lib)

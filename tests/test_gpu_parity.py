@@ -214,3 +214,8 @@ def test_n2048_transform_batch_8192(gpu_lib):
         assert np.abs(err).max() < 2 ** 14
     finally:
         e.close()
+
+
+def test_abi_edges(gpu_lib):
+    """empty batches, calls in the wrong state, bad arguments (status codes of include/tfhe_amd.h)"""
+    P.check_abi_edges(gpu_lib)
