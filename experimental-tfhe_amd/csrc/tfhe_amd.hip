@@ -1176,12 +1176,10 @@ int launch_privks_t(tfhe_amd_cb *cb, int32_t *out_d, long long stride_in_group, 
     if (slices < 1) slices = 1;
     int i_per_block = ((n2 + 1 + slices - 1) / slices + 63) / 64 * 64;
     slices = (n2 + 1 + i_per_block - 1) / i_per_block;
-    if (cb->p.t21 * BB <= 32)  // all digits in the upper word of each input
-        TFHE_LAUNCH((k_privks<int64_t, TB, BB, EPT, 256, false, true>), dim3(tiles, slices), dim3(256), 0, c->stream, out_d,
-                    stride_in_group, stride_of_group, group, x_d, n2 + 1, tab, n2, cb->p.t21, row, count, i_per_block);
-    else
-        TFHE_LAUNCH((k_privks<int64_t, TB, BB, EPT, 256, false, false>), dim3(tiles, slices), dim3(256), 0, c->stream, out_d,
-                    stride_in_group, stride_of_group, group, x_d, n2 + 1, tab, n2, cb->p.t21, row, count, i_per_block);
+    // (fallback: only reached when t21 * basebit > 32, i.e. the digits span both words of each input;
+    // the other shapes go through k_ks_mfma)
+    TFHE_LAUNCH((k_privks<int64_t, TB, BB, EPT, 256>), dim3(tiles, slices), dim3(256), 0, c->stream, out_d,
+                stride_in_group, stride_of_group, group, x_d, n2 + 1, tab, n2, cb->p.t21, row, count, i_per_block);
     if (hipGetLastError() != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "k_privks launch");
     return TFHE_AMD_OK;
 }

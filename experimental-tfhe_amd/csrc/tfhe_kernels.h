@@ -1413,16 +1413,14 @@ TFHE_GLOBAL void k_keyswitch32(int32_t *__restrict__ out, const int32_t *__restr
 //        (the circuit bootstrap runs its l1 gadget levels as l1 groups of one launch)
 // FALLBACK for shapes the matrix-core kernel (k_ks_mfma below) does not cover (t * basebit > 32); the
 // PoC's 10 x 3 goes through k_ks_mfma.
-// HI_ONLY (64-bit inputs): every digit lies in the upper 32 bits (t * basebit <= 32, as at the PoC's 10 x 3),
-// so only that word of each input is kept and broadcast: half the scalar registers.
-template <typename XT, int TB, int BB, int EPT, int THREADS, bool PACKED, bool HI_ONLY = false>
+template <typename XT, int TB, int BB, int EPT, int THREADS>
 TFHE_GLOBAL void __launch_bounds__(THREADS)
     k_privks(int32_t *__restrict__ out, long long stride_in_group, long long stride_of_group, int group,
              const XT *__restrict__ x, int x_stride, const int32_t *__restrict__ tab, int n2, int t, int row_ints,
              int count, int i_per_block) {
     using UX = typename std::make_unsigned<XT>::type;
     constexpr int NR = (1 << BB) - 1, BASE = 1 << BB, SEG = THREADS * EPT, W = 8 * (int)sizeof(XT);
-    constexpr int ROWS_PER_BLOCK = PACKED ? NR : BASE, FIRST_ROW = PACKED ? 0 : 1;
+    constexpr int ROWS_PER_BLOCK = BASE, FIRST_ROW = 1;
     constexpr UX mask = (UX)BASE - 1;
     const int lane = threadIdx.x & 63;
     const int tile0 = blockIdx.x * TB;
@@ -1441,7 +1439,7 @@ TFHE_GLOBAL void __launch_bounds__(THREADS)
 #pragma unroll 1
         for (int i0 = i_begin; i0 < i_end; i0 += 64) {
             // lane L: x[b][i0+L] + prec_offset (0 => all digits 0); the words that carry digits
-            constexpr bool TWO_WORDS = sizeof(XT) == 8 && !HI_ONLY;
+            constexpr bool TWO_WORDS = sizeof(XT) == 8;
             using AB = typename std::conditional<TWO_WORDS, uint64_t, uint32_t>::type;
             constexpr int WA = TWO_WORDS ? 64 : 32;
             int a0[TB], a1[TWO_WORDS ? TB : 1];
@@ -1457,7 +1455,7 @@ TFHE_GLOBAL void __launch_bounds__(THREADS)
             for (int b = 0; b < TB; b++) {
                 const bool ok = (tile0 + b < count) && (i0 + lane < i_end);
                 const UX v = ok ? (UX)(raw[b] + prec_offset) : (UX)0;
-                a0[b] = (sizeof(XT) == 8 && HI_ONLY) ? (int)(uint32_t)((uint64_t)v >> 32) : (int)(uint32_t)v;
+                a0[b] = (int)(uint32_t)v;
                 if (TWO_WORDS) a1[TWO_WORDS ? b : 0] = (int)(uint32_t)((uint64_t)v >> 32);
             }
             const int cnt = (i_end - i0 < 64) ? (i_end - i0) : 64;

@@ -150,6 +150,13 @@ def test_circuit_bootstrap_full_poc_block(gpu_lib):
                               bb21=3, B=3, seed=63)
 
 
+def test_privks_two_word_digits(gpu_lib):
+    """a private key switch whose digits span both words of the 64-bit inputs (t21 * basebit = 33 > 32): the
+    shape the matrix-core kernel does not cover, served by the k_privks fallback (1.5 GB synthetic table)"""
+    P.check_circuit_bootstrap(gpu_lib, n0=4, N1=1024, N2=1024, l1=2, bg1=8, l2=3, bg2=10, t10=4, bb10=3, t21=11,
+                              bb21=3, B=3, seed=64)
+
+
 def test_batch_4096_properties(gpu_lib):
     """BASELINE config 2 at full size: 4096 gate bootstraps.  Checked by (i) decrypt-sign of every
     output, (ii) bit-equality with the oracle on a subset, (iii) persistent schedule == one launch
