@@ -27,6 +27,8 @@
     } while (0)
 
 #define TFHE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// no instruction is scheduled across this point
+#define TFHE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // true in every lane iff `cond` holds in at least one active lane of the wave
 #define TFHE_WAVE_ANY(cond) (__builtin_amdgcn_ballot_w64(cond) != 0ull)
 // placed at the top of a wave-uniform `if` body: keeps it a real scalar branch (hipcc otherwise
@@ -68,6 +70,12 @@ __device__ __forceinline__ uint32_t tfhe_lds_offset(const void *p) {
 __device__ __forceinline__ uint32_t tfhe_lds_load32(const void *, uint32_t off) {
     typedef __attribute__((address_space(3))) const uint32_t lds_u32;
     return *(lds_u32 *)(uintptr_t)off;
+}
+// p[idx] for a wave-uniform address of data no kernel writes while this one runs: a scalar load
+// (constant address space), the result lives in a scalar register
+__device__ __forceinline__ int32_t tfhe_uniform_load32(const int32_t *p, int idx) {
+    typedef __attribute__((address_space(4))) const int32_t const_i32;
+    return ((const_i32 *)(uintptr_t)p)[idx];
 }
 #define TFHE_TRAP() __builtin_trap()
 // D = A(32x32 int8) * B(32x32 int8) + C(32x32 int32) on the matrix cores, one wave.  Lane l holds

@@ -561,15 +561,25 @@ TFHE_DEVICE void rotated_minus_one(const WaveLds<T, LOGN> &w, int q, int a, type
         constexpr uint32_t PB = N * 4;  // polynomial size in bytes; bit LOGN + 2 of a byte offset = the sign
         const uint32_t poly_lds = w.acc_lds + (uint32_t)q * PB;
         const uint32_t B = ((uint32_t)(t - a) & (2 * N - 1)) * 4;
+        // the rotated reads are issued GRP at a time and then consumed (left to itself hipcc waits for each
+        // read right behind its issue: one LDS round trip per coefficient); 8 measured best of 4 / 8 / 16
+        constexpr int GRP = 8;
 #pragma unroll
-        for (int m = 0; m < PPL; m++) {
+        for (int g = 0; g < 2 * PPL; g += GRP) {
+            uint32_t src[GRP];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+            for (int e = 0; e < GRP; e++) {
+                const int K = 64 * ((g + e) >> 1) + ((g + e) & 1) * NC;
+                src[e] = tfhe_lds_load32(w.smem, tfhe_and_or(B + (uint32_t)K * 4, PB - 4, poly_lds));
+            }
+            TFHE_SCHED_BARRIER();
+#pragma unroll
+            for (int e = 0; e < GRP; e++) {
+                const int m = (g + e) >> 1, h = (g + e) & 1;
                 const int K = 64 * m + h * NC;
                 const uint32_t x = B + (uint32_t)K * 4;
-                const uint32_t src = tfhe_lds_load32(w.smem, tfhe_and_or(x, PB - 4, poly_lds));
                 const uint32_t s = tfhe_sign_mask<LOGN + 2>(x);
-                const uint32_t v = (tfhe_xad(src, s, (uint32_t)offset - (uint32_t)p[t + K]) - s) ^ (uint32_t)flip;
+                const uint32_t v = (tfhe_xad(src[e], s, (uint32_t)offset - (uint32_t)p[t + K]) - s) ^ (uint32_t)flip;
                 if (h == 0)
                     lo[m] = (U)v;
                 else
@@ -982,13 +992,16 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
         bk0 += (size_t)((ct / A.sel_div) * A.sel_mul + A.sel_add) * A.gsw_sample_stride;
 
     // ---- CMux loop (lwe_functions.cpp:337-361)
+    // the rotation amount is requested one step ahead, as a scalar load
+    int a_next = ((A.flags & BR_NO_ROTATE) || A.n_steps <= 0) ? 0 : tfhe_uniform_load32(rot, 0);
 #pragma unroll 1
     for (int i = 0; i < A.n_steps; i++) {
         const double2 *bkrow = bk0 + (size_t)i * A.bk_step_stride;
         int a = 0;
         const bool rotate = !(A.flags & BR_NO_ROTATE);
         if (rotate) {
-            a = rot[i];
+            a = a_next;
+            a_next = (i + 1 < A.n_steps) ? tfhe_uniform_load32(rot, i + 1) : 0;
             if (A.flags & BR_MODSWITCH) a = modswitch_2N<LOGN>(a);
             a = TFHE_UNIFORM(a);
             if (a == 0) continue;  // :348-350

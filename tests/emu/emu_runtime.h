@@ -45,6 +45,7 @@ using dim3 = emu::Dim3;
 #define TFHE_HOST_DEVICE inline
 #define TFHE_WAVE_FENCE() emu::wave_fence()
 #define TFHE_UNIFORM(x) (x)
+#define TFHE_SCHED_BARRIER() ((void)0)
 #define TFHE_WAVE_ANY(cond) emu::wave_any(cond)
 #define TFHE_KEEP_BRANCH() ((void)0)
 #define TFHE_OPAQUE(x) ((void)0)
@@ -61,6 +62,7 @@ static inline uint32_t tfhe_lds_load32(const void *, uint32_t off) {
     memcpy(&v, emu::dyn_smem() + off, 4);
     return v;
 }
+static inline int32_t tfhe_uniform_load32(const int32_t *p, int idx) { return p[idx]; }
 #define TFHE_TRAP() abort()
 namespace emu {
 typedef int v4i_t __attribute__((vector_size(16)));
