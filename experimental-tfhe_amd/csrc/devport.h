@@ -27,6 +27,10 @@
     } while (0)
 
 #define TFHE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// the SIMD (0..3) this wave runs on: HW_REG_HW_ID bits [5:4]
+#define TFHE_SIMD_ID() ((int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3))
+// issue priority of this wave among the waves of its SIMD (0 lowest .. 3), s_setprio
+#define TFHE_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
 // no instruction is scheduled across this point
 #define TFHE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // true in every lane iff `cond` holds in at least one active lane of the wave

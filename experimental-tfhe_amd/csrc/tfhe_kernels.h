@@ -437,8 +437,36 @@ struct WaveLds {
     T *acc;               // [2][N] accumulator
     typename WaveFFT<LOGN>::Xch xch;  // [Geom::XCH] transpose buffer + lane maps
     TwLds<LOGN> tw;       // twiddle source
+    // Issue balance between the two waves of a SIMD (8-wave workgroups).  Left alone, the SIMD favours one of
+    // its two waves (the older): measured on MI355X, waves 0-3 of a workgroup finished their 630 CMux steps in
+    // 5.7 ms and waves 4-7 in 8.8 ms, the second wave of every SIMD running its last third alone at half the
+    // SIMD's throughput.  Each wave therefore publishes its progress in LDS and takes the high issue priority
+    // (s_setprio) only while it is not ahead of its partner: both finish together (7.9 ms), -7 % kernel time.
+    volatile int *progress;  // [WAVES] steps done by each wave of the workgroup
+    int self, partner;       // partner == self: alone on its SIMD, nothing to do
+    TFHE_DEVICE void balance(int step, int lane) const {
+        if (partner == self) return;
+        if (lane == 0) progress[self] = step;
+        const int other = TFHE_UNIFORM(progress[partner]);
+        if (other < step)
+            TFHE_SETPRIO(0);
+        else
+            TFHE_SETPRIO(3);
+    }
 };
 
+#ifdef TFHE_PROBE
+// PROBE BUILD ONLY (tools/wave_probe.py, -DTFHE_PROBE; the shipped library has none of this): shader clock and
+// in-loop lifetime of every wave, start / end / placement of every workgroup of k_blind_rotate
+__device__ unsigned long long tfhe_dbg[32];  // 0: sum of shader cycles, 1: sum of 100 MHz ticks, 2: waves, [16 + wave]: ticks per wave index
+__device__ unsigned long long tfhe_dbg_wg[1024 * 4];  // per workgroup: start, end (100 MHz ticks), HW_ID, XCC_ID
+TFHE_DEVICE unsigned long long tfhe_clk() {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long c = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    return c;
+}
+#endif
 // Fourier-domain multiply-accumulate of one decomposed limb with one key row
 // (lagrangehalfc_impl_fma.s:96-107), bk already in registers.  FIRST: the accumulator is still the
 // +0 of tLweFFTClear (tgsw_functions.cpp:438) -- fma(a, b, -(+0)) and fma(a, b, +0) are a*b up to the
@@ -894,7 +922,10 @@ struct BlindRotateLds {
     static constexpr size_t acc_at(int wave) { return (size_t)wave * acc_bytes; }
     static constexpr size_t tw_at = WAVES * acc_bytes;
     static constexpr size_t xch_at(int wave) { return tw_at + tw_bytes + (size_t)wave * xch_bytes; }
-    static constexpr size_t total = tw_bytes + WAVES * wave_bytes;
+    // after the transpose buffers: per-wave progress counters and SIMD ids (WaveLds::balance)
+    static constexpr size_t sync_at = tw_bytes + WAVES * wave_bytes;
+    static constexpr size_t total = sync_at + 64;
+    static_assert(WAVES <= 8, "sync area holds 8 + 8 ints");
 };
 
 #ifdef TFHE_EMU
@@ -910,6 +941,19 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
     using Lds = BlindRotateLds<T, LOGN, WAVES>;
     constexpr int N = G::N, PPL = G::PPL;
     TFHE_DYN_LDS(smem);
+#ifdef TFHE_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        tfhe_dbg_wg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        tfhe_dbg_wg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        tfhe_dbg_wg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
+    volatile int *sync = reinterpret_cast<volatile int *>(smem + Lds::sync_at);  // [wave]: progress; [8 + wave]: SIMD of the wave
+    const int my_simd = TFHE_SIMD_ID();
+    if ((threadIdx.x & 63) == 0) {
+        sync[threadIdx.x >> 6] = -1;
+        sync[8 + (threadIdx.x >> 6)] = my_simd;
+    }
     {
         double2 *tw = reinterpret_cast<double2 *>(smem + Lds::tw_at);
         for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = A.tw[i];
@@ -918,6 +962,9 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
 
     const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
     const int t = threadIdx.x & 63;
+    int partner = wave;  // the other wave of this workgroup on the same SIMD (8-wave workgroups: exactly one)
+    for (int k = 0; k < WAVES; k++)
+        if (k != wave && sync[8 + k] == my_simd) partner = k;
     const int ct = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
     if (ct >= A.batch) return;
 
@@ -929,6 +976,9 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
     w.xch = WaveFFT<LOGN>::make_xch(reinterpret_cast<double *>(smem + Lds::xch_at(wave)), t);
     w.tw.tw = reinterpret_cast<const double2 *>(smem + Lds::tw_at);
     w.tw.t = t;
+    w.progress = sync;
+    w.self = wave;
+    w.partner = TFHE_UNIFORM(partner);
 
     const int32_t *rot = A.rot + (size_t)ct * A.rot_stride;
     // The accumulator: [2][N] in the wave's LDS slice, or (ACCREG) accr[q][h][m] = coefficient
@@ -992,6 +1042,9 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
         bk0 += (size_t)((ct / A.sel_div) * A.sel_mul + A.sel_add) * A.gsw_sample_stride;
 
     // ---- CMux loop (lwe_functions.cpp:337-361)
+#ifdef TFHE_PROBE
+    const unsigned long long dbg_c0 = tfhe_clk(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // the rotation amount is requested one step ahead, as a scalar load
     int a_next = ((A.flags & BR_NO_ROTATE) || A.n_steps <= 0) ? 0 : tfhe_uniform_load32(rot, 0);
 #pragma unroll 1
@@ -1006,9 +1059,21 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
             a = TFHE_UNIFORM(a);
             if (a == 0) continue;  // :348-350
         }
+        w.balance(i, t);
         cmux_step<T, LOGN, PAIR, LC, BGC, Lds::CPLX_XCH, (WAVES <= 4), ACCREG>(w, bkrow, a, rotate, A.gd, t, accr);
     }
 
+#ifdef TFHE_PROBE
+    {
+        const unsigned long long c1 = tfhe_clk(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (t == 0) {
+            atomicAdd(&tfhe_dbg[0], c1 - dbg_c0);
+            atomicAdd(&tfhe_dbg[1], r1 - dbg_r0);
+            atomicAdd(&tfhe_dbg[2], 1ull);
+            atomicAdd(&tfhe_dbg[16 + (wave & 7)], r1 - dbg_r0);
+        }
+    }
+#endif
     // ---- output
     if (A.flags & BR_EXTRACT) {  // tLweExtractLweSampleIndex, index 0 (tlwe_functions.cpp:351-363)
         T *out = A.lwe_out + (size_t)ct * (N + 1);
@@ -1054,6 +1119,9 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
 #undef ACC_REG
 #undef ACC_SET
 #undef ACC_GET
+#ifdef TFHE_PROBE
+    if (t == 0 && blockIdx.x < 1024) atomicMax(&tfhe_dbg_wg[blockIdx.x * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // ------------------------------------------- standalone batched transforms

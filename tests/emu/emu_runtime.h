@@ -46,6 +46,8 @@ using dim3 = emu::Dim3;
 #define TFHE_WAVE_FENCE() emu::wave_fence()
 #define TFHE_UNIFORM(x) (x)
 #define TFHE_SCHED_BARRIER() ((void)0)
+#define TFHE_SIMD_ID() ((int)((threadIdx.x >> 6) & 3))
+#define TFHE_SETPRIO(p) ((void)0)
 #define TFHE_WAVE_ANY(cond) emu::wave_any(cond)
 #define TFHE_KEEP_BRANCH() ((void)0)
 #define TFHE_OPAQUE(x) ((void)0)

@@ -22,11 +22,12 @@ def test_lds_budgets_fit_160k():
         accreg = (N == 2048 and torus_bytes == 8)    # accumulator in registers, one scratch polynomial in LDS
         cplx = (N == 1024) or accreg                 # complex-point transposes
         xch = (16 if cplx else 8) * (NC + 64)
+        sync = 64                                    # progress counters + SIMD ids (WaveLds::balance)
         if accreg:
-            return 16 * 2 * NC + waves * max(torus_bytes * N, xch)
-        return 16 * 2 * NC + waves * (torus_bytes * 2 * N + xch)
-    assert br(4, 1024, 8) == 155648 <= 163840
+            return 16 * 2 * NC + waves * max(torus_bytes * N, xch) + sync
+        return 16 * 2 * NC + waves * (torus_bytes * 2 * N + xch) + sync
+    assert br(4, 1024, 8) == 155648 + 64 <= 163840
     assert br(4, 2048, 4) <= 163840
     assert br(8, 1024, 4) <= 163840
-    assert br(8, 2048, 4) == 32768 + 4 * 17408 <= 163840
+    assert br(8, 2048, 4) == 32768 + 4 * 17408 + 64 <= 163840
     assert 2 * (2 * 8 * 4096) <= 163840  # k_ks_mfma: two workgroups per CU, double-buffered key slices of 8 K-steps
