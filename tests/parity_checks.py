@@ -357,6 +357,41 @@ def check_rounding_extremes(lib_path):
         e.close()
 
 
+def check_rounding_extremes64(lib_path, N=1024, l=4, Bgbit=9):
+    """Torus64 rounding: the short sequence holds for |x| < 2^83, beyond it the kernel falls back to the
+    reference's bit-field form (per wave).  All digits -Bg/2 against key coefficients -2^63 reach
+    2*l*N*(Bg/2)*2^63 >= 2^84; mixed with ordinary samples and keys in one batch, plus values straddling the
+    2^32 split (ties) that the short sequence treats specially."""
+    rs = np.random.RandomState(78)
+    offset = 0
+    for i in range(l + 1):
+        offset |= 1 << (63 - i * Bgbit)                      # poc:349-350 (with the rounding bit)
+    e = T.Engine(torus_bits=64, n=3, N=N, l=l, Bgbit=Bgbit, ks_t=0, lib_path=lib_path)
+    try:
+        coef = np.full((3, 2 * l, 2, N), -2 ** 63, np.int64)
+        coef[1] = rs.randint(-2 ** 63, 2 ** 63 - 1, size=(2 * l, 2, N), dtype=np.int64)   # ordinary key
+        coef[2, :, :, ::2] = 2 ** 63 - 1                                                  # alternating extremes
+        gsw_lag = O.execute_reverse_torus64(N, coef.reshape(-1, N)).reshape(3, 2 * l, 2, N)
+        g = e.gsw_from_fft(gsw_lag)
+        allneg = np.full(2 * N, (-offset) & (2 ** 64 - 1), np.uint64).view(np.int64)       # every digit = -Bg/2
+        rnd = lambda: rs.randint(-2 ** 63, 2 ** 63 - 1, size=2 * N, dtype=np.int64)
+        acc = np.stack([allneg, rnd(), np.where(np.arange(2 * N) % 3 == 0, allneg, 0).astype(np.int64), allneg, rnd(),
+                        allneg]).reshape(6, 2, N)   # more samples than one workgroup has waves: the choice is per wave
+        for idx in range(3):
+            want = np.stack([O.extprod64(N, acc[b], gsw_lag[idx], l, Bgbit) for b in range(6)]).reshape(6, 2, N)
+            assert np.array_equal(e.extern_mul(acc, g, idx), want), f"Torus64 external product at extreme magnitude (key {idx})"
+        # a key that is the constant polynomial 1 in one slot: the product is the digit polynomial itself, small
+        # integers whose roundings sit exactly on / next to integers and the 2^32 split of the short sequence
+        one = np.zeros((1, 2 * l, 2, N), np.int64)
+        one[0, :, :, 0] = np.array([1, 2 ** 31, 2 ** 32, -2 ** 31, 2 ** 32 + 1, -(2 ** 32), 2 ** 33 - 1, -(2 ** 31) - 1][:2 * l]).reshape(2 * l, 1)
+        lag1 = O.execute_reverse_torus64(N, one.reshape(-1, N)).reshape(1, 2 * l, 2, N)
+        g1 = e.gsw_from_fft(lag1)
+        want = np.stack([O.extprod64(N, acc[b], lag1[0], l, Bgbit) for b in range(6)]).reshape(6, 2, N)
+        assert np.array_equal(e.extern_mul(acc, g1, 0), want), "Torus64 external product, products on the 2^31 / 2^32 boundaries"
+    finally:
+        e.close()
+
+
 # ------------------------------------------------------------ circuit bootstrap
 def check_circuit_bootstrap(lib_path, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, B, seed=61):
     """circuitPrivKS and the whole tfhe_CircuitBootstrapFFT pipeline (preKeySwitch, preModSwitch,

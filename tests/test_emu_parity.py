@@ -26,6 +26,12 @@ def test_rounding_extremes_emu(emu_lib):
     P.check_rounding_extremes(emu_lib)
 
 
+@pytest.mark.parametrize("N,l,Bgbit", [(1024, 4, 9), (2048, 4, 9)])
+def test_rounding_extremes_torus64_emu(emu_lib, N, l, Bgbit):
+    """the short Torus64 rounding sequence, its guard and the exact fallback (both blind-rotation shapes)"""
+    P.check_rounding_extremes64(emu_lib, N=N, l=l, Bgbit=Bgbit)
+
+
 def test_gate_path_emu_runtime_gadget(emu_lib):
     """l = 2 with a Bgbit the kernel has no compile-time instantiation for, and l = 4 (two digit pairs per polynomial)"""
     P.check_gate_path(emu_lib, N=1024, n=3, l=2, Bgbit=9, ks_t=8, ks_bb=2, B=3, check_export=False, seed=12)

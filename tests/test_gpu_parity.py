@@ -74,6 +74,12 @@ def test_rounding_extremes(gpu_lib):
     P.check_rounding_extremes(gpu_lib)
 
 
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_rounding_extremes_torus64(gpu_lib, N):
+    """Torus64 rounding: short sequence (|x| < 2^83), guard and exact fallback at magnitudes up to 2^85"""
+    P.check_rounding_extremes64(gpu_lib, N=N, l=4, Bgbit=9)
+
+
 def test_gate_path_full_parameters(gpu_lib):
     """BASELINE config 1/2 parameter set: n=630, N=1024, k=1, l=2, Bgbit=10, ks 8x2"""
     P.check_gate_path(gpu_lib, N=1024, n=630, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=6, check_export=True)
