@@ -81,6 +81,16 @@ __device__ __forceinline__ int32_t tfhe_uniform_load32(const int32_t *p, int idx
     typedef __attribute__((address_space(4))) const int32_t const_i32;
     return ((const_i32 *)(uintptr_t)p)[idx];
 }
+// 32-bit LDS word shared between waves of the workgroup (progress counters): plain DS instructions on an
+// LDS byte offset, re-read on every call (a generic `volatile int *` compiles to FLAT accesses here)
+__device__ __forceinline__ uint32_t tfhe_lds_peek32(uint32_t off) {
+    typedef __attribute__((address_space(3))) volatile const uint32_t lds_vu32;
+    return *(lds_vu32 *)(uintptr_t)off;
+}
+__device__ __forceinline__ void tfhe_lds_poke32(uint32_t off, uint32_t v) {
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    *(lds_vu32 *)(uintptr_t)off = v;
+}
 #define TFHE_TRAP() __builtin_trap()
 // D = A(32x32 int8) * B(32x32 int8) + C(32x32 int32) on the matrix cores, one wave.  Lane l holds
 // A[row l & 31][k = 16 * (l >> 5) + 0..15] and B[k = 16 * (l >> 5) + 0..15][col l & 31] as 16 bytes each;

@@ -459,12 +459,12 @@ struct WaveLds {
     // 5.7 ms and waves 4-7 in 8.8 ms, the second wave of every SIMD running its last third alone at half the
     // SIMD's throughput.  Each wave therefore publishes its progress in LDS and takes the high issue priority
     // (s_setprio) only while it is not ahead of its partner: both finish together (7.9 ms), -7 % kernel time.
-    volatile int *progress;  // [WAVES] steps done by each wave of the workgroup
+    uint32_t progress_lds;   // LDS byte offset of int[WAVES]: steps done by each wave of the workgroup
     int self, partner;       // partner == self: alone on its SIMD, nothing to do
     TFHE_DEVICE void balance(int step, int lane) const {
         if (partner == self) return;
-        if (lane == 0) progress[self] = step;
-        const int other = TFHE_UNIFORM(progress[partner]);
+        if (lane == 0) tfhe_lds_poke32(progress_lds + 4u * (uint32_t)self, (uint32_t)step);
+        const int other = TFHE_UNIFORM((int)tfhe_lds_peek32(progress_lds + 4u * (uint32_t)partner));
         if (other < step)
             TFHE_SETPRIO(0);
         else
@@ -965,11 +965,11 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
         tfhe_dbg_wg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 #endif
-    volatile int *sync = reinterpret_cast<volatile int *>(smem + Lds::sync_at);  // [wave]: progress; [8 + wave]: SIMD of the wave
+    const uint32_t sync_lds = tfhe_lds_offset(smem + Lds::sync_at);  // int [wave]: progress; [8 + wave]: SIMD of the wave
     const int my_simd = TFHE_SIMD_ID();
     if ((threadIdx.x & 63) == 0) {
-        sync[threadIdx.x >> 6] = -1;
-        sync[8 + (threadIdx.x >> 6)] = my_simd;
+        tfhe_lds_poke32(sync_lds + 4u * (threadIdx.x >> 6), (uint32_t)-1);
+        tfhe_lds_poke32(sync_lds + 4u * (8 + (threadIdx.x >> 6)), (uint32_t)my_simd);
     }
     {
         double2 *tw = reinterpret_cast<double2 *>(smem + Lds::tw_at);
@@ -981,7 +981,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
     const int t = threadIdx.x & 63;
     int partner = wave;  // the other wave of this workgroup on the same SIMD (8-wave workgroups: exactly one)
     for (int k = 0; k < WAVES; k++)
-        if (k != wave && sync[8 + k] == my_simd) partner = k;
+        if (k != wave && (int)tfhe_lds_peek32(sync_lds + 4u * (uint32_t)(8 + k)) == my_simd) partner = k;
     const int ct = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
     if (ct >= A.batch) return;
 
@@ -993,7 +993,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
     w.xch = WaveFFT<LOGN>::make_xch(reinterpret_cast<double *>(smem + Lds::xch_at(wave)), t);
     w.tw.tw = reinterpret_cast<const double2 *>(smem + Lds::tw_at);
     w.tw.t = t;
-    w.progress = sync;
+    w.progress_lds = sync_lds;
     w.self = wave;
     w.partner = TFHE_UNIFORM(partner);
 
