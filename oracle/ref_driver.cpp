@@ -344,7 +344,8 @@ int main(int argc, char **argv) {
         // (decomposition tgsw_functions.cpp:224-337, rotation numeric_functions.cpp:304-347,
         // extraction tlwe_functions.cpp:351-363, mod switch numeric_functions.cpp:54-60, key switch
         // lwe_functions.cpp:136-171) is written here because those reference files do not compile.
-        //   boot32  args: n l Bgbit ks_t ks_bb count ; in: [mu i32][pad i32][bkfft][ks][x] ; out: count*(n+1) i32
+        //   boot32  args: n l Bgbit ks_t ks_bb count [first] ; in: [mu i32][pad i32][bkfft][ks][x rows] ; out: count*(n+1) i32
+        //           (rows first .. first+count-1 of x: one input file serves several processes)
         //   bench32 args: n l Bgbit ks_t ks_bb seconds ; synthetic keys/samples; prints "<count> <seconds>"
         const int N = 1024, n = (int)arg(0), l = (int)arg(1), Bgbit = (int)arg(2), t = (int)arg(3), bb = (int)arg(4);
         const int kpl = 2 * l, base = 1 << bb;
@@ -364,8 +365,14 @@ int main(int argc, char **argv) {
             memcpy(ks.data(), p, ks_len * 4);
             p += ks_len * 4;
             count = (size_t)arg(5);
+            const size_t first = (size_t)arg(6);
+            const size_t have = (in.size() - (size_t)(p - in.data())) / 4 / (size_t)(n + 1);
+            if (first + count > have) {
+                fprintf(stderr, "boot32: rows %zu..%zu requested, the file holds %zu\n", first, first + count, have);
+                return 2;
+            }
             xs.resize(count * (n + 1));
-            memcpy(xs.data(), p, xs.size() * 4);
+            memcpy(xs.data(), p + first * (size_t)(n + 1) * 4, xs.size() * 4);
         } else {
             budget = (double)arg(5);
             SplitMix rng(42);

@@ -117,7 +117,7 @@ def pytest_collection_finish(session):
     _install_tripwire()
     if not gpu_present():
         return
-    for mod in ("test_compat", "test_dropin"):
+    for mod in ("test_ref_batch", "test_compat", "test_dropin"):
         if any(os.path.basename(str(i.fspath)) == mod + ".py" for i in gpu_items):
             try:
                 importlib.import_module(mod).prerun_gpu_drivers()

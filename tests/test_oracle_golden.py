@@ -109,3 +109,29 @@ def test_live_reference_fresh_inputs(N):
     assert np.array_equal(O.execute_direct_torus32(N, acc), O.ref("dir_t32", acc, np.int32, N).reshape(cnt, N))
     acc64 = O.lagrange_addmul(N, np.zeros((cnt, N)), ld, l64)
     assert np.array_equal(O.execute_direct_torus64(N, acc64), O.ref("dir_t64", acc64, np.int64, N).reshape(cnt, N))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref/ref_driver not built here")
+def test_oracle_gate_bootstrap_matches_reference_object_code():
+    """tfhe_bootstrap_FFT end to end: the oracle against the composition of the reference's OWN transform /
+    multiply-accumulate object code (ref_driver boot32: fftp1024.execute_reverse_int, the AddMul assembly,
+    fftp1024.execute_direct_torus32 around the integer glue of lwe_functions.cpp:136-171,337-446), on real
+    keys at a short n (the per-step arithmetic does not depend on n), incl. the slice argument the GPU
+    full-batch test uses."""
+    N, n, l, Bgbit, t, bb = 1024, 6, 2, 10, 8, 2
+    seed = 0x5446484500000001
+    lk, tk = O.keygen_binary(n, seed, 1), O.keygen_binary(N, seed, 2)
+    bk = O.bk_create32(N, lk, tk, l, Bgbit, 2.0 ** -25, seed, 1000)
+    ks = O.ks_create32(tk, lk, t, bb, 2.0 ** -15, seed, 100000)
+    mu = 1 << 29
+    rs = np.random.RandomState(5)
+    x = np.concatenate([np.stack([O.lwe_encrypt32(mu if i % 2 else -mu, 2.0 ** -15, lk, O.rng(seed, 70 + i)) for i in range(3)]),
+                        rs.randint(-2 ** 31, 2 ** 31, size=(3, n + 1)).astype(np.int32)])
+    x[4, 2] = 0  # a rotation by zero: the skipped step (lwe_functions.cpp:348-350)
+    want = np.stack([O.bootstrap32(N, bk, ks, mu, x[i], l, Bgbit, t, bb) for i in range(6)])
+    blob = (np.array([mu, 0], np.int32).tobytes() + np.ascontiguousarray(bk, np.float64).tobytes()
+            + np.ascontiguousarray(ks, np.int32).tobytes() + x.tobytes())
+    got = O.ref("boot32", blob, np.int32, n, l, Bgbit, t, bb, 6).reshape(6, n + 1)
+    assert np.array_equal(got, want)
+    part = O.ref("boot32", blob, np.int32, n, l, Bgbit, t, bb, 2, 3).reshape(2, n + 1)   # rows 3..4
+    assert np.array_equal(part, want[3:5])
