@@ -1,7 +1,10 @@
-"""BASELINE config 2 at full size against the compiled reference: every output of a 4096-sample batch of gate
+"""BASELINE configs 2 and 4 at full size against the compiled reference.  Config 2: every output of a 4096-sample batch of gate
 bootstraps (n=630, N=1024, l=2, key switch 8x2) from the HIP engine, compared bit for bit with
 `oracle/_ref/ref_driver boot32` -- tfhe_bootstrap_FFT composed from the reference's own FFT / AddMul object code
 (CB/spqlios/*.s, fft_processor_spqlios.cpp) -- run by one CPU process per host core.
+
+Config 4: the four `execute_*` conversions at N=2048 on a batch of 8192 polynomials against `ref_driver rev_int /
+rev_t64 / dir_t32 / dir_t64` (FFT_Processor_Spqlios on the reference's assembly transforms), every polynomial.
 
 The reference processes are children: they run in conftest.pytest_collection_finish (prerun_gpu_drivers), before
 this process touches the GPU; the test itself only loads their outputs.  oracle/_ref/ travels to the GPU box
@@ -36,6 +39,36 @@ def _inputs():
     return lk, bk, ks, x
 
 
+FFT_N, FFT_B = 2048, 8192
+
+
+def _fft_inputs():
+    rs = np.random.RandomState(2048)
+    dig = rs.randint(-256, 256, size=(FFT_B, FFT_N)).astype(np.int32)              # gadget digits (Bgbit2 = 9)
+    a64 = rs.randint(-2 ** 63, 2 ** 63 - 1, size=(FFT_B, FFT_N), dtype=np.int64)   # Torus64 polynomials
+    return dig, a64
+
+
+def _ref_file(op, src, dst, *args):
+    rc = subprocess.call([O.REF_DRIVER, op, os.path.join(RUN_DIR, src), os.path.join(RUN_DIR, dst)] + [str(a) for a in args])
+    if rc:
+        raise RuntimeError("ref_driver %s failed (%d)" % (op, rc))
+
+
+def _prerun_fft():
+    dig, a64 = _fft_inputs()
+    dig.tofile(os.path.join(RUN_DIR, "fft_dig.bin"))
+    a64.tofile(os.path.join(RUN_DIR, "fft_a64.bin"))
+    _ref_file("rev_int", "fft_dig.bin", "fft_lag_dig.bin", FFT_N)       # execute_reverse_int
+    _ref_file("rev_t64", "fft_a64.bin", "fft_lag_a64.bin", FFT_N)       # execute_reverse_torus64
+    _ref_file("dir_t64", "fft_lag_a64.bin", "fft_t64.bin", FFT_N)       # execute_direct_torus64
+    _ref_file("dir_t32", "fft_lag_dig.bin", "fft_t32.bin", FFT_N)       # execute_direct_torus32
+    for f in ("fft_dig.bin", "fft_a64.bin"):
+        os.remove(os.path.join(RUN_DIR, f))
+    with open(os.path.join(RUN_DIR, "fft_done"), "w") as f:
+        f.write("ok\n")
+
+
 def prerun_gpu_drivers():
     """conftest.pytest_collection_finish, on a GPU box, before this process initialises the GPU"""
     if not O.have_ref():
@@ -43,6 +76,7 @@ def prerun_gpu_drivers():
     os.makedirs(RUN_DIR, exist_ok=True)
     for f in os.listdir(RUN_DIR):
         os.remove(os.path.join(RUN_DIR, f))
+    _prerun_fft()
     lk, bk, ks, x = _inputs()
     fin = os.path.join(RUN_DIR, "in.bin")
     with open(fin, "wb") as f:
@@ -95,6 +129,28 @@ def test_full_batch_bit_identical_to_compiled_reference(gpu_lib):
     assert bad.size == 0, "%d of %d bootstraps differ from the compiled reference (first: %s)" % (bad.size, BATCH, bad[:8])
     # and the 64 real encryptions decrypt to their messages
     assert all((O.lwe_phase32(got[i], lk) > 0) == bool(i % 2) for i in range(64))
+
+
+@pytest.mark.gpu
+def test_n2048_transforms_batch_8192_bit_identical_to_compiled_reference(gpu_lib):
+    """BASELINE config 4: all 8192 polynomials of each conversion against FFT_Processor_Spqlios itself"""
+    if not O.have_ref():
+        pytest.skip("oracle/_ref/ref_driver not present")
+    assert os.path.exists(os.path.join(RUN_DIR, "fft_done")), "the reference processes did not run before the session's GPU tests"
+    import parity_checks as P
+    dig, a64 = _fft_inputs()
+    load = lambda name, dt: np.fromfile(os.path.join(RUN_DIR, name), dt).reshape(FFT_B, FFT_N)
+    T = importlib.import_module("experimental-tfhe_amd")
+    e = T.Engine(torus_bits=64, n=1, N=FFT_N, l=4, Bgbit=9, ks_t=0, lib_path=gpu_lib)
+    try:
+        lag_dig = e.ifft_int32(dig)
+        assert P.same_doubles(lag_dig, load("fft_lag_dig.bin", np.float64)), "execute_reverse_int"
+        lag_a64 = e.ifft_torus64(a64)
+        assert P.same_doubles(lag_a64, load("fft_lag_a64.bin", np.float64)), "execute_reverse_torus64"
+        assert np.array_equal(e.fft_torus64(lag_a64), load("fft_t64.bin", np.int64)), "execute_direct_torus64"
+        assert np.array_equal(e.fft_torus32(lag_dig), load("fft_t32.bin", np.int32)), "execute_direct_torus32"
+    finally:
+        e.close()
 
 
 if __name__ == "__main__":  # python tests/test_ref_batch.py prerun   (timing of the reference side on this host)
