@@ -31,6 +31,10 @@
 #define TFHE_SIMD_ID() ((int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 4) & 3))
 // issue priority of this wave among the waves of its SIMD (0 lowest .. 3), s_setprio
 #define TFHE_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+// signed bit-field extract: bits [off, off + width) of x, sign-extended (v_bfe_i32; off, width may be scalar registers)
+#define TFHE_SBFE(x, off, width) ((int32_t)__builtin_amdgcn_sbfe((int32_t)(x), (uint32_t)(off), (uint32_t)(width)))
+// low 32 bits of ((hi:lo) >> sh), 0 <= sh < 32 (v_alignbit_b32)
+#define TFHE_ALIGNBIT(hi, lo, sh) __builtin_amdgcn_alignbit((hi), (lo), (uint32_t)(sh))
 // no instruction is scheduled across this point
 #define TFHE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // true in every lane iff `cond` holds in at least one active lane of the wave

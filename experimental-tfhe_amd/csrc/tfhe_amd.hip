@@ -505,7 +505,9 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
         uint64_t s = 0;
         for (int i = 0; i <= p->l; i++) s |= 1ull << (63 - i * p->Bgbit);
         c->gd.offset = s;
-        c->gd.flip = 0;
+        uint64_t f = 0;  // Bg/2 at every digit position: bit (Bgbit - 1) of the field at 64 - (i+1) Bgbit
+        for (int i = 0; i < p->l; i++) f |= 1ull << (63 - i * p->Bgbit);
+        c->gd.flip = f;
     }
     *out = c;
     return TFHE_AMD_OK;

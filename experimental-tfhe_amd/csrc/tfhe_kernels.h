@@ -427,7 +427,7 @@ struct Torus<int64_t> {
 // Torus32: no rounding bit; poc:349-350 for Torus64: with rounding bit)
 struct Gadget {
     uint64_t offset;
-    uint64_t flip;  // Torus32 only: Bg/2 at every digit position (see ifft_mac_digits); else 0
+    uint64_t flip;  // Bg/2 at every digit position (see ifft_mac_digits)
     int32_t Bgbit;
     int32_t l;
 };
@@ -533,8 +533,6 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
     using U = typename Torus<T>::U;
     constexpr int PPL = Geom<LOGN>::PPL;
     const int Bgbit = BGC ? BGC : gd.Bgbit;
-    const U mask = ((U)1 << Bgbit) - 1;
-    const int32_t halfBg = 1 << (Bgbit - 1);
     double2 bk[HALFROW ? 1 : 2][PPL];  // key row of the first digit, fetched underneath the transform
     // wave-uniform row pointer + 32-bit lane offset: one address register for the whole row
     const unsigned char *kb = reinterpret_cast<const unsigned char *>(bkrow);
@@ -549,16 +547,44 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
 #pragma unroll
     for (int e = 0; e < ND; e++) {
         const int decal = Torus<T>::BITS - (d0 + e + 1) * Bgbit;
+        // lo/hi arrive with the top bit of every digit field flipped (Gadget::flip), so the field read as a
+        // signed Bgbit-bit number IS (field - Bg/2): one v_bfe_i32 per digit
+        if constexpr (Torus<T>::BITS == 32) {
 #pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            if (Torus<T>::BITS == 32) {
-                // lo/hi arrive with the top bit of every digit field flipped (Gadget::flip), so the
-                // field read as a signed Bgbit-bit number IS (field - Bg/2): one v_bfe_i32 per digit
+            for (int m = 0; m < PPL; m++) {
                 xr[e][m] = (double)(((int32_t)((uint32_t)lo[m] << (32 - decal - Bgbit))) >> (32 - Bgbit));
                 xi[e][m] = (double)(((int32_t)((uint32_t)hi[m] << (32 - decal - Bgbit))) >> (32 - Bgbit));
+            }
+        } else {
+            // the same on 64 bits, from the field's 32-bit word -- or, where it straddles the words, from a 32-bit
+            // window on both.  Which of the three it is depends on the (wave-uniform) digit index only: one
+            // scalar branch around the whole polynomial.
+            auto extract = [&](auto mode) {
+                constexpr int MODE = decltype(mode)::value;
+#pragma unroll
+                for (int m = 0; m < PPL; m++) {
+                    const uint64_t a = (uint64_t)lo[m], b = (uint64_t)hi[m];
+                    if (MODE == 0) {
+                        xr[e][m] = (double)TFHE_SBFE((uint32_t)(a >> 32), decal - 32, Bgbit);
+                        xi[e][m] = (double)TFHE_SBFE((uint32_t)(b >> 32), decal - 32, Bgbit);
+                    } else if (MODE == 1) {
+                        xr[e][m] = (double)TFHE_SBFE(TFHE_ALIGNBIT((uint32_t)(a >> 32), (uint32_t)a, decal), 0, Bgbit);
+                        xi[e][m] = (double)TFHE_SBFE(TFHE_ALIGNBIT((uint32_t)(b >> 32), (uint32_t)b, decal), 0, Bgbit);
+                    } else {
+                        xr[e][m] = (double)TFHE_SBFE((uint32_t)a, decal, Bgbit);
+                        xi[e][m] = (double)TFHE_SBFE((uint32_t)b, decal, Bgbit);
+                    }
+                }
+            };
+            if (decal >= 32) {
+                TFHE_KEEP_BRANCH();
+                extract(std::integral_constant<int, 0>{});
+            } else if (decal + Bgbit > 32) {
+                TFHE_KEEP_BRANCH();
+                extract(std::integral_constant<int, 1>{});
             } else {
-                xr[e][m] = (double)((int32_t)((lo[m] >> decal) & mask) - halfBg);
-                xi[e][m] = (double)((int32_t)((hi[m] >> decal) & mask) - halfBg);
+                TFHE_KEEP_BRANCH();
+                extract(std::integral_constant<int, 2>{});
             }
         }
     }

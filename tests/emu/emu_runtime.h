@@ -46,6 +46,11 @@ using dim3 = emu::Dim3;
 #define TFHE_WAVE_FENCE() emu::wave_fence()
 #define TFHE_UNIFORM(x) (x)
 #define TFHE_SCHED_BARRIER() ((void)0)
+static inline int32_t tfhe_emu_sbfe(uint32_t x, int off, int width) {
+    return (int32_t)((uint32_t)(x >> off) << (32 - width)) >> (32 - width);
+}
+#define TFHE_SBFE(x, off, width) tfhe_emu_sbfe((uint32_t)(x), (int)(off), (int)(width))
+#define TFHE_ALIGNBIT(hi, lo, sh) ((uint32_t)((((uint64_t)(hi) << 32) | (uint32_t)(lo)) >> (sh)))
 #define TFHE_SIMD_ID() ((int)((threadIdx.x >> 6) & 3))
 #define TFHE_SETPRIO(p) ((void)0)
 #define TFHE_WAVE_ANY(cond) emu::wave_any(cond)
