@@ -1728,8 +1728,24 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_ks_mfma(KsMfmaArgs A) {
     // touch them until the chunk they are for: arithmetic here would wait for the loads, and with them for
     // the key loads issued before); finish_words adds the rounding offset and keeps the 32 bits that carry
     // the digits (t * BB <= 32)
+    // A lane reads ITS sample's WPC consecutive words as one or two 16-byte loads (rows are only word-aligned:
+    // the packed type tells the compiler so): per wave-instruction the 32 rows are 32 cache lines whatever the
+    // width, and one dword per instruction made these loads as expensive as the chunk's MFMAs.  The last
+    // chunk may reach past n_in (zero key rows there): it is read word by word, clamped.
+    struct __attribute__((packed, aligned(4))) Words {
+        UX v[WPC];
+    };
     auto load_words = [&](int c, UX (&w)[2][WPC]) {
         const int i0 = c * WPC;
+        if (i0 + WPC <= A.n_in) {
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                const Words tmp = *reinterpret_cast<const Words *>(xrow[rb] + i0);
+#pragma unroll
+                for (int e = 0; e < WPC; e++) w[rb][e] = tmp.v[e];
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < WPC; e++) {
             const int i = i0 + e;
