@@ -35,6 +35,8 @@
 #define TFHE_SBFE(x, off, width) ((int32_t)__builtin_amdgcn_sbfe((int32_t)(x), (uint32_t)(off), (uint32_t)(width)))
 // low 32 bits of ((hi:lo) >> sh), 0 <= sh < 32 (v_alignbit_b32)
 #define TFHE_ALIGNBIT(hi, lo, sh) __builtin_amdgcn_alignbit((hi), (lo), (uint32_t)(sh))
+// next `size` instructions of the classes in `mask` (LLVM sched_group_barrier: 0x2 VALU, 0x8 MFMA, 0x100 DS read, ...)
+#define TFHE_SCHED_GROUP(mask, size) __builtin_amdgcn_sched_group_barrier((mask), (size), 0)
 // no instruction is scheduled across this point
 #define TFHE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // true in every lane iff `cond` holds in at least one active lane of the wave

@@ -1841,6 +1841,16 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_ks_mfma(KsMfmaArgs A) {
                     acc[1][l] = TFHE_MFMA_I8(a[1], bf[e & 1][l], acc[1][l]);
                 }
             }
+            // issue order of the chunk: every MFMA is followed by a few of the next K-step's one-hot VALU
+            // instructions and every other one by a B-fragment read, so the VALU work and the LDS latency run
+            // while the matrix pipe is busy (left alone hipcc issues a K-step's 8 MFMAs back to back and its
+            // 26 VALU instructions after them, with the matrix pipe idle)
+#pragma unroll
+            for (int g = 0; g < CH * 8; g++) {
+                TFHE_SCHED_GROUP(0x008, 1);  // 1 MFMA
+                TFHE_SCHED_GROUP(0x002, 3);  // 3 VALU (2 and 4 measured within 2 %)
+                if ((g & 1) == 0) TFHE_SCHED_GROUP(0x100, 1);  // 1 DS read
+            }
         }
         if (more) {
             store_key((c + 1) & 1, stage);
