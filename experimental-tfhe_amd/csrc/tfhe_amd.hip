@@ -162,6 +162,24 @@ int set_lds(tfhe_amd_ctx *c, KernelT kernel, size_t bytes) {
     return TFHE_AMD_OK;
 }
 
+// grid of a persistent-wave kernel: as many workgroups as the device keeps resident (occupancy of this kernel
+// with its dynamic LDS x number of CUs), never more than the work needs
+template <typename KernelT>
+int persistent_grid(tfhe_amd_ctx *c, KernelT kernel, int block, size_t lds, int needed, int *grid) {
+#ifdef TFHE_EMU
+    *grid = needed < 3 ? needed : 3;  // a small fixed grid: the batch loop of every wave is exercised
+    (void)c; (void)kernel; (void)block; (void)lds;
+#else
+    const void *key = reinterpret_cast<const void *>(kernel);
+    int per_cu = 0, cus = 0;
+    HIPCHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, key, block, lds));
+    HIPCHECK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    const long long resident = (long long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    *grid = (int)(needed < resident ? needed : resident);
+#endif
+    return TFHE_AMD_OK;
+}
+
 // one instantiation per (torus, N): waves per workgroup chosen so LDS fits 160 KiB
 template <typename T, int LOGN, int WAVES, int PAIR, int LC = 0, int BGC = 0>
 int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
@@ -194,7 +212,9 @@ int launch_ifft_w(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
     using Lds = FftLds<LOGN, WAVES>;
     auto kernel = k_ifft_batch<TIN, LOGN, WAVES, PACK>;
     if (int rc = set_lds(c, kernel, Lds::total)) return rc;
-    TFHE_LAUNCH((k_ifft_batch<TIN, LOGN, WAVES, PACK>), dim3((batch + WAVES - 1) / WAVES), dim3(WAVES * 64), Lds::total,
+    int grid = 0;
+    if (int rc = persistent_grid(c, kernel, WAVES * 64, Lds::total, (batch + WAVES - 1) / WAVES, &grid)) return rc;
+    TFHE_LAUNCH((k_ifft_batch<TIN, LOGN, WAVES, PACK>), dim3(grid), dim3(WAVES * 64), Lds::total,
                 c->stream, out_d, in_d, (const double2 *)c->tw_d, batch);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
@@ -211,7 +231,9 @@ int launch_fft_w(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
     using Lds = FftLds<LOGN, WAVES>;
     auto kernel = k_fft_batch<TOUT, LOGN, WAVES>;
     if (int rc = set_lds(c, kernel, Lds::total)) return rc;
-    TFHE_LAUNCH((k_fft_batch<TOUT, LOGN, WAVES>), dim3((batch + WAVES - 1) / WAVES), dim3(WAVES * 64), Lds::total,
+    int grid = 0;
+    if (int rc = persistent_grid(c, kernel, WAVES * 64, Lds::total, (batch + WAVES - 1) / WAVES, &grid)) return rc;
+    TFHE_LAUNCH((k_fft_batch<TOUT, LOGN, WAVES>), dim3(grid), dim3(WAVES * 64), Lds::total,
                 c->stream, out_d, in_d, (const double2 *)c->tw_d, batch);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;

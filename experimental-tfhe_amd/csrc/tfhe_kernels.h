@@ -366,8 +366,12 @@ struct Torus<int32_t> {
     using U = uint32_t;
     static constexpr int BITS = 32;
     static constexpr bool HAS_FAST = true;
-    // int32_t(int64_t(x)), fft_processor_spqlios.cpp:102 (truncate toward zero, wrap)
-    TFHE_DEVICE static int32_t from_double(double x) { return (int32_t)(int64_t)x; }
+    // int32_t(int64_t(x)), fft_processor_spqlios.cpp:102 (truncate toward zero, wrap).  Beyond the int64 range
+    // the C expression is undefined; the reference as compiled for x86 (cvttsd2si: 0x8000000000000000) yields 0,
+    // which is what this returns too (such values do not occur: the external product stays below 2^52)
+    TFHE_DEVICE static int32_t from_double(double x) {
+        return (__builtin_fabs(x) < 0x1p63) ? (int32_t)(int64_t)x : 0;
+    }
     // The same value for |x| < 2^51 in 2 fp64 operations instead of 5: t = trunc(x) is an integer
     // below 2^51, so t + 1.5*2^52 is exact (ulp 1) and carries t mod 2^32 in its low word.
     // `guard` ORs the high words of t; guard_ok() then bounds every exponent seen with one compare
@@ -1181,6 +1185,11 @@ struct FftLds {
 // PACK: write the key layout of the blind-rotation kernel instead ([row][PPL][64] complex, scaled by
 // 2/N -- what k_pack_gsw makes of the reference layout), i.e. tGswToFFTConvert straight into a
 // device-resident key without the intermediate LagrangeHalfC array.
+//
+// PERSISTENT waves: the grid is sized to the chip (launch_ifft_w / launch_fft_w), every wave walks the batch
+// with stride gridDim.x * WAVES.  The twiddle table is staged once per workgroup instead of once per WAVES
+// polynomials (32 KB from L2 + a barrier in front of every 4 transforms at N = 2048), and a wave requests its
+// NEXT polynomial before it transforms the current one, so its HBM latency runs under the butterflies.
 template <typename TIN, int LOGN, int WAVES, bool PACK = false>
 TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     k_ifft_batch(double *__restrict__ out, const TIN *__restrict__ in, const double2 *__restrict__ twg, int batch) {
@@ -1190,52 +1199,58 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     double2 *tw = reinterpret_cast<double2 *>(smem);
     const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
     const int t = threadIdx.x & 63;
-    const int b = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
-    const bool live = b < batch;
-    // the polynomial's loads are issued BEFORE the twiddle table is staged, so that their HBM latency
-    // runs under the staging instead of after the barrier (a ragged last workgroup re-reads the last
-    // polynomial: every wave must reach the barrier)
-    const TIN *p = in + (size_t)(live ? b : batch - 1) * N;
+    const int stride = TFHE_UNIFORM((int)(gridDim.x * WAVES));
+    int b = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
+    // the first polynomial's loads are issued BEFORE the twiddle table is staged: their HBM latency runs
+    // under the staging and its barrier
     TIN raw_r[PPL], raw_i[PPL];
+    auto request = [&](int poly) {
+        const TIN *p = in + (size_t)poly * N;
 #pragma unroll
-    for (int m = 0; m < PPL; m++) {
-        raw_r[m] = p[G::jA(t, m)];
-        raw_i[m] = p[G::jA(t, m) + NC];
-    }
+        for (int m = 0; m < PPL; m++) {
+            raw_r[m] = p[G::jA(t, m)];
+            raw_i[m] = p[G::jA(t, m) + NC];
+        }
+    };
+    if (b < batch) request(b);
     for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = twg[i];
     __syncthreads();
-    if (!live) return;
     const typename WaveFFT<LOGN>::Xch xch = WaveFFT<LOGN>::make_xch(
         reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH, t);
-    double xr[1][PPL], xi[1][PPL];
-#pragma unroll
-    for (int m = 0; m < PPL; m++) {
-        xr[0][m] = (double)raw_r[m];
-        xi[0][m] = (double)raw_i[m];
-    }
     const TwLds<LOGN> twp{tw, t};
-    WaveFFT<LOGN>::template ifft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
-    if (PACK) {
-        double2 *o = reinterpret_cast<double2 *>(out) + (size_t)b * NC;
-        const double scale = 2.0 / (double)N;  // exact: a power of two
+#pragma unroll 1
+    for (; b < batch; b += stride) {
+        double xr[1][PPL], xi[1][PPL];
 #pragma unroll
-        for (int m = 0; m < PPL; m++) o[64 * m + t] = make_double2(xr[0][m] * scale, xi[0][m] * scale);
-        return;
-    }
-    // The reference's order has lane t holding PPL CONSECUTIVE outputs (jC): stored from there, every
-    // store instruction would touch 64 different 128-byte lines.  One more pass through the wave's LDS
-    // buffer turns it into the lane-contiguous order jA, 512 contiguous bytes per store instruction.
-    WaveFFT<LOGN>::template transpose<G::RD_C2, G::RD_A2>(xr[0], xch);
-    WaveFFT<LOGN>::template transpose<G::RD_C2, G::RD_A2>(xi[0], xch);
-    double *o = out + (size_t)b * N;
+        for (int m = 0; m < PPL; m++) {
+            xr[0][m] = (double)raw_r[m];
+            xi[0][m] = (double)raw_i[m];
+        }
+        if (b + stride < batch) request(b + stride);
+        WaveFFT<LOGN>::template ifft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
+        if (PACK) {
+            double2 *o = reinterpret_cast<double2 *>(out) + (size_t)b * NC;
+            const double scale = 2.0 / (double)N;  // exact: a power of two
 #pragma unroll
-    for (int m = 0; m < PPL; m++) {
-        o[G::jA(t, m)] = xr[0][m];
-        o[G::jA(t, m) + NC] = xi[0][m];
+            for (int m = 0; m < PPL; m++) o[64 * m + t] = make_double2(xr[0][m] * scale, xi[0][m] * scale);
+            continue;
+        }
+        // The reference's order has lane t holding PPL CONSECUTIVE outputs (jC): stored from there, every
+        // store instruction would touch 64 different 128-byte lines.  One more pass through the wave's LDS
+        // buffer turns it into the lane-contiguous order jA, 512 contiguous bytes per store instruction.
+        WaveFFT<LOGN>::template transpose<G::RD_C2, G::RD_A2>(xr[0], xch);
+        WaveFFT<LOGN>::template transpose<G::RD_C2, G::RD_A2>(xi[0], xch);
+        double *o = out + (size_t)b * N;
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            o[G::jA(t, m)] = xr[0][m];
+            o[G::jA(t, m) + NC] = xi[0][m];
+        }
     }
 }
 
-// execute_direct_torus32 / _torus64: LagrangeHalfC -> torus coefficients (scale 2/N first)
+// execute_direct_torus32 / _torus64: LagrangeHalfC -> torus coefficients (scale 2/N first); persistent waves
+// with the next polynomial requested ahead, as k_ifft_batch
 template <typename TOUT, int LOGN, int WAVES>
 TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     k_fft_batch(TOUT *__restrict__ out, const double *__restrict__ in, const double2 *__restrict__ twg, int batch) {
@@ -1245,38 +1260,63 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     double2 *tw = reinterpret_cast<double2 *>(smem);
     const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
     const int t = threadIdx.x & 63;
-    const int b = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
-    const bool live = b < batch;
-    // loads first (lane-contiguous order jA: 512 contiguous bytes per instruction), then the twiddle
-    // staging and its barrier run under their latency; see k_ifft_batch
-    const double *p = in + (size_t)(live ? b : batch - 1) * N;
+    const int stride = TFHE_UNIFORM((int)(gridDim.x * WAVES));
+    int b = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
     const double scale = 2.0 / (double)N;  // fft_processor_spqlios.cpp:78
-    double xr[1][PPL], xi[1][PPL];
+    // loads in the lane-contiguous order jA: 512 contiguous bytes per instruction
+    double raw_r[PPL], raw_i[PPL];
+    auto request = [&](int poly) {
+        const double *p = in + (size_t)poly * N;
 #pragma unroll
-    for (int m = 0; m < PPL; m++) {
-        xr[0][m] = p[G::jA(t, m)];
-        xi[0][m] = p[G::jA(t, m) + NC];
-    }
+        for (int m = 0; m < PPL; m++) {
+            raw_r[m] = p[G::jA(t, m)];
+            raw_i[m] = p[G::jA(t, m) + NC];
+        }
+    };
+    if (b < batch) request(b);
     for (int i = threadIdx.x; i < G::TW; i += WAVES * 64) tw[i] = twg[i];
     __syncthreads();
-    if (!live) return;
     const typename WaveFFT<LOGN>::Xch xch = WaveFFT<LOGN>::make_xch(
         reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH, t);
-#pragma unroll
-    for (int m = 0; m < PPL; m++) {
-        xr[0][m] *= scale;
-        xi[0][m] *= scale;
-    }
-    // into the transform's input order (lane t holds the PPL consecutive points jC) through LDS
-    WaveFFT<LOGN>::template transpose<G::RD_A2, G::RD_C2>(xr[0], xch);
-    WaveFFT<LOGN>::template transpose<G::RD_A2, G::RD_C2>(xi[0], xch);
     const TwLds<LOGN> twp{tw, t};
-    WaveFFT<LOGN>::template fft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
-    TOUT *o = out + (size_t)b * N;
+#pragma unroll 1
+    for (; b < batch; b += stride) {
+        double xr[1][PPL], xi[1][PPL];
 #pragma unroll
-    for (int m = 0; m < PPL; m++) {
-        o[G::jA(t, m)] = Torus<TOUT>::from_double(xr[0][m]);
-        o[G::jA(t, m) + NC] = Torus<TOUT>::from_double(xi[0][m]);
+        for (int m = 0; m < PPL; m++) {
+            xr[0][m] = raw_r[m] * scale;
+            xi[0][m] = raw_i[m] * scale;
+        }
+        if (b + stride < batch) request(b + stride);
+        // into the transform's input order (lane t holds the PPL consecutive points jC) through LDS
+        WaveFFT<LOGN>::template transpose<G::RD_A2, G::RD_C2>(xr[0], xch);
+        WaveFFT<LOGN>::template transpose<G::RD_A2, G::RD_C2>(xi[0], xch);
+        WaveFFT<LOGN>::template fft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
+        // rounding: the short exact sequences of the blind-rotation kernels (Torus<T>::from_double_fast), the
+        // reference's own form where the wave's guard trips (|x| >= 2^51 resp. 2^83)
+        TOUT *o = out + (size_t)b * N;
+        TOUT r0[PPL], r1[PPL];
+        uint32_t guard = 0;
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            r0[m] = Torus<TOUT>::from_double_fast(xr[0][m], guard);
+            r1[m] = Torus<TOUT>::from_double_fast(xi[0][m], guard);
+        }
+        if (TFHE_WAVE_ANY(!Torus<TOUT>::guard_ok(guard))) {
+            TFHE_KEEP_BRANCH();
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                TFHE_OPAQUE(xr[0][m]);
+                TFHE_OPAQUE(xi[0][m]);
+                r0[m] = Torus<TOUT>::from_double(xr[0][m]);
+                r1[m] = Torus<TOUT>::from_double(xi[0][m]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < PPL; m++) {
+            o[G::jA(t, m)] = r0[m];
+            o[G::jA(t, m) + NC] = r1[m];
+        }
     }
 }
 

@@ -79,6 +79,9 @@ def check_fft_plugin(lib_path, N, count=4, seed=11):
         # around 2^64 (wrap) and far above (left shifts of 64 or more: defined as 0)
         for sc in (2.0 ** -70, 2.0 ** -52, 2.0 ** 12, 2.0 ** 30, 2.0 ** 70):
             assert np.array_equal(e.fft_torus64(lag64 * sc), O.execute_direct_torus64(N, lag64 * sc)), f"direct_torus64 x {sc}"
+        # execute_direct_torus32 around and beyond the 2^51 bound of the short rounding sequence (per-wave fallback)
+        for sc in (2.0 ** -40, 2.0 ** 8, 2.0 ** 11, 2.0 ** 14, 2.0 ** 40):
+            assert np.array_equal(e.fft_torus32(lag32 * sc), O.execute_direct_torus32(N, lag32 * sc)), f"direct_torus32 x {sc}"
         assert np.array_equal(e.fft_torus32(np.zeros((1, N))), np.zeros((1, N), np.int32))
         assert np.array_equal(e.fft_torus64(np.zeros((1, N))), np.zeros((1, N), np.int64))
         got = e.lagrange_addmul(lag32, O.execute_reverse_int(N, dig), O.execute_reverse_int(N, a32))

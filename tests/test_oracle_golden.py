@@ -107,6 +107,9 @@ def test_live_reference_fresh_inputs(N):
     assert np.array_equal(bits(acc), bits(O.ref("addmul", np.concatenate([np.zeros((cnt, N)), ld, la], axis=1),
                                                  np.float64, N).reshape(cnt, N)))
     assert np.array_equal(O.execute_direct_torus32(N, acc), O.ref("dir_t32", acc, np.int32, N).reshape(cnt, N))
+    # beyond the int64 range int32_t(int64_t(x)) is undefined in C; the compiled reference yields 0 there
+    big = acc * 2.0 ** 40
+    assert np.array_equal(O.execute_direct_torus32(N, big), O.ref("dir_t32", big, np.int32, N).reshape(cnt, N))
     acc64 = O.lagrange_addmul(N, np.zeros((cnt, N)), ld, l64)
     assert np.array_equal(O.execute_direct_torus64(N, acc64), O.ref("dir_t64", acc64, np.int64, N).reshape(cnt, N))
 
