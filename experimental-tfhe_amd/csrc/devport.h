@@ -97,6 +97,10 @@ __device__ __forceinline__ void tfhe_lds_poke32(uint32_t off, uint32_t v) {
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
     *(lds_vu32 *)(uintptr_t)off = v;
 }
+__device__ __forceinline__ double tfhe_uniform_load_f64(const double *p, int idx) {
+    typedef __attribute__((address_space(4))) const double const_f64;
+    return ((const_f64 *)(uintptr_t)p)[idx];
+}
 #define TFHE_TRAP() __builtin_trap()
 // D = A(32x32 int8) * B(32x32 int8) + C(32x32 int32) on the matrix cores, one wave.  Lane l holds
 // A[row l & 31][k = 16 * (l >> 5) + 0..15] and B[k = 16 * (l >> 5) + 0..15][col l & 31] as 16 bytes each;

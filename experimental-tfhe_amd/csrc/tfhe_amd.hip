@@ -219,7 +219,7 @@ int launch_ifft_w(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
-// 4 waves (= polynomials) per workgroup: measured against 8 and 12 on MI355X (profiles/r02_config4_fft.jsonl),
+// 4 waves (= polynomials) per workgroup: measured against 8 and 12 on MI355X in the non-persistent form (profiles/r02_config4_fft.jsonl),
 // 4 is fastest at N=2048 (0.55-0.64 of 8 TB/s vs 0.40-0.56) and within 4 % of the best at N=1024
 constexpr int FFT_WAVES = 4;
 template <typename TIN, int LOGN, bool PACK = false>

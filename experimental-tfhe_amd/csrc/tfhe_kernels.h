@@ -110,7 +110,17 @@ struct TwLds {
     TFHE_DEVICE double2 passB(int s, int m) const {
         return TFHE_TW_SRC[G::tw_base(s << G::CB) + ((m & (s - 1)) << G::CB) + (t & ((1 << G::CB) - 1))];
     }
-    TFHE_DEVICE double2 passC(int m) const { return TFHE_TW_SRC[G::tw_base(4) + (m & 3)]; }
+    // the four twiddles of the stride-4 stage (N = 1024) are the same in every lane: held in scalar registers,
+    // fetched once per kernel from the global table (uniform address -> s_load); 24 LDS reads less per CMux, +1 %
+    double2 c4[4];
+    TFHE_DEVICE void load_uniform(const double2 *global_table) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            c4[m].x = tfhe_uniform_load_f64(reinterpret_cast<const double *>(global_table + G::tw_base(4) + m), 0);
+            c4[m].y = tfhe_uniform_load_f64(reinterpret_cast<const double *>(global_table + G::tw_base(4) + m), 1);
+        }
+    }
+    TFHE_DEVICE double2 passC(int m) const { return c4[m & 3]; }
 #undef TFHE_TW_SRC
 };
 template <int LOGN>
@@ -1023,6 +1033,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
     w.xch = WaveFFT<LOGN>::make_xch(reinterpret_cast<double *>(smem + Lds::xch_at(wave)), t);
     w.tw.tw = reinterpret_cast<const double2 *>(smem + Lds::tw_at);
     w.tw.t = t;
+    w.tw.load_uniform(A.tw);
     w.progress_lds = sync_lds;
     w.self = wave;
     w.partner = TFHE_UNIFORM(partner);
@@ -1217,7 +1228,10 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     __syncthreads();
     const typename WaveFFT<LOGN>::Xch xch = WaveFFT<LOGN>::make_xch(
         reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH, t);
-    const TwLds<LOGN> twp{tw, t};
+    TwLds<LOGN> twp;
+    twp.tw = tw;
+    twp.t = t;
+    twp.load_uniform(twg);
 #pragma unroll 1
     for (; b < batch; b += stride) {
         double xr[1][PPL], xi[1][PPL];
@@ -1278,7 +1292,10 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     __syncthreads();
     const typename WaveFFT<LOGN>::Xch xch = WaveFFT<LOGN>::make_xch(
         reinterpret_cast<double *>(smem + FftLds<LOGN, WAVES>::tw_bytes) + (size_t)wave * G::XCH, t);
-    const TwLds<LOGN> twp{tw, t};
+    TwLds<LOGN> twp;
+    twp.tw = tw;
+    twp.t = t;
+    twp.load_uniform(twg);
 #pragma unroll 1
     for (; b < batch; b += stride) {
         double xr[1][PPL], xi[1][PPL];
