@@ -8,7 +8,12 @@
 //     a wave's DS instructions execute in order),
 //   * the Fourier-domain accumulator of the external product never leaves registers,
 //   * bootstrapping-key rows are read straight from HBM/L2 with one coalesced 16-byte
-//     load per lane per complex value, in a layout fixed at key-upload time.
+//     load per lane per complex value, in a layout fixed at key-upload time,
+//   * the two waves that share a SIMD keep each other's pace through progress counters in LDS
+//     and s_setprio (WaveLds::balance): the hardware otherwise favours the older wave and the
+//     younger one finishes alone.
+// (The Torus64 / N = 2048 instantiation of the circuit bootstrap keeps the accumulator in
+// registers instead and runs one wave per SIMD: BlindRotateLds::ACCREG.)
 //
 // Arithmetic follows the reference's FMA assembly operation by operation (SURVEY.md
 // App. A; CB/spqlios/spqlios-{i,}fft-fma.s, lagrangehalfc_impl_fma.s), so Torus32 /
