@@ -47,6 +47,8 @@
 // makes a register value opaque at this point: arithmetic on it cannot be hoisted above (used to
 // keep a rarely taken fallback from being computed speculatively on the hot path)
 #define TFHE_OPAQUE(x) asm volatile("" : "+v"(x))
+// the same for a wave-uniform value held in scalar registers
+#define TFHE_OPAQUE_SCALAR(x) asm volatile("" : "+s"(x))
 // *p += v on an LDS word owned by this lane, as ONE DS instruction with no result (ds_add_u32 /
 // ds_add_u64): no read, no VALU add, no wait.  Ordered with the wave's other DS operations.
 #define TFHE_LDS_ADD(p, v) ((void)__hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
@@ -100,6 +102,15 @@ __device__ __forceinline__ void tfhe_lds_poke32(uint32_t off, uint32_t v) {
 __device__ __forceinline__ double tfhe_uniform_load_f64(const double *p, int idx) {
     typedef __attribute__((address_space(4))) const double const_f64;
     return ((const_f64 *)(uintptr_t)p)[idx];
+}
+// Buffer addressing for rows of read-only data: descriptor (base, no stride, no bounds in practice) in scalar
+// registers; a load = descriptor + 32-bit lane offset + scalar offset (4 KB window) + 12-bit immediate.
+typedef __amdgpu_buffer_rsrc_t TFHE_BUFFER_RSRC;
+#define TFHE_MAKE_BUFFER_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc((void *)(ptr), 0, 0x7fffffff, 0x00020000)
+__device__ __forceinline__ double2 tfhe_buffer_load_d2(TFHE_BUFFER_RSRC rsrc, uint32_t lane_off, uint32_t off) {
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_off + (off & 4095u)), (int)(off & ~4095u), 0);
+    return __builtin_bit_cast(double2, v);
 }
 #define TFHE_TRAP() __builtin_trap()
 // D = A(32x32 int8) * B(32x32 int8) + C(32x32 int32) on the matrix cores, one wave.  Lane l holds

@@ -57,6 +57,7 @@ static inline int32_t tfhe_emu_sbfe(uint32_t x, int off, int width) {
 #define TFHE_WAVE_ANY(cond) emu::wave_any(cond)
 #define TFHE_KEEP_BRANCH() ((void)0)
 #define TFHE_OPAQUE(x) ((void)0)
+#define TFHE_OPAQUE_SCALAR(x) ((void)0)
 #define TFHE_READLANE(v, lane) emu::readlane((v), (lane))
 #define TFHE_LDS_ADD(p, v) ((void)(*(p) += (v)))
 static inline uint32_t tfhe_and_or(uint32_t x, uint32_t m, uint32_t o) { return (x & m) | o; }
@@ -93,6 +94,11 @@ struct double2 {
     double x, y;
 };
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+typedef const unsigned char *TFHE_BUFFER_RSRC;
+#define TFHE_MAKE_BUFFER_RSRC(ptr) ((const unsigned char *)(ptr))
+static inline double2 tfhe_buffer_load_d2(TFHE_BUFFER_RSRC rsrc, uint32_t lane_off, uint32_t off) {
+    return *(const double2 *)(rsrc + lane_off + off);
+}
 
 // ---- host runtime subset -------------------------------------------------------------
 typedef int hipError_t;
