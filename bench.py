@@ -120,6 +120,10 @@ def main():
                     help="also time BASELINE config 2's literal schedule (one launch per CMux) after the timed region; "
                          "off by default so a rocprofv3 --stats run of the default command sees k_blind_rotate only "
                          "in its persistent form")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="also time (after the timed region, one GPU) the same K steps issued alternately on two contexts / "
+                         "streams: consecutive batches are independent, the next blind rotation fills the CUs the current "
+                         "one's tail and key switch leave idle; reported as pipelined_two_contexts, never as `value`")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -266,6 +270,34 @@ def main():
             streamed["hipgraph"] = {"error": str(e)}
         eng.set_option(T.OPT_STREAMED_GRAPH, 0)
 
+    pipelined = None
+    if world == 1 and a.pipelined:
+        job2 = shard.GateJob(cfg, SEED, device=local, lib_path=a.lib)  # second context: its own stream and key replicas
+        e2 = job2.eng
+        e2.set_option(T.OPT_KS_GATHER, int(a.ks_gather))
+        x2_d, u2_d, o2_d = e2.to_device(x_host), e2.alloc(B * (cfg.N + 1) * 4), e2.alloc(B * (cfg.n + 1) * 4)
+        lanes = [(eng, x_d, u_d, out_d), (e2, x2_d, u2_d, o2_d)]
+
+        def pstep(k):
+            e, xd, ud, od = lanes[k & 1]
+            e._chk(e.lib.tfhe_amd_bootstrap_woks(e.ctx, ud.ptr, mu, xd.ptr, B))
+            e._chk(e.lib.tfhe_amd_keyswitch(e.ctx, od.ptr, ud.ptr, B))
+
+        for k in range(2 * max(1, a.warmup)):
+            pstep(k)
+        eng.sync()
+        e2.sync()
+        tp = time.perf_counter()
+        for k in range(a.steps):
+            pstep(k)
+        eng.sync()
+        e2.sync()
+        p_elapsed = time.perf_counter() - tp
+        same2 = bool(np.array_equal(o2_d.download(np.int32, (B, cfg.n + 1)), out_all))
+        pipelined = {"value": B * a.steps / p_elapsed, "unit": "bootstraps/s", "ms_per_step": 1e3 * p_elapsed / a.steps,
+                     "contexts": 2, "identical_to_single_context": same2}
+        job2.close()
+
     if rank == 0:
         # HBM bytes per launch of the dominant kernel as measured by the PMC passes of an earlier profile of
         # this same command (tools/make_traffic.py -> profiles/traffic.json); null until such a profile exists
@@ -323,6 +355,8 @@ def main():
         }
         if streamed is not None:
             line["streamed_schedule"] = streamed
+        if pipelined is not None:
+            line["pipelined_two_contexts"] = pipelined
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
