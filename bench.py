@@ -6,19 +6,26 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of tfhe_bootstrap_FFT (blind rotation + extraction + key switch) over a
-batch of 4096 synthetic LWE samples ALREADY RESIDENT IN HBM (BASELINE config 2: n=630,
-N=1024, k=1, l=2; Bgbit=10, key switch 8x2 bits).  N > 1: every rank runs the same per-GPU
-batch on its own GPU with replicated keys (weak scaling, no data-path collective);
+batch of synthetic LWE samples ALREADY RESIDENT IN HBM (n=630, N=1024, k=1, l=2; Bgbit=10, key
+switch 8x2 bits).  Workload by flags:
+  --gpus 1            BASELINE config 2: 4096 samples per step
+  --gpus N (N > 1)    BASELINE config 5: 2^20 samples per step cut into N contiguous slices, one
+                      launch per rank and step, replicated keys, no data-path collective ("strong")
+  --batch B           B samples per GPU per step ("weak");  --total M: M per step over all GPUs
+  --dist              the multi-GPU code path (torch first, process group, barrier, max over ranks)
+                      with whatever world size the environment gives -- also 1
 value = all ranks' bootstraps / max-over-ranks time.
 
 The JSON line also carries
-  roofline      dominant kernel (k_blind_rotate): algorithmic bytes of the streamed external
-                product (16,388 B per CMux per sample + 65,536 B key row per CMux per
-                launch) / HIP-event kernel time, against 8 TB/s HBM; plus the fp64-VALU view
-                (173,056 flop per CMux vs 78.6 TF), since that kernel sits at the ridge point
+  roofline      dominant kernel (k_blind_rotate).  bound = "fp64_issue": wave64 fp64 instructions
+                per second (2,144 per CMux per sample, the floor of the bit-exact DAG) / HIP-event
+                kernel time, against 1024 SIMDs x 2.4 GHz / 4 cycles.  `hbm_contract` keeps the
+                north-star byte accounting (16,388 B per CMux per sample + 65,536 B key
+                row per CMux per launch, against 8 TB/s), `traffic` the PMC-measured HBM bytes
+                (the persistent kernel moves ~2 % of the contract bytes), `fp64_valu` the flop view
   cpu_baseline  the same bootstrap composed from the REFERENCE's own FFT/MAC object code
-                (oracle/_ref/ref_driver bench32), one process per host core, bounded to ~10 s;
-                falls back to the C oracle ("port") where the reference binary is absent.
+                (oracle/_ref/ref_driver bench32), one process per host core, bounded to ~10 s,
+                on rank 0; falls back to the C oracle ("port") where the reference binary is absent.
 Only that cpu_baseline leg touches oracle/.
 
 Process hygiene on the GPU pool: every child process (library build, CPU baseline) is spawned
@@ -110,6 +117,13 @@ def main():
     ap.add_argument("--total", type=int, default=None,
                     help="bootstraps per step over ALL GPUs, sharded contiguously (strong scaling); default with "
                          "--gpus > 1: 2^20 (BASELINE config 5)")
+    ap.add_argument("--dist", action="store_true",
+                    help="take the multi-GPU code path (torch imported before the engine, torch.distributed process group, "
+                         "barrier + max-over-ranks on a device tensor) even with one rank: the path the driver's "
+                         "N = 2/4/8 runs take, runnable on a 1-GPU box")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the multi-rank path (nccl == RCCL on ROCm; gloo: CPU tests on the "
+                         "emulator build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--ks-gather", action="store_true", help="per-sample gather key switch instead of the matrix-core one")
@@ -130,6 +144,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    use_dist = world > 1 or a.dist
     T = importlib.import_module("experimental-tfhe_amd")  # pure python so far: nothing dlopen'ed yet
     shard = importlib.import_module("experimental-tfhe_amd.shard")
     cfg = shard.GateConfig()
@@ -141,16 +156,24 @@ def main():
     # contiguously over the ranks, strong scaling) unless --batch asks for a fixed per-GPU batch
     if a.batch is not None:
         B, scaling, total_per_step = a.batch, "weak", a.batch * world
+        baseline_config = "config 2 shape (fixed batch per GPU)" if a.batch == BATCH_PER_GPU else "custom batch per GPU"
     elif a.total is not None or world > 1:
         total_per_step = a.total if a.total is not None else TOTAL_MULTI_GPU
         lo, hi = shard.shard_range(total_per_step, rank, world)
         B, scaling = hi - lo, "strong"
+        baseline_config = ("BASELINE config 5 (2^20 gate bootstraps per step sharded over the GPUs)"
+                           if total_per_step == TOTAL_MULTI_GPU else "custom total per step, sharded")
     else:
+        # one GPU, no flags: the config the metric is quoted on.  With a single GPU "weak" and "strong" coincide;
+        # the label says which rule --gpus N > 1 WITHOUT flags does not share with it (that is config 5, strong)
         B, scaling, total_per_step = BATCH_PER_GPU, "weak", BATCH_PER_GPU
+        baseline_config = "BASELINE config 2 (batch 4096 gate bootstraps, one GPU)"
     x_host = shard.synthetic_samples(cfg, B, seed=1234 + rank)
     nchk = min(16, B)
     oracle_idx, oracle_want = list(range(nchk, min(nchk + 8, B))), None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and not a.no_cpu_baseline:
+        # rank 0 only, and BEFORE torch / the engine are loaded (children are spawned here); the other ranks
+        # meanwhile wait in init_process_group
         cpu_line = cpu_baseline(cfg, a.cpu_seconds)
         # the checker's answers for a few of the timed inputs, computed NOW (before the GPU is touched);
         # compared bit for bit with the GPU's outputs after the timed region
@@ -165,14 +188,18 @@ def main():
             del obk, oks
 
     dist = None
-    if world > 1:
+    if use_dist:
         import torch  # BEFORE the engine library: one HIP runtime in the process
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
-        dev = torch.device("cuda", local)
+        if a.backend == "nccl":
+            torch.cuda.set_device(local)
+            dev = torch.device("cuda", local)
+        else:
+            dev = torch.device("cpu")
+        dist.init_process_group(a.backend, rank=rank, world_size=world)  # nccl == RCCL on ROCm
 
     try:
         job = shard.GateJob(cfg, SEED, device=local, lib_path=a.lib)  # identical key replicas on every rank
@@ -209,8 +236,9 @@ def main():
         eng.sync()
         if dist is not None:
             dist.barrier()
-            import torch
-            torch.cuda.synchronize()
+            if a.backend == "nccl":
+                import torch
+                torch.cuda.synchronize()
             eng.sync()
 
     for _ in range(a.warmup):
@@ -317,6 +345,8 @@ def main():
         algo_bytes = B * cfg.n * BYTES_PER_CMUX + cfg.n * BYTES_PER_ROW
         achieved = algo_bytes / (br_ms * 1e-3)
         flops = B * cfg.n * FLOP_PER_CMUX / (br_ms * 1e-3)
+        fp64_instr_rate = B * cfg.n * FP64_INSTR_PER_CMUX / (br_ms * 1e-3)   # wave64 fp64 instructions per second, whole chip
+        fp64_instr_peak = SIMDS * CLOCK_HZ / FP64_ISSUE_CYCLES
         line = {
             "metric": "gate bootstraps/sec (N=1024, 128-bit params)",
             "value": total / elapsed,
@@ -330,23 +360,39 @@ def main():
             "vs_baseline": None,
             "dtype": "f64 (anticyclic FFT) over int32 torus",
             "data": "synthetic",
-            "config": {"workload": f"{total_per_step} gate bootstraps per step ({B} on rank 0), {cfg.describe()}, persistent "
-                                   "blind-rotation kernel + key-switch kernel, inputs resident in HBM",
+            "config": {"workload": f"{baseline_config}: {total_per_step} gate bootstraps per step ({B} on rank 0), "
+                                   f"{cfg.describe()}, persistent blind-rotation kernel + key-switch kernel, inputs resident in HBM",
+                       "baseline_config": baseline_config,
                        "batch_per_gpu": B, "total_per_step": total_per_step,
                        "parallelism": f"batch-sharded x{world} (contiguous slices), keys replicated, no data-path collective",
+                       "scaling_note": "--gpus 1 without flags is config 2 (4096 per step); --gpus N > 1 without flags is config 5 "
+                                       "(2^20 per step cut into N slices, strong); a strict strong-scaling series takes its "
+                                       "N = 1 point from `--gpus 1 --total 1048576` (per-GPU throughput at 4096 and at 2^20 per "
+                                       "launch agree within 1 %: profiles/r03_config5_one_gpu.json)",
+                       "process_group": (f"torch.distributed {a.backend}, world {world}" if dist is not None else "none (single process)"),
                        "ks_kernel": "gather" if a.ks_gather else "matrix-core (k_ks_mfma)",
                        "library": os.path.basename(a.lib) if a.lib else "libtfhe_amd.so"},
-            "roofline": {"bound": "hbm", "kernel": "k_blind_rotate<int32,N=1024>", "achieved": achieved / 1e9,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_ms": br_ms, "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "north-star accounting: bytes of the one-launch-per-CMux schedule; the persistent "
-                                 "kernel keeps the accumulator in LDS and is bound by fp64 issue (fp64_issue below)",
+            # The dominant kernel is bound by fp64 ISSUE (one wave64 fp64 instruction per 4 cycles per SIMD), not by HBM:
+            # the persistent kernel keeps the accumulators in LDS, so the bytes of the one-launch-per-CMux schedule
+            #  never move -- `hbm_contract` keeps that accounting, `traffic` is what the PMC counters saw.
+            "roofline": {"bound": "fp64_issue", "kernel": "k_blind_rotate<int32,N=1024>",
+                         "achieved": fp64_instr_rate / 1e9, "peak": fp64_instr_peak / 1e9,
+                         "unit": "G fp64 wave-instr/s", "frac": fp64_instr_rate / fp64_instr_peak,
+                         "fp64_wave_instr_per_cmux": FP64_INSTR_PER_CMUX,
+                         "cmux_per_s": B * cfg.n / (br_ms * 1e-3),
+                         "floor_cmux_per_s": fp64_instr_peak / FP64_INSTR_PER_CMUX,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_hbm_contract_bytes": None if traffic is None else traffic / algo_bytes,
+                         "kernel_ms": br_ms,
+                         "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64 instruction; 2,144 such instructions per "
+                                 "CMux per sample is the floor of the reference's radix-2 DAG reproduced bit for bit (DESIGN.md 2)",
+                         "hbm_contract": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                          "frac": achieved / HBM_PEAK, "algorithmic_bytes_per_launch": algo_bytes,
+                                          "note": "north-star accounting (SURVEY 8d): 16,388 B per CMux per sample + 65,536 B key "
+                                                  "row per CMux per launch, as if every CMux were its own launch; the persistent "
+                                                  "kernel does not move these bytes (see traffic)"},
                          "fp64_valu": {"achieved_tflops": flops / 1e12, "peak_tflops": FP64_PEAK / 1e12,
-                                       "frac": flops / FP64_PEAK},
-                         "fp64_issue": {"cmux_per_s": B * cfg.n / (br_ms * 1e-3),
-                                        "floor_cmux_per_s": SIMDS * CLOCK_HZ / (FP64_INSTR_PER_CMUX * FP64_ISSUE_CYCLES),
-                                        "frac": (B * cfg.n / (br_ms * 1e-3)) /
-                                                (SIMDS * CLOCK_HZ / (FP64_INSTR_PER_CMUX * FP64_ISSUE_CYCLES))}},
+                                       "frac": flops / FP64_PEAK}},
             "kernels_ms": {"blind_rotate_extract": br_ms, "keyswitch": ks_ms},
             "decrypt_check": bool(ok),
             "oracle_bit_check": None if oracle_want is None else {"samples": len(oracle_idx), "identical": oracle_ok},

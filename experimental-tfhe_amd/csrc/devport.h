@@ -39,6 +39,14 @@
 #define TFHE_SCHED_GROUP(mask, size) __builtin_amdgcn_sched_group_barrier((mask), (size), 0)
 // no instruction is scheduled across this point
 #define TFHE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// nothing moves across this point: neither the IR optimiser's memory operations (empty asm with a memory clobber)
+// nor the machine scheduler's instructions.  Used where the ORDER of independent loads decides the register
+// pressure (hipcc otherwise hoists every load of a phase to its top).
+#define TFHE_ORDER()                                 \
+    do {                                             \
+        asm volatile("" ::: "memory");               \
+        __builtin_amdgcn_sched_barrier(0);           \
+    } while (0)
 // true in every lane iff `cond` holds in at least one active lane of the wave
 #define TFHE_WAVE_ANY(cond) (__builtin_amdgcn_ballot_w64(cond) != 0ull)
 // placed at the top of a wave-uniform `if` body: keeps it a real scalar branch (hipcc otherwise

@@ -43,6 +43,7 @@ struct tfhe_amd_ctx {
     size_t ws_acc_bytes;
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
+    int br_split_max;      // TFHE_AMD_OPT_BR_SPLIT: largest batch served by k_blind_rotate_split (< 0: BR_SPLIT_AUTO_MAX, 0: never)
     int ks_force_gather;   // TFHE_AMD_OPT_KS_GATHER: != 0 per-sample gather kernel even where the matrix-core kernel applies
     // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
     // hipGraph and replayed while the call's arguments stay the same
@@ -59,6 +60,11 @@ struct tfhe_amd_ctx {
 };
 
 namespace {
+
+// Batches up to this size run the blind rotation on k_blind_rotate_split (one ciphertext per workgroup, one
+// workgroup per CU: 256 ciphertexts per round of ~2 ms); above it one wave per ciphertext (k_blind_rotate) has the
+// higher throughput.  Measured crossover: profiles/r03_latency.jsonl.
+constexpr int BR_SPLIT_AUTO_MAX = 512;
 
 int fail(tfhe_amd_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
@@ -191,7 +197,28 @@ int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
+// latency-shaped kernel (one ciphertext per 4-wave workgroup, tfhe_kernels.h k_blind_rotate_split): gate gadget
+// length, N = 1024, plain blind rotations only
+template <int BGC>
+int launch_br_split(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
+    auto kernel = k_blind_rotate_split<BGC>;
+    if (int rc = set_lds(c, kernel, SplitLds::total)) return rc;
+    TFHE_LAUNCH((k_blind_rotate_split<BGC>), dim3(a.batch), dim3(256), SplitLds::total, c->stream, a);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+bool br_split_applies(const tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
+    if (c->logn != 10 || c->p.l != 2 || a.n_steps < 1) return false;
+    if ((a.flags & (BR_NO_ROTATE | BR_CMUX_DATA)) || a.gsw_sel || a.sel_div > 0) return false;
+    const int limit = c->br_split_max < 0 ? BR_SPLIT_AUTO_MAX : c->br_split_max;
+    return a.batch <= limit;
+}
 int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
+    if (br_split_applies(c, a)) {
+        if (c->p.Bgbit == 10) return launch_br_split<10>(c, a);
+        if (c->p.Bgbit == 8) return launch_br_split<8>(c, a);
+        return launch_br_split<0>(c, a);
+    }
     // N=1024/Torus32: 2 waves per SIMD (256 VGPRs), digits in pairs.  PPL=16 shapes transform
     // one digit at a time (a pair would need 128 more registers than the file has).
     if (c->logn == 11) return launch_br_t<int32_t, 11, 4, 1>(c, a);
@@ -485,7 +512,8 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->bk = nullptr;
     c->ks_d = nullptr;
     c->ksm_d = nullptr;
-    c->ks_force_gather = getenv("TFHE_AMD_KS_GATHER") ? atoi(getenv("TFHE_AMD_KS_GATHER")) : 0;
+    c->ks_force_gather = 0;
+    c->br_split_max = -1;
     c->streamed_graph = false;
     c->streamed_warm = 0;
     memset(&c->sg, 0, sizeof(c->sg));
@@ -579,10 +607,14 @@ int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
     if (!c) return TFHE_AMD_ERR_PARAM;
     switch (option) {
         case TFHE_AMD_OPT_KS_GATHER:
-            c->ks_force_gather = value;
+            c->ks_force_gather = value != 0;  // normalised: it also indexes the warm-up bits of the streamed schedule
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_STREAMED_GRAPH:
             c->streamed_graph = value != 0;
+            return TFHE_AMD_OK;
+        case TFHE_AMD_OPT_BR_SPLIT:
+            c->br_split_max = value;
+            drop_streamed_graph(c);  // a captured schedule holds the kernel choice
             return TFHE_AMD_OK;
         default:
             return fail(c, TFHE_AMD_ERR_PARAM, "unknown option");
@@ -1036,7 +1068,7 @@ int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, con
         // and let the first call of each schedule variant run as plain launches
         if (int rc = grow(c, &c->ws_lwe, &c->ws_lwe_bytes, (size_t)batch * (c->p.N + 1) * 4)) return rc;
         if (int rc = grow(c, &c->ws_acc, &c->ws_acc_bytes, (size_t)batch * 2 * c->p.N * 4)) return rc;
-        const unsigned vbit = 1u << c->ks_force_gather;
+        const unsigned vbit = c->ks_force_gather ? 2u : 1u;
         if (!(c->streamed_warm & vbit)) {
             c->streamed_warm |= vbit;
             return streamed_plain(c, out_d, mu, x_d, batch);

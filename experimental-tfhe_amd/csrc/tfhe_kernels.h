@@ -1187,6 +1187,263 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
 #endif
 }
 
+// ------------------------------------------- latency-shaped blind rotation (small batches)
+// The reference bootstraps ONE sample per call (lwe_functions.cpp:434-446).  With one wave per ciphertext
+// (k_blind_rotate) a lone bootstrap is a single wave walking 630 CMux steps of ~2,560 vector instructions
+// each; this kernel gives the ciphertext a whole 4-wave workgroup -- one wave on each SIMD of a CU --
+// and splits every CMux over them (gate gadget: l = 2, so the external product has 2l = 4 rows):
+//   phase 1, all four waves:  wave p = (q, d) forms the rotated polynomial q of (X^a - 1) * acc, extracts
+//            gadget digit d and transforms it (one inverse FFT per SIMD); the Lagrange-domain digit goes to
+//            the workgroup's hand-over buffer in LDS (lane-contiguous 16-byte points, conflict-free);
+//   phase 2, waves 0 and 1:   wave q' owns OUTPUT polynomial q' -- it multiply-accumulates the four digits
+//            with its half of the key row in the reference's row order p = 0..3 (the fma chain of
+//            lagrangehalfc_impl_fma.s:96-107 is sequential in p, so one wave must own one output polynomial),
+//            runs the forward transform, rounds and adds into the accumulator in LDS.
+// Two workgroup barriers per CMux (digits complete / accumulator updated).  The key half-rows of step i+1 are
+// requested right after the MAC of step i (128 registers per wave, in flight for a whole step), so a lone
+// ciphertext never waits for L2 / HBM.  Arithmetic per element is exactly that of k_blind_rotate (same
+// helper functions, same operation order): outputs are bit-identical; tests run both kernels on the same inputs.
+struct SplitLds {
+    using G = Geom<10>;
+    static constexpr int WAVES = 4;
+    static constexpr size_t acc_bytes = sizeof(int32_t) * 2 * G::N;   // at offset 0: rotated_minus_one's AND-OR addressing
+    static constexpr size_t tw_at = acc_bytes;
+    static constexpr size_t tw_bytes = sizeof(double2) * G::TW;
+    static constexpr size_t xch_bytes = sizeof(double2) * G::XCH;      // complex-point transposes
+    static constexpr size_t xch_at(int wave) { return tw_at + tw_bytes + (size_t)wave * xch_bytes; }
+    static constexpr size_t hand_at = tw_at + tw_bytes + WAVES * xch_bytes;
+    static constexpr size_t hand_bytes = sizeof(double2) * WAVES * G::NC;  // four Lagrange-domain digits
+    static constexpr size_t total = hand_at + hand_bytes;              // 94,208 B: one workgroup per CU
+};
+
+// BGC: Bgbit when known at compile time (0: read A.gd.Bgbit).  Gadget length 2, Torus32, N = 1024.
+// Flags honoured: BR_INIT_TESTVEC (+ BR_MODSWITCH, BR_TV_CONST, BR_TV_HALF), BR_EXTRACT; without them the
+// accumulator is loaded from / stored to acc_io.  (BR_NO_ROTATE / BR_CMUX_DATA / per-sample keys stay on
+// k_blind_rotate: the host never routes them here.)
+template <int BGC>
+TFHE_GLOBAL void __launch_bounds__(256, 2) k_blind_rotate_split(BlindRotateArgs<int32_t> A) {
+    using T = int32_t;
+    using U = uint32_t;
+    using G = Geom<10>;
+    using L = SplitLds;
+    constexpr int N = G::N, NC = G::NC, PPL = G::PPL;
+    TFHE_DYN_LDS(smem);
+    const int tid = (int)threadIdx.x;
+    const int wave = TFHE_UNIFORM(tid >> 6);
+    const int t = tid & 63;
+    const int ct = (int)blockIdx.x;
+    if (ct >= A.batch) return;  // whole workgroup
+    T *acc = reinterpret_cast<T *>(smem);
+    {
+        double2 *tw = reinterpret_cast<double2 *>(smem + L::tw_at);
+        for (int i = tid; i < G::TW; i += 256) tw[i] = A.tw[i];
+    }
+    const int32_t *rot = A.rot + (size_t)ct * A.rot_stride;
+    // ---- accumulator initialisation, 8 coefficients per thread (flat index e over [2][N])
+    if (A.flags & BR_INIT_TESTVEC) {
+        int barb = rot[A.n_steps];
+        if (A.flags & BR_MODSWITCH) barb = modswitch_2N<10>(barb);
+        const int a0 = (2 * N - barb) & (2 * N - 1);  // lwe_functions.cpp:385-386
+        const T *tv = A.tv + (size_t)ct * A.tv_stride;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int j = tid + 256 * m;
+            const int idx = (j - a0) & (2 * N - 1);
+            const int src = idx & (N - 1);
+            U v;
+            if (A.flags & BR_TV_CONST)
+                v = (U)A.tv_const;
+            else if (A.flags & BR_TV_HALF)
+                v = (src < N / 2) ? (U)(0 - (U)A.tv_const) : (U)A.tv_const;
+            else
+                v = (U)tv[src];
+            acc[j] = 0;
+            acc[N + j] = (T)((idx & N) ? (U)(0 - v) : v);
+        }
+    } else {
+        const T *src = A.acc_io + (size_t)ct * 2 * N;
+#pragma unroll
+        for (int m = 0; m < 8; m++) acc[tid + 256 * m] = src[tid + 256 * m];
+    }
+    __syncthreads();
+
+    WaveLds<T, 10> w;
+    w.smem = smem;
+    w.acc = acc;
+    w.acc_lds = tfhe_lds_offset(acc);
+    if (w.acc_lds & (uint32_t)(sizeof(T) * N - 1)) TFHE_TRAP();  // rotated_minus_one relies on it: fail loudly
+    w.xch = WaveFFT<10>::make_xch(reinterpret_cast<double *>(smem + L::xch_at(wave)), t);
+    w.tw.tw = reinterpret_cast<const double2 *>(smem + L::tw_at);
+    w.tw.t = t;
+    w.tw.load_uniform(A.tw);
+    w.progress_lds = 0;
+    w.self = w.partner = wave;
+
+    const U offset = (U)A.gd.offset, flip = (U)A.gd.flip;
+    const int Bgbit = BGC ? BGC : A.gd.Bgbit;
+    const int q = wave >> 1, d = wave & 1;          // phase 1: row p = q * l + d = wave
+    const int decal = 32 - (d + 1) * Bgbit;         // wave-uniform
+    const bool fwd = wave < 2;                      // phase 2: this wave owns output polynomial `wave`
+    double2 *hand = reinterpret_cast<double2 *>(smem + L::hand_at);
+
+    // rotation of step i (0 = skipped, lwe_functions.cpp:348-350); wave-uniform scalar loads
+    auto rotation = [&](int i) {
+        int a = tfhe_uniform_load32(rot, i);
+        if (A.flags & BR_MODSWITCH) a = modswitch_2N<10>(a);
+        return TFHE_UNIFORM(a);
+    };
+    auto next_step = [&](int i) {  // first step >= i with a non-zero rotation
+        while (i < A.n_steps && rotation(i) == 0) i++;
+        return i;
+    };
+    // This wave's half (output polynomial `wave`) of the key row of a step: rows p = 0..3, [PPL][64] complex each.
+    // Rows 0 and 1 are requested a whole step ahead (right after the previous MAC: 64 registers carried through
+    // phase 1); rows 2 and 3 at the end of phase 1, when its registers are free -- they arrive under the MAC of rows
+    // 0 and 1 from L2, where the idle waves 2 and 3 pulled them during the previous phase 2 (`touch`).  Carrying all
+    // four rows (128 registers) through phase 1 made hipcc park them in AGPRs: ~420 v_accvgpr moves per CMux.
+    double2 bkA[2][PPL], bkB[2][PPL];
+    const uint32_t lane16 = (uint32_t)t * 16u + (uint32_t)(wave & 1) * (uint32_t)(PPL * 64 * 16);
+    auto key_rsrc = [&](int i) {
+        return TFHE_MAKE_BUFFER_RSRC(reinterpret_cast<const unsigned char *>(A.bk + (size_t)i * A.bk_step_stride));
+    };
+    auto request_rows = [&](double2 (&dst)[2][PPL], int i, int p0) {
+        const TFHE_BUFFER_RSRC rsrc = key_rsrc(i);
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int m = 0; m < PPL; m++)
+                dst[p][m] = tfhe_buffer_load_d2(rsrc, lane16, (uint32_t)((((p0 + p) * 2) * PPL + m) * 64) * 16u);
+    };
+    // waves 2, 3: one dword of every 128-byte line of rows 2 and 3 (both output halves: 32 KB = 256 lines, 2 per lane)
+    // of step i's key row -> this XCD's L2.  The values are folded into `sink`, which is what keeps the loads alive.
+    uint32_t sink = 0, touched[2] = {0, 0};
+    auto touch = [&](int i) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(A.bk + (size_t)i * A.bk_step_stride) + (size_t)2 * 2 * PPL * 64 * 4;
+        const int line = ((wave & 1) * 64 + t) * 2;
+#pragma unroll
+        for (int k = 0; k < 2; k++) touched[k] = row[(size_t)(line + k) * 32];
+    };
+
+    int i = next_step(0);
+    if (fwd && i < A.n_steps) {
+        TFHE_KEEP_BRANCH();
+        request_rows(bkA, i, 0);
+    }
+#pragma unroll 1
+    while (i < A.n_steps) {
+        const int a = rotation(i);
+        const int inext = next_step(i + 1);
+        // ---- phase 1: digit d of polynomial q of (X^a - 1) * acc, to the Lagrange domain
+        {
+            U lo[PPL], hi[PPL];
+            rotated_minus_one<T, 10>(w, q, a, offset, flip, lo, hi, t);
+            double xr[1][PPL], xi[1][PPL];
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {  // field tops are flipped: the signed field IS digit - Bg/2 (Gadget::flip)
+                xr[0][m] = (double)TFHE_SBFE(lo[m], decal, Bgbit);
+                xi[0][m] = (double)TFHE_SBFE(hi[m], decal, Bgbit);
+            }
+            WaveFFT<10>::template ifft<1, TwLds<10>, true>(xr, xi, w.tw, w.xch, t);
+            double2 *h = hand + wave * NC + t;
+#pragma unroll
+            for (int m = 0; m < PPL; m++) h[64 * m] = make_double2(xr[0][m], xi[0][m]);
+        }
+        TFHE_ORDER();
+        if (fwd) {
+            TFHE_KEEP_BRANCH();
+            request_rows(bkB, i, 2);
+        }
+        __syncthreads();  // the four digits are in the hand-over buffer
+        // ---- phase 2 (waves 0, 1): MAC in row order, forward transform, round, acc += result
+        if (fwd) {
+            TFHE_KEEP_BRANCH();
+            double fr[1][PPL], fi[1][PPL];
+            // digits read one row ahead of their MAC (two rows = 64 registers in flight; left to itself hipcc issues
+            // all four rows' reads up front: 128 registers next to the 128 of the key rows, and spills)
+            double ar[2][PPL], ai[2][PPL];
+            auto read_digit = [&](int p) {
+                const double2 *h = hand + p * NC + t;
+#pragma unroll
+                for (int m = 0; m < PPL; m++) {
+                    const double2 v = h[64 * m];
+                    ar[p & 1][m] = v.x;
+                    ai[p & 1][m] = v.y;
+                }
+            };
+            read_digit(0);
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                if (p < 3) read_digit(p + 1);
+                TFHE_ORDER();
+                if (p == 0)
+                    mac_half_row<PPL, true>(fr[0], fi[0], ar[0], ai[0], bkA[0]);
+                else
+                    mac_half_row<PPL, false>(fr[0], fi[0], ar[p & 1], ai[p & 1], p == 1 ? bkA[1] : bkB[p - 2]);
+#pragma unroll
+                for (int m = 0; m < PPL; m++) {  // pins the row's arithmetic here (the optimiser otherwise sinks all four
+                    TFHE_OPAQUE(fr[0][m]);       // rows below the key request, and every digit and key register stays live)
+                    TFHE_OPAQUE(fi[0][m]);
+                }
+                TFHE_ORDER();
+            }
+            TFHE_ORDER();  // not above the MAC: the old and the new rows would both be live
+            if (inext < A.n_steps) {
+                TFHE_KEEP_BRANCH();
+                request_rows(bkA, inext, 0);  // in flight during the transform below and the whole of the next phase 1
+            }
+            TFHE_ORDER();
+            WaveFFT<10>::template fft<1, TwLds<10>, true>(fr, fi, w.tw, w.xch, t);
+            U r0[PPL], r1[PPL];
+            uint32_t guard = 0;
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                r0[m] = (U)Torus<T>::from_double_fast(fr[0][m], guard);
+                r1[m] = (U)Torus<T>::from_double_fast(fi[0][m], guard);
+            }
+            if (TFHE_WAVE_ANY(!Torus<T>::guard_ok(guard))) {  // |x| >= 2^51 somewhere: the reference's own form
+                TFHE_KEEP_BRANCH();
+#pragma unroll
+                for (int m = 0; m < PPL; m++) {
+                    TFHE_OPAQUE(fr[0][m]);
+                    TFHE_OPAQUE(fi[0][m]);
+                    r0[m] = (U)Torus<T>::from_double(fr[0][m]);
+                    r1[m] = (U)Torus<T>::from_double(fi[0][m]);
+                }
+            }
+            U *pacc = reinterpret_cast<U *>(acc + wave * N);
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                TFHE_LDS_ADD(&pacc[G::jA(t, m)], r0[m]);
+                TFHE_LDS_ADD(&pacc[G::jA(t, m) + NC], r1[m]);
+            }
+        } else {
+            TFHE_KEEP_BRANCH();
+            sink ^= touched[0] ^ touched[1];  // the previous step's touches have long landed
+            if (inext < A.n_steps) {
+                TFHE_KEEP_BRANCH();
+                touch(inext);
+            }
+        }
+        __syncthreads();  // accumulator updated; hand-over buffer free
+        i = inext;
+    }
+    if (sink == 0x9E3779B9u && A.batch < 0) A.lwe_out[0] = (T)sink;  // never true: keeps `touch` observable
+    // ---- output
+    if (A.flags & BR_EXTRACT) {  // tLweExtractLweSampleIndex, index 0 (tlwe_functions.cpp:351-363)
+        T *out = A.lwe_out + (size_t)ct * (N + 1);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int j = tid + 256 * m;
+            out[j] = (j == 0) ? acc[0] : (T)(0 - (U)acc[N - j]);
+        }
+        if (tid == 0) out[N] = (T)((U)acc[N] + (U)A.out_b_add);
+    } else {
+        T *dst = A.acc_io + (size_t)ct * 2 * N;
+#pragma unroll
+        for (int m = 0; m < 8; m++) dst[tid + 256 * m] = acc[tid + 256 * m];
+    }
+}
+
 // ------------------------------------------- standalone batched transforms
 // FFT plugin boundary (CB/spqlios/lagrangehalfc_impl.h:8-31), one wave per polynomial.
 template <int LOGN, int WAVES>

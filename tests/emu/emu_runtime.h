@@ -46,6 +46,7 @@ using dim3 = emu::Dim3;
 #define TFHE_WAVE_FENCE() emu::wave_fence()
 #define TFHE_UNIFORM(x) (x)
 #define TFHE_SCHED_BARRIER() ((void)0)
+#define TFHE_ORDER() ((void)0)
 #define TFHE_SCHED_GROUP(mask, size) ((void)0)
 static inline int32_t tfhe_emu_sbfe(uint32_t x, int off, int width) {
     return (int32_t)((uint32_t)(x >> off) << (32 - width)) >> (32 - width);

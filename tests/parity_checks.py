@@ -101,11 +101,16 @@ def check_fft_plugin(lib_path, N, count=4, seed=11):
 
 
 # ------------------------------------------------------------ Torus32 path
-def check_gate_path(lib_path, N, n, l, Bgbit, ks_t, ks_bb, B, seed=21, check_export=True):
+def check_gate_path(lib_path, N, n, l, Bgbit, ks_t, ks_bb, B, seed=21, check_export=True, br_split=None):
+    """br_split: None = the library's own choice of blind-rotation kernel; 0 = one wave per ciphertext
+    (k_blind_rotate) whatever the batch; a large value = the latency-shaped kernel (k_blind_rotate_split)
+    wherever it applies (Torus32, N = 1024, l = 2)."""
     rs = np.random.RandomState(seed)
     s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb)
     e = s.eng
     try:
+        if br_split is not None:
+            e.set_option(T.OPT_BR_SPLIT, br_split)
         # harness parity: the library's key generator == the oracle's (same PRNG spec)
         assert np.array_equal(T.keygen_binary(n, s.seed, 1, lib_path=lib_path), s.lwe_key)
         bkt = T.keygen_bk_torus(32, s.lwe_key, s.tkey, l, Bgbit, s.bk_stdev, s.seed, 1000, lib_path=lib_path)

@@ -26,13 +26,53 @@ def test_bench_line_on_emulator(emu_lib):
     assert d["unit"] == "bootstraps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the binding unit is fp64 issue; the north-star HBM accounting rides along as hbm_contract
+    assert r["bound"] == "fp64_issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["peak"] - 1024 * 2.4 / 4) < 1e-9 and r["fp64_wave_instr_per_cmux"] == 2144
+    h = r["hbm_contract"]
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
     # 16,388 B per CMux per sample + 65,536 B key row per CMux per launch, n = 630 CMux
-    assert r["algorithmic_bytes_per_launch"] == 2 * 630 * 16388 + 630 * 65536
+    assert h["algorithmic_bytes_per_launch"] == 2 * 630 * 16388 + 630 * 65536
+    assert "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "bootstraps/s"
     assert d["decrypt_check"] is True
     assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_multi_rank_path_on_emulator(emu_lib):
+    """the world > 1 branch of bench.py (torch first, process group, barrier, max over ranks on a tensor, --total
+    slicing, cpu_baseline on rank 0) under torch.distributed.run with two ranks: gloo + the emulator build here,
+    nccl (= RCCL) + the HIP library on the GPU boxes"""
+    port = 29600 + (os.getpid() % 300)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--lib", emu_lib, "--backend", "gloo", "--total", "5", "--steps", "1", "--warmup", "0",
+                          "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 only
+    d = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["total_per_step"] == 5 and d["config"]["batch_per_gpu"] == 3  # ragged: 3 + 2
+    assert "gloo, world 2" in d["config"]["process_group"]
+    assert d["decrypt_check"] is True
+    assert abs(d["value"] - 5 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_dist_flag_single_rank_on_emulator(emu_lib):
+    """--dist: the same branch with world size 1 (what a 1-GPU box can run of the driver's N > 1 launch)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + (os.getpid() % 90)))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", emu_lib, "--dist", "--backend", "gloo", "--total", "2",
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and "gloo, world 1" in d["config"]["process_group"]
+    assert "cpu_baseline" not in d
 
 
 def test_smoke_logic_on_emulator(emu_lib, monkeypatch):

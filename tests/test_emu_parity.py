@@ -22,6 +22,20 @@ def test_gate_path_emu_n1024(emu_lib):
     P.check_gate_path(emu_lib, N=1024, n=6, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=3)
 
 
+@pytest.mark.parametrize("B", [1, 3])
+def test_gate_path_emu_both_blind_rotation_kernels(emu_lib, B):
+    """the same inputs through the latency-shaped kernel (one ciphertext per 4-wave workgroup) and through the
+    one-wave-per-ciphertext kernel: both bit-identical to the oracle"""
+    P.check_gate_path(emu_lib, N=1024, n=5, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=B, check_export=False, br_split=1 << 30)
+    P.check_gate_path(emu_lib, N=1024, n=5, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=B, check_export=False, br_split=0)
+
+
+def test_gate_path_emu_split_kernel_runtime_bgbit(emu_lib):
+    """k_blind_rotate_split<0> (Bgbit read at run time) and <8> (the circuit bootstrap's output gadget)"""
+    P.check_gate_path(emu_lib, N=1024, n=3, l=2, Bgbit=9, ks_t=8, ks_bb=2, B=2, check_export=False, seed=12, br_split=1 << 30)
+    P.check_gate_path(emu_lib, N=1024, n=3, l=2, Bgbit=8, ks_t=8, ks_bb=2, B=2, check_export=False, seed=14, br_split=1 << 30)
+
+
 def test_rounding_extremes_emu(emu_lib):
     P.check_rounding_extremes(emu_lib)
 

@@ -201,6 +201,79 @@ def test_batch_4096_properties(gpu_lib):
         s.close()
 
 
+def test_config5_single_gpu_leg_one_launch(gpu_lib):
+    """BASELINE config 5, the leg one GPU can run: 2^20 gate bootstraps in ONE launch of the blind rotation and ONE
+    of the key switch (what every rank of `bench.py --gpus N` does with its slice).  Checked by (i) bit-equality with
+    the oracle on 16 scattered samples, (ii) the last samples of the batch being copies of the first ones (64-bit
+    offsets at the far end of every buffer), (iii) every 65,536th output equal to a small-batch run of the same
+    inputs -- which the library serves with its other blind-rotation kernel, (iv) decrypt-sign of real encryptions
+    placed at both ends."""
+    N, n, l, Bgbit, t, bb, B = 1024, 630, 2, 10, 8, 2, 1 << 20
+    s = P.GateSetup(gpu_lib, N, n, l, Bgbit, t, bb)
+    try:
+        mu = 1 << 29
+        rs = np.random.RandomState(5)
+        x = np.frombuffer(rs.bytes(B * (n + 1) * 4), dtype=np.int32).reshape(B, n + 1).copy()  # uniformly random samples
+        msgs = [mu if (i % 3) else -mu for i in range(8)]
+        real = s.encrypt(msgs)
+        x[:8] = real
+        x[B // 2:B // 2 + 8] = real
+        ntail = 24
+        x[B - ntail:] = x[:ntail]
+        out = s.eng.bootstrap(mu, x)
+        assert out.shape == (B, n + 1)
+        assert np.array_equal(out[B - ntail:], out[:ntail]), "far end of the batch"
+        assert np.array_equal(out[B // 2:B // 2 + 8], out[:8]), "middle of the batch"
+        for i in range(8):
+            assert (O.lwe_phase32(out[i], s.lwe_key) > 0) == (msgs[i] > 0), "decrypt-sign"
+        strided = np.arange(0, B, 65536)
+        small = s.eng.bootstrap(mu, np.ascontiguousarray(x[strided]))
+        assert np.array_equal(out[strided], small), "every 65,536th output vs a 16-sample launch of the same inputs"
+        scattered = np.concatenate([[0, 1, 65535, 65536, B // 2 - 1, B // 2 + 8, B - ntail - 1, B - 1],
+                                    rs.choice(B, 8, replace=False)])
+        want = np.stack([O.bootstrap32(N, s.bk, s.ks, mu, x[i], l, Bgbit, t, bb) for i in scattered])
+        assert np.array_equal(out[scattered], want), "oracle, 16 scattered samples"
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 6, 7])
+def test_gate_path_latency_kernel(gpu_lib, B):
+    """BASELINE config 1's shape (the reference bootstraps one sample per call, lwe_functions.cpp:434-446): batches
+    1..7 through the latency-shaped blind rotation (one ciphertext per 4-wave workgroup) AND through the
+    one-wave-per-ciphertext kernel, every entry point of the gate path bit-compared with the oracle"""
+    P.check_gate_path(gpu_lib, N=1024, n=11, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=B, check_export=False, seed=100 + B,
+                      br_split=1 << 30)
+    P.check_gate_path(gpu_lib, N=1024, n=11, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=B, check_export=False, seed=100 + B,
+                      br_split=0)
+
+
+def test_gate_path_latency_kernel_full_parameters(gpu_lib):
+    """n = 630 on the latency-shaped kernel, including a batch above one workgroup per CU (300 > 256)"""
+    P.check_gate_path(gpu_lib, N=1024, n=630, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=3, check_export=False, br_split=1 << 30)
+    N, n, l, Bgbit, t, bb, B = 1024, 630, 2, 10, 8, 2, 300
+    s = P.GateSetup(gpu_lib, N, n, l, Bgbit, t, bb)
+    try:
+        rs = np.random.RandomState(300)
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(B, n + 1)).astype(np.int32)
+        s.eng.set_option(T.OPT_BR_SPLIT, 1 << 30)
+        a = s.eng.bootstrap(1 << 29, x)
+        s.eng.set_option(T.OPT_BR_SPLIT, 0)
+        b = s.eng.bootstrap(1 << 29, x)
+        assert np.array_equal(a, b), "latency-shaped kernel vs one wave per ciphertext, 300 samples"
+        sub = rs.choice(B, 6, replace=False)
+        want = np.stack([O.bootstrap32(N, s.bk, s.ks, 1 << 29, x[i], l, Bgbit, t, bb) for i in sub])
+        assert np.array_equal(a[sub], want)
+    finally:
+        s.close()
+
+
+def test_gate_path_latency_kernel_other_bgbit(gpu_lib):
+    """k_blind_rotate_split<8> (the circuit bootstrap's output gadget) and <0> (Bgbit read at run time)"""
+    P.check_gate_path(gpu_lib, N=1024, n=7, l=2, Bgbit=8, ks_t=8, ks_bb=2, B=5, check_export=False, seed=14, br_split=1 << 30)
+    P.check_gate_path(gpu_lib, N=1024, n=6, l=2, Bgbit=9, ks_t=8, ks_bb=2, B=5, check_export=False, seed=12, br_split=1 << 30)
+
+
 def test_n2048_transform_batch_8192(gpu_lib):
     """BASELINE config 4: N=2048 transforms, batch 8192.  Round-trip and linearity properties on
     the whole batch, oracle equality on a subset."""

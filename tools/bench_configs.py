@@ -3,6 +3,7 @@
 
     python tools/bench_configs.py fft   [--batch 8192] [--reps 5]     BASELINE config 4
     python tools/bench_configs.py cb    [--cb-batch 768] [--reps 3]   BASELINE config 3
+    python tools/bench_configs.py lat   [--lat-batches 1,8,64,...]    BASELINE config 1 (latency) and small batches
     python tools/bench_configs.py all
 
 fft  batched N=2048 transforms through the FFT-plugin entry points: 8,192
@@ -175,9 +176,54 @@ def bench_cb(T, a):
     return [line, l2line]
 
 
+def bench_latency(T, a):
+    """BASELINE config 1: a single gate bootstrap (and small batches) -- the reference's own unit of work is one
+    sample per call (lwe_functions.cpp:434-446).  Each batch size is timed on both blind-rotation kernels: the
+    latency-shaped one (one ciphertext per 4-wave workgroup, k_blind_rotate_split) and one wave per ciphertext
+    (k_blind_rotate); `auto` is what the library picks by itself.  HIP-event time of tfhe_amd_bootstrap (blind
+    rotation + extraction + key switch) and host wall time of call + sync."""
+    import time
+    shard = importlib.import_module("experimental-tfhe_amd.shard")
+    cfg = shard.GateConfig() if not a.small else shard.GateConfig(n=6)
+    job = shard.GateJob(cfg, 0x5446484500000001, device=0, lib_path=a.lib)
+    eng, lib = job.eng, job.eng.lib
+    sizes = [1, 2, 3] if a.small else [int(x) for x in a.lat_batches.split(",")]
+    bmax = max(sizes)
+    x = shard.synthetic_samples(cfg, bmax, seed=99)
+    nreal = min(8, bmax)
+    msgs = [(1 << 29) if (i & 1) else -(1 << 29) for i in range(nreal)]
+    x[:nreal] = job.encrypt(msgs)
+    x_d, out_d = eng.to_device(x), eng.alloc(bmax * (cfg.n + 1) * 4)
+    eng._chk(lib.tfhe_amd_bootstrap(eng.ctx, out_d.ptr, 1 << 29, x_d.ptr, bmax))  # workspaces sized once
+    ref_out = {}
+    for B in sizes:
+        line = {"workload": f"tfhe_bootstrap_FFT, batch {B}, {cfg.describe()}", "batch": B}
+        for name, opt in (("split", 1 << 30), ("one_wave_per_ciphertext", 0), ("auto", -1)):
+            eng.set_option(T.OPT_BR_SPLIT, opt)
+            fn = lambda: eng._chk(lib.tfhe_amd_bootstrap(eng.ctx, out_d.ptr, 1 << 29, x_d.ptr, B))
+            best, mean = timed(eng, a.reps, fn)
+            eng.sync()
+            walls = []
+            for _ in range(a.reps):
+                t0 = time.perf_counter()
+                fn()
+                eng.sync()
+                walls.append(time.perf_counter() - t0)
+            out = out_d.download(np.int32, (bmax, cfg.n + 1))[:B]
+            same = bool(np.array_equal(out, ref_out.setdefault(B, out)))
+            ok = all((job.phase(out[i]) > 0) == (msgs[i] > 0) for i in range(min(nreal, B)))
+            line[name] = {"ms_min": best, "ms_mean": mean, "host_wall_ms_min": 1e3 * min(walls),
+                          "bootstraps_per_s": B / (best * 1e-3), "decrypt_check": bool(ok), "identical_to_split": same}
+        line["speedup_split_over_one_wave"] = line["one_wave_per_ciphertext"]["ms_min"] / line["split"]["ms_min"]
+        print(json.dumps(line), flush=True)
+    eng.set_option(T.OPT_BR_SPLIT, -1)
+    job.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["fft", "cb", "all"])
+    ap.add_argument("what", choices=["fft", "cb", "lat", "all"])
+    ap.add_argument("--lat-batches", default="1,8,64,256,512,768,1024,2048,4096")
     ap.add_argument("--batch", type=int, default=8192, help="polynomials per launch (fft)")
     ap.add_argument("--cb-batch", type=int, default=1024,
                     help="LWE inputs per circuit-bootstrap launch (default 1024 = one Torus64 N=2048 ciphertext per wave, "
@@ -193,6 +239,8 @@ def main():
         bench_fft(T, a)
     if a.what in ("cb", "all"):
         bench_cb(T, a)
+    if a.what in ("lat", "all"):
+        bench_latency(T, a)
 
 
 if __name__ == "__main__":
