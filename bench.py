@@ -145,6 +145,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     use_dist = world > 1 or a.dist
+    if a.backend == "gloo":
+        local = 0  # CPU test runs on the emulator build: one (emulated) device for every rank
     T = importlib.import_module("experimental-tfhe_amd")  # pure python so far: nothing dlopen'ed yet
     shard = importlib.import_module("experimental-tfhe_amd.shard")
     cfg = shard.GateConfig()
@@ -199,7 +201,23 @@ def main():
             dev = torch.device("cuda", local)
         else:
             dev = torch.device("cpu")
-        dist.init_process_group(a.backend, rank=rank, world_size=world)  # nccl == RCCL on ROCm
+        # RCCL prints a version banner on STDOUT when its communicator is created (at the first collective); stdout
+        # of this program is the one JSON line, so file descriptor 1 points at stderr until that has happened
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if a.backend == "nccl":
+                dist.init_process_group(a.backend, rank=rank, world_size=world, device_id=dev)  # nccl == RCCL on ROCm
+            else:
+                dist.init_process_group(a.backend, rank=rank, world_size=world)
+            dist.barrier()
+            if a.backend == "nccl":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     try:
         job = shard.GateJob(cfg, SEED, device=local, lib_path=a.lib)  # identical key replicas on every rank

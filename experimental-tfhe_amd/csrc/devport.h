@@ -121,6 +121,8 @@ __device__ __forceinline__ double2 tfhe_buffer_load_d2(TFHE_BUFFER_RSRC rsrc, ui
     return __builtin_bit_cast(double2, v);
 }
 #define TFHE_TRAP() __builtin_trap()
+// the workgroup's dynamic LDS block
+#define TFHE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 // D = A(32x32 int8) * B(32x32 int8) + C(32x32 int32) on the matrix cores, one wave.  Lane l holds
 // A[row l & 31][k = 16 * (l >> 5) + 0..15] and B[k = 16 * (l >> 5) + 0..15][col l & 31] as 16 bytes each;
 // C/D: column l & 31, row (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5).

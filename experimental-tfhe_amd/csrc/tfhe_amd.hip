@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/tfhe_amd.h"
@@ -44,6 +45,7 @@ struct tfhe_amd_ctx {
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
     int br_split_max;      // TFHE_AMD_OPT_BR_SPLIT: largest batch served by k_blind_rotate_split (< 0: BR_SPLIT_AUTO_MAX, 0: never)
+    int br_team;           // TFHE_AMD_OPT_BR_TEAM: Torus64 / N = 2048 blind rotations on k_blind_rotate_team (default) or k_blind_rotate
     int ks_force_gather;   // TFHE_AMD_OPT_KS_GATHER: != 0 per-sample gather kernel even where the matrix-core kernel applies
     // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
     // hipGraph and replayed while the call's arguments stay the same
@@ -57,6 +59,7 @@ struct tfhe_amd_ctx {
         int ks_gather;
     } sg;
     std::vector<const void *> lds_configured;  // kernels whose dynamic-LDS limit is raised on this device
+    std::vector<std::pair<const void *, long long>> resident_blocks;  // persistent-wave kernels: workgroups the device keeps resident
 };
 
 namespace {
@@ -172,17 +175,19 @@ int set_lds(tfhe_amd_ctx *c, KernelT kernel, size_t bytes) {
 // with its dynamic LDS x number of CUs), never more than the work needs
 template <typename KernelT>
 int persistent_grid(tfhe_amd_ctx *c, KernelT kernel, int block, size_t lds, int needed, int *grid) {
-#ifdef TFHE_EMU
-    *grid = needed < 3 ? needed : 3;  // a small fixed grid: the batch loop of every wave is exercised
-    (void)c; (void)kernel; (void)block; (void)lds;
-#else
+    // constant per (kernel, its LDS size, device): queried once per context, not on every small-batch plugin call
     const void *key = reinterpret_cast<const void *>(kernel);
-    int per_cu = 0, cus = 0;
-    HIPCHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, key, block, lds));
-    HIPCHECK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    const long long resident = (long long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+    long long resident = 0;
+    for (const auto &e : c->resident_blocks)
+        if (e.first == key) resident = e.second;
+    if (!resident) {
+        int per_cu = 0, cus = 0;
+        HIPCHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, key, block, lds));
+        HIPCHECK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        resident = (long long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+        c->resident_blocks.emplace_back(key, resident);
+    }
     *grid = (int)(needed < resident ? needed : resident);
-#endif
     return TFHE_AMD_OK;
 }
 
@@ -229,7 +234,20 @@ int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
     if (c->p.l == 2) return launch_br_t<int32_t, 10, 8, 2, 2>(c, a);
     return launch_br_t<int32_t, 10, 8, 2>(c, a);
 }
+// Torus64 / N = 2048 plain blind rotations: two waves per ciphertext, two ciphertexts per workgroup
+// (tfhe_kernels.h k_blind_rotate_team)
+template <int TEAMS>
+int launch_br_team(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
+    auto kernel = k_blind_rotate_team<TEAMS>;
+    if (int rc = set_lds(c, kernel, TeamLds<TEAMS>::total)) return rc;
+    TFHE_LAUNCH((k_blind_rotate_team<TEAMS>), dim3((a.batch + TEAMS - 1) / TEAMS), dim3(TEAMS * 128), TeamLds<TEAMS>::total, c->stream, a);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
 int launch_br64(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
+    if (c->logn == 11 && c->br_team && a.n_steps >= 1 && !(a.flags & (BR_NO_ROTATE | BR_CMUX_DATA | BR_MODSWITCH)) && !a.gsw_sel &&
+        a.sel_div <= 0)
+        return c->br_team == 2 ? launch_br_team<2>(c, a) : launch_br_team<4>(c, a);
     // N=2048: accumulator in registers, 4 waves per workgroup (one per SIMD); tfhe_kernels.h, BlindRotateLds::ACCREG
     return c->logn == 10 ? launch_br_t<int64_t, 10, 4, 2>(c, a) : launch_br_t<int64_t, 11, 4, 1>(c, a);
 }
@@ -271,9 +289,7 @@ int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
 }
 
 void drop_streamed_graph(tfhe_amd_ctx *c) {
-#ifndef TFHE_EMU
     if (c->sg.exec) (void)hipGraphExecDestroy((hipGraphExec_t)c->sg.exec);
-#endif
     c->sg.exec = nullptr;
 }
 
@@ -469,11 +485,6 @@ extern "C" {
 
 int tfhe_amd_device_info(int device, char *buf, size_t len) {
     if (!buf || len == 0) return TFHE_AMD_ERR_PARAM;
-#ifdef TFHE_EMU
-    (void)device;
-    snprintf(buf, len, "CPU emulation of the kernels (tests/emu), not a device");
-    return TFHE_AMD_OK;
-#else
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return TFHE_AMD_ERR_DEVICE;
     int rt = 0, drv = 0;
@@ -484,7 +495,6 @@ int tfhe_amd_device_info(int device, char *buf, size_t len) {
              p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000, (double)p.totalGlobalMem / (1 << 30),
              p.sharedMemPerBlock >> 10, (size_t)p.sharedMemPerBlockOptin >> 10, p.l2CacheSize >> 20, p.warpSize, rt, drv);
     return TFHE_AMD_OK;
-#endif
 }
 
 const char *tfhe_amd_version(void) { return "experimental-tfhe_amd 0.1 (gfx950)"; }
@@ -514,6 +524,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->ksm_d = nullptr;
     c->ks_force_gather = 0;
     c->br_split_max = -1;
+    c->br_team = 1;
     c->streamed_graph = false;
     c->streamed_warm = 0;
     memset(&c->sg, 0, sizeof(c->sg));
@@ -525,13 +536,11 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
         delete c;
         return TFHE_AMD_ERR_DEVICE;
     }
-#ifndef TFHE_EMU
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return TFHE_AMD_ERR_DEVICE;
     }
     c->own_stream = true;
-#endif
     // from here on the context owns device objects: failures go through tfhe_amd_ctx_destroy
     std::vector<double2> tw;
     if (!build_tables(p->N, c->fft_trig, c->ifft_trig, tw)) {
@@ -575,9 +584,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     if (c->vp_rot_d) (void)hipFree(c->vp_rot_d);
     if (c->hp_tw_d) (void)hipFree(c->hp_tw_d);
     drop_streamed_graph(c);
-#ifndef TFHE_EMU
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
-#endif
     delete c;
 }
 
@@ -585,7 +592,6 @@ const char *tfhe_amd_last_error(const tfhe_amd_ctx *c) { return c ? c->err.c_str
 
 int tfhe_amd_set_stream(tfhe_amd_ctx *c, void *s) {
     if (!c) return TFHE_AMD_ERR_PARAM;
-#ifndef TFHE_EMU
     if (s) {
         if (c->own_stream) {
             HIPCHECK(c, hipStreamSynchronize(c->stream));
@@ -597,9 +603,6 @@ int tfhe_amd_set_stream(tfhe_amd_ctx *c, void *s) {
         HIPCHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-#else
-    (void)s;
-#endif
     return TFHE_AMD_OK;
 }
 
@@ -611,6 +614,9 @@ int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_STREAMED_GRAPH:
             c->streamed_graph = value != 0;
+            return TFHE_AMD_OK;
+        case TFHE_AMD_OPT_BR_TEAM:
+            c->br_team = value;  // 0: one wave per ciphertext; 2: two teams per workgroup; else four
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_BR_SPLIT:
             c->br_split_max = value;
@@ -1062,7 +1068,6 @@ int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, con
     if (!c->bk) return fail(c, TFHE_AMD_ERR_STATE, "no bootstrapping key");
     if (!c->ks_d) return fail(c, TFHE_AMD_ERR_STATE, "no key-switch key");
     if (batch == 0) return TFHE_AMD_OK;
-#ifndef TFHE_EMU
     if (c->streamed_graph) {
         // workspace growth and per-kernel LDS attributes must not happen inside a capture: grow now,
         // and let the first call of each schedule variant run as plain launches
@@ -1100,7 +1105,6 @@ int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, con
         HIPCHECK(c, hipGraphLaunch((hipGraphExec_t)c->sg.exec, c->stream));
         return TFHE_AMD_OK;
     }
-#endif
     return streamed_plain(c, out_d, mu, x_d, batch);
 }
 
@@ -1367,24 +1371,38 @@ int tfhe_amd_cb_load_privks_plane(tfhe_amd_cb *cb, int u, const int32_t *plane) 
     if (hipSetDevice(cb->c2->device) != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "hipSetDevice");
     const size_t bytes = (size_t)(cb->p.N2 + 1) * cb->p.t21 * ((size_t)1 << cb->p.bb21) * 2 * cb->p.N1 * 4;
     tfhe_amd_ctx *c = cb->c2;
-    if (!cb->privks_d[u] && hipMalloc((void **)&cb->privks_d[u], bytes) != hipSuccess)
-        return cb_fail(cb, TFHE_AMD_ERR_ALLOC, "hipMalloc(privKS plane)");
-    if (hipMemcpyAsync(cb->privks_d[u], plane, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
-        return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "upload privKS plane");
+    // The plane is built in NEW buffers and swapped in only when complete: a failed (re)load leaves the handle
+    // without this plane (calls then answer ERR_STATE), never with a half-written one.
+    (void)hipStreamSynchronize(c->stream);  // no kernel may still read the buffers released below
+    if (cb->privks_d[u]) (void)hipFree(cb->privks_d[u]);
+    if (cb->privksm_d[u]) (void)hipFree(cb->privksm_d[u]);
+    cb->privks_d[u] = nullptr;
+    cb->privksm_d[u] = nullptr;
+    int32_t *ref_d = nullptr;
+    int8_t *mat_d = nullptr;
+    auto bail = [&](int code, const char *what) {
+        (void)hipStreamSynchronize(c->stream);  // the asynchronous upload / pack must not outlive their buffers
+        if (ref_d) (void)hipFree(ref_d);
+        if (mat_d) (void)hipFree(mat_d);
+        return cb_fail(cb, code, what);
+    };
+    if (hipMalloc((void **)&ref_d, bytes) != hipSuccess) return bail(TFHE_AMD_ERR_ALLOC, "hipMalloc(privKS plane)");
+    if (hipMemcpyAsync(ref_d, plane, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+        return bail(TFHE_AMD_ERR_DEVICE, "upload privKS plane");
     if (ks_mfma_supported(cb->p.t21, cb->p.bb21)) {
         // re-layout for the matrix-core kernel, then drop the reference-layout copy
         const int n_in = cb->p.N2 + 1, row = 2 * cb->p.N1;
-        if (!cb->privksm_d[u] &&
-            hipMalloc((void **)&cb->privksm_d[u], ks_mfma_bytes(n_in, cb->p.t21, cb->p.bb21, row)) != hipSuccess)
-            return cb_fail(cb, TFHE_AMD_ERR_ALLOC, "hipMalloc(privKS plane, matrix-core layout)");
-        if (ks_mfma_pack(c->stream, cb->privksm_d[u], cb->privks_d[u], n_in, cb->p.t21, cb->p.bb21, row))
-            return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "k_ks_mfma_pack launch");
-        if (hipStreamSynchronize(c->stream) != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "pack privKS plane");
-        (void)hipFree(cb->privks_d[u]);
-        cb->privks_d[u] = nullptr;
+        if (hipMalloc((void **)&mat_d, ks_mfma_bytes(n_in, cb->p.t21, cb->p.bb21, row)) != hipSuccess)
+            return bail(TFHE_AMD_ERR_ALLOC, "hipMalloc(privKS plane, matrix-core layout)");
+        if (ks_mfma_pack(c->stream, mat_d, ref_d, n_in, cb->p.t21, cb->p.bb21, row))
+            return bail(TFHE_AMD_ERR_DEVICE, "k_ks_mfma_pack launch");
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(TFHE_AMD_ERR_DEVICE, "pack privKS plane");
+        (void)hipFree(ref_d);
+        cb->privksm_d[u] = mat_d;
         return TFHE_AMD_OK;
     }
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return cb_fail(cb, TFHE_AMD_ERR_DEVICE, "upload privKS plane");
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(TFHE_AMD_ERR_DEVICE, "upload privKS plane");
+    cb->privks_d[u] = ref_d;
     return TFHE_AMD_OK;
 }
 

@@ -58,68 +58,7 @@ inline void check(int rc, tfhe_amd_ctx *c, const char *what) {
 
 // ---- library-form structs (fields evidenced by use in CB/*_functions.cpp) --------
 #ifndef TFHE_AMD_COMPAT_NO_TYPES
-struct LweParams {
-    int n;
-    double alpha_min, alpha_max;
-};
-struct LweSample {  // lwe_functions.cpp:20-24
-    Torus32 *a;
-    Torus32 b;
-    double current_variance;
-};
-struct TorusPolynomial {  // numeric_functions.cpp:199-223
-    int N;
-    Torus32 *coefsT;
-};
-struct LagrangeHalfCPolynomial {  // N doubles re|im, poc_types.h:96-102
-    double *values;
-};
-struct TLweParams {
-    int N, k;
-    double alpha_min, alpha_max;
-    LweParams extracted_lweparams;
-};
-struct TLweSample {  // tlwe_functions.cpp:27-31
-    TorusPolynomial *a;
-    TorusPolynomial *b;
-    double current_variance;
-    int k;
-};
-struct TLweSampleFFT {  // tlwe_functions.cpp:34-38
-    LagrangeHalfCPolynomial *a;
-    LagrangeHalfCPolynomial *b;
-    double current_variance;
-    int k;
-};
-struct TGswParams {  // tgsw_functions.cpp:15-38
-    int l, Bgbit, Bg;
-    int32_t halfBg;
-    uint32_t maskMod;
-    const TLweParams *tlwe_params;
-    int kpl;
-    Torus32 *h;
-    uint32_t offset;
-};
-struct TGswSampleFFT {  // tgsw_functions.cpp:47-53
-    TLweSampleFFT *all_samples;
-    TLweSampleFFT **sample;
-    int k, l;
-};
-struct LweKeySwitchKey {  // lwe_functions.cpp:96-110
-    int n, t, basebit, base;
-    const LweParams *out_params;
-    LweSample *ks0_raw;
-    LweSample **ks1_raw;
-    LweSample ***ks;
-};
-struct LweBootstrappingKeyFFT {  // lwe_functions.cpp:272-281
-    const LweParams *in_out_params;
-    const TGswParams *bk_params;
-    const TLweParams *accum_params;
-    const LweParams *extract_params;
-    const TGswSampleFFT *bkFFT;
-    const LweKeySwitchKey *ks;
-};
+#include "tfhe_amd_library_types.inc"
 #endif
 
 // ---- one resident engine per (key object, shape) -----------------------------------------------
@@ -127,6 +66,8 @@ struct LweBootstrappingKeyFFT {  // lwe_functions.cpp:272-281
 // different prefixes of it (tGswFFTExternMulToTLwe: 1 sample, tfhe_blindRotate_FFT: n samples) and with
 // or without the key-switch key, so the registry is keyed on the pointer AND the shape it was attached with.
 struct Resident {
+    const void *owner = nullptr;  // the object the caller knows this engine by when it is not the registry key itself
+                                  // (attach(bk) registers under bk->bkFFT; release(bk) must find it)
     tfhe_amd_ctx *ctx = nullptr;
     tfhe_amd_gsw *gsw = nullptr;
     int n = 0, N = 0, l = 0;
@@ -144,6 +85,9 @@ struct ResidentKey {
         return Bgbit < o.Bgbit;
     }
 };
+// Threading contract: like the reference (global scratch in fft_processor_spqlios.cpp:21-24,163-164, global RNG
+// numeric_functions.cpp:14) the shims are SINGLE-THREADED: the registry is an unguarded static map and every
+// resident engine has one set of staging buffers.  Concurrent callers use the batch C ABI with one context each.
 inline std::map<ResidentKey, Resident> &registry() {
     static std::map<ResidentKey, Resident> r;
     return r;
@@ -163,12 +107,14 @@ inline void staging(Resident &R, size_t bytes) {
 
 // flatten n TGswSampleFFT (pointer-rich) into [n][2l][2][N] doubles and upload
 template <class GswT>
-inline Resident &attach_gsw(const GswT *bkFFT, int n, int N, int l, int Bgbit, const LweKeySwitchKey *ks = nullptr) {
+inline Resident &attach_gsw(const GswT *bkFFT, int n, int N, int l, int Bgbit, const LweKeySwitchKey *ks = nullptr,
+                            const void *owner = nullptr) {
     auto &reg = registry();
     const ResidentKey key{(const void *)bkFFT, (const void *)ks, n, N, l, Bgbit};
     auto it = reg.find(key);
     if (it != reg.end()) return it->second;
     Resident R;
+    R.owner = owner;
     R.n = n;
     R.N = N;
     R.l = l;
@@ -218,12 +164,15 @@ inline void release_entry(std::map<ResidentKey, Resident>::iterator it) {
     tfhe_amd_ctx_destroy(R.ctx);
     registry().erase(it);
 }
-// every resident engine attached through this key object (whatever shape it was attached with)
+// every resident engine made from this key object, whatever shape it was attached with and whichever of its
+// addresses the caller passes: the LweBootstrappingKeyFFT, its bkFFT array or its key-switch key.  (The copies are
+// keyed by ADDRESS: a key that is freed and rebuilt at the same address without a release() in between would be
+// served from the stale GPU copy.)
 inline void release(const void *key_object) {
     auto &reg = registry();
     for (auto it = reg.begin(); it != reg.end();) {
         auto cur = it++;
-        if (cur->first.obj == key_object) release_entry(cur);
+        if (cur->first.obj == key_object || cur->first.ks == key_object || cur->second.owner == key_object) release_entry(cur);
     }
 }
 inline void release_all() {
@@ -232,7 +181,7 @@ inline void release_all() {
 
 inline Resident &attach(const LweBootstrappingKeyFFT *bk) {
     return attach_gsw(bk->bkFFT, bk->in_out_params->n, bk->accum_params->N, bk->bk_params->l, bk->bk_params->Bgbit,
-                      bk->ks);
+                      bk->ks, bk);
 }
 
 // ---- library-form entry points ----------------------------------------------------------------

@@ -27,68 +27,7 @@
 #ifndef TFHE_AMD_DROPIN_NO_LIBRARY_TYPES
 typedef int32_t Torus32;
 typedef int64_t Torus64;
-struct LweParams {
-    int n;
-    double alpha_min, alpha_max;
-};
-struct LweSample {  // lwe_functions.cpp:20-24
-    Torus32 *a;
-    Torus32 b;
-    double current_variance;
-};
-struct TorusPolynomial {  // numeric_functions.cpp:199-223
-    int N;
-    Torus32 *coefsT;
-};
-struct LagrangeHalfCPolynomial {  // N doubles re|im
-    double *values;
-};
-struct TLweParams {
-    int N, k;
-    double alpha_min, alpha_max;
-    LweParams extracted_lweparams;
-};
-struct TLweSample {  // tlwe_functions.cpp:27-31
-    TorusPolynomial *a;
-    TorusPolynomial *b;
-    double current_variance;
-    int k;
-};
-struct TLweSampleFFT {  // tlwe_functions.cpp:34-38
-    LagrangeHalfCPolynomial *a;
-    LagrangeHalfCPolynomial *b;
-    double current_variance;
-    int k;
-};
-struct TGswParams {  // tgsw_functions.cpp:15-38
-    int l, Bgbit, Bg;
-    int32_t halfBg;
-    uint32_t maskMod;
-    const TLweParams *tlwe_params;
-    int kpl;
-    Torus32 *h;
-    uint32_t offset;
-};
-struct TGswSampleFFT {  // tgsw_functions.cpp:47-53
-    TLweSampleFFT *all_samples;
-    TLweSampleFFT **sample;
-    int k, l;
-};
-struct LweKeySwitchKey {  // lwe_functions.cpp:96-110
-    int n, t, basebit, base;
-    const LweParams *out_params;
-    LweSample *ks0_raw;
-    LweSample **ks1_raw;
-    LweSample ***ks;
-};
-struct LweBootstrappingKeyFFT {  // lwe_functions.cpp:272-281
-    const LweParams *in_out_params;
-    const TGswParams *bk_params;
-    const TLweParams *accum_params;
-    const LweParams *extract_params;
-    const TGswSampleFFT *bkFFT;
-    const LweKeySwitchKey *ks;
-};
+#include "tfhe_amd_library_types.inc"
 #endif
 
 extern "C" {

@@ -139,6 +139,27 @@ static int run_lib(const char *inp, const char *outp) {
         tGswFFTExternMulToTLwe(&as2, &gsw[n - 1], &gp);
         out.put(acc2.data(), 4 * (size_t)2 * N);
     }
+    // release(bk), then a DIFFERENT key rebuilt at the same addresses (the TGSW samples in reverse order: same
+    // structs, other polynomial pointers): the next call must upload it again, not reuse the stale GPU copy
+    {
+#ifdef DROPIN
+        tfhe_amd_dropin_release(&bk);
+#else
+        release(&bk);
+#endif
+        for (int i = 0; i < n; i++)
+            for (int r = 0; r < kpl; r++)
+                for (int q = 0; q < 2; q++)
+                    polys[((size_t)i * kpl + r) * 2 + q].values = (double *)bkflat + (((size_t)(n - 1 - i) * kpl + r) * 2 + q) * N;
+        LweSample x{(Torus32 *)xs, xs[n], 0};
+        LweSample u{ra.data(), 0, 0}, r{rb.data(), 0, 0};
+        tfhe_bootstrap_woKS_FFT(&u, &bk, mu, &x);
+        out.put(u.a, 4 * (size_t)N);
+        out.put(&u.b, 4);
+        tfhe_bootstrap_FFT(&r, &bk, mu, &x);
+        out.put(r.a, 4 * (size_t)n);
+        out.put(&r.b, 4);
+    }
 #ifdef DROPIN
     tfhe_amd_dropin_release(nullptr);
     out.save(outp);

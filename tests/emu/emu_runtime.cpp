@@ -183,7 +183,22 @@ v16i_t mfma_i32_32x32x32_i8(const v4i_t &a, const v4i_t &b, const v16i_t &c_in) 
     return c;
 }
 
+}  // namespace emu
+struct EmuGraph {
+    std::vector<std::function<void()>> nodes;
+};
+namespace emu {
+static thread_local EmuGraph *t_capture = nullptr;  // hipStreamCaptureModeThreadLocal
+
+static void launch_now(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes);
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes) {
+    if (t_capture) {
+        t_capture->nodes.push_back([body, grid, block, smem_bytes]() { launch_now(body, grid, block, smem_bytes); });
+        return;
+    }
+    launch_now(body, grid, block, smem_bytes);
+}
+static void launch_now(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes) {
     const unsigned nb = grid.x * grid.y;
     unsigned nthreads = std::min<unsigned>(nb, std::max(1u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("TFHE_EMU_THREADS")) nthreads = std::max(1, atoi(e));
@@ -204,7 +219,15 @@ void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t sme
     }
 }
 
+static void launch_flat_now(const std::function<void()> &body, Dim3 grid, Dim3 block);
 void launch_flat(const std::function<void()> &body, Dim3 grid, Dim3 block) {
+    if (t_capture) {
+        t_capture->nodes.push_back([body, grid, block]() { launch_flat_now(body, grid, block); });
+        return;
+    }
+    launch_flat_now(body, grid, block);
+}
+static void launch_flat_now(const std::function<void()> &body, Dim3 grid, Dim3 block) {
     const unsigned nb = grid.x;
     unsigned nthreads = std::min<unsigned>(std::max(1u, nb / 64), std::max(1u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("TFHE_EMU_THREADS")) nthreads = std::max(1, atoi(e));
@@ -234,6 +257,42 @@ void launch_flat(const std::function<void()> &body, Dim3 grid, Dim3 block) {
 }
 
 }  // namespace emu
+
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
+    if (emu::t_capture) return hipErrorInvalidValue;
+    emu::t_capture = new EmuGraph();
+    return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *graph) {
+    *graph = emu::t_capture;
+    emu::t_capture = nullptr;
+    return *graph ? hipSuccess : hipErrorInvalidValue;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t *exec, hipGraph_t graph, void *, void *, unsigned long long) {
+    *exec = new EmuGraph(*graph);
+    return hipSuccess;
+}
+hipError_t hipGraphDestroy(hipGraph_t graph) {
+    delete graph;
+    return hipSuccess;
+}
+hipError_t hipGraphExecDestroy(hipGraphExec_t exec) {
+    delete exec;
+    return hipSuccess;
+}
+hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t) {
+    for (auto &node : exec->nodes) node();
+    return hipSuccess;
+}
+hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+    memset(p, 0, sizeof(*p));
+    snprintf(p->name, sizeof(p->name), "CPU emulation of the kernels (tests/emu), not a device");
+    snprintf(p->gcnArchName, sizeof(p->gcnArchName), "emu");
+    p->multiProcessorCount = 3;
+    p->warpSize = 64;
+    p->sharedMemPerBlock = p->sharedMemPerBlockOptin = 160 * 1024;
+    return hipSuccess;
+}
 
 double emu_now_ms() {
     struct timespec ts;

@@ -22,6 +22,7 @@ struct Dim3 {
     Dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 extern thread_local Dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+// (while a stream capture is open on the calling thread, launches are recorded into the graph instead of run)
 void launch(const std::function<void()> &body, Dim3 grid, Dim3 block, size_t smem_bytes);
 // kernels that never synchronise (no barrier, no LDS hand-off): work-items run as a plain loop
 void launch_flat(const std::function<void()> &body, Dim3 grid, Dim3 block);
@@ -104,6 +105,7 @@ static inline double2 tfhe_buffer_load_d2(TFHE_BUFFER_RSRC rsrc, uint32_t lane_o
 // ---- host runtime subset -------------------------------------------------------------
 typedef int hipError_t;
 typedef void *hipStream_t;
+#define TFHE_DYN_LDS(name) unsigned char *name = emu::dyn_smem()
 enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
@@ -131,3 +133,31 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 template <class F>
 static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+// streams: launches run synchronously, a stream is only a token
+enum { hipStreamNonBlocking = 1 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)(new char); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { delete (char *)s; return hipSuccess; }
+// device queries: one emulated "device" whose persistent-wave kernels get a small fixed grid (3 workgroups), so
+// that the batch loop of every wave is exercised at test sizes
+struct hipDeviceProp_t {
+    char name[256], gcnArchName[256];
+    int multiProcessorCount, clockRate, l2CacheSize, warpSize;
+    size_t totalGlobalMem, sharedMemPerBlock, sharedMemPerBlockOptin;
+};
+hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int device);
+static inline hipError_t hipRuntimeGetVersion(int *v) { *v = 0; return hipSuccess; }
+static inline hipError_t hipDriverGetVersion(int *v) { *v = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 1; return hipSuccess; }
+// stream capture / graphs: a graph is the list of launches recorded between Begin and EndCapture
+struct EmuGraph;
+typedef EmuGraph *hipGraph_t;
+typedef EmuGraph *hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeThreadLocal };
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode);
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *graph);
+hipError_t hipGraphInstantiate(hipGraphExec_t *exec, hipGraph_t graph, void *, void *, unsigned long long);
+hipError_t hipGraphDestroy(hipGraph_t graph);
+hipError_t hipGraphExecDestroy(hipGraphExec_t exec);
+hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t);

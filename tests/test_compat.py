@@ -69,6 +69,10 @@ def run_lib_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=
                               O.blind_rotate_extract32(N, v, bk, rot[c, n], rot[c, :n], l, Bgbit)), "blindRotateAndExtract"
         assert np.array_equal(take(np.int32, 2 * N), O.blind_rotate32(N, acc[c], bk, rot[c, :n], l, Bgbit).ravel()), "blindRotate"
         assert np.array_equal(take(np.int32, 2 * N), O.extprod32(N, acc[c], bk[n - 1], l, Bgbit).ravel()), "tGswFFTExternMulToTLwe"
+    # after release(bk): the key rebuilt at the same addresses with its TGSW samples in reverse order
+    bkr = np.ascontiguousarray(bk[::-1])
+    assert np.array_equal(take(np.int32, N + 1), O.bootstrap_woks32(N, bkr, mu, x[0], l, Bgbit)), "release(bk) + rebuilt key, woKS"
+    assert np.array_equal(take(np.int32, n + 1), O.bootstrap32(N, bkr, ks, mu, x[0], l, Bgbit, t, bb)), "release(bk) + rebuilt key"
     if not plugin:  # the literal drop-in driver (tests/test_dropin.py) has no FFT-plugin section
         assert pos == len(raw)
         return

@@ -105,8 +105,18 @@ def test_torus64_path(gpu_lib, N, n, l, Bgbit, B):
 
 
 def test_circuit_bootstrap_blind_rotation_full(gpu_lib):
-    """PoC parameter block (poc:70-85): n0=500, N2=2048, l2=4, Bgbit2=9, Torus64"""
+    """PoC parameter block (poc:70-85): n0=500, N2=2048, l2=4, Bgbit2=9, Torus64 -- on both blind-rotation kernels
+    (two waves per ciphertext = the default, one wave per ciphertext)"""
     P.check_torus64_path(gpu_lib, N=2048, n=500, l=4, Bgbit=9, B=4, seed=41)
+    P.check_torus64_path(gpu_lib, N=2048, n=500, l=4, Bgbit=9, B=3, seed=42, br_team=0)
+
+
+@pytest.mark.parametrize("B,l,Bgbit,n", [(1, 4, 9, 9), (7, 4, 9, 6), (33, 4, 9, 5), (6, 3, 7, 8), (5, 1, 12, 8), (2, 8, 4, 3)])
+def test_torus64_n2048_team_kernel(gpu_lib, B, l, Bgbit, n):
+    """k_blind_rotate_team (two waves per ciphertext, two ciphertexts per workgroup): odd and even batches, several
+    workgroups, gadget lengths 1..8, digits in the high word, the low word and across both"""
+    P.check_torus64_path(gpu_lib, N=2048, n=n, l=l, Bgbit=Bgbit, B=B, seed=200 + B, br_team=1)
+    P.check_torus64_path(gpu_lib, N=2048, n=n, l=l, Bgbit=Bgbit, B=B, seed=200 + B, br_team=0)
 
 
 def test_cmux_on_data(gpu_lib):
