@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libtfhe_amd.so")
 
 OK, ERR_PARAM, ERR_DEVICE, ERR_STATE, ERR_ALLOC = range(5)
-OPT_KS_GATHER, OPT_STREAMED_GRAPH, OPT_BR_SPLIT, OPT_BR_TEAM = 2, 4, 5, 6
+OPT_KS_GATHER, OPT_STREAMED_GRAPH, OPT_BR_SPLIT = 2, 4, 5
 
 # every symbol include/tfhe_amd.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [

@@ -120,6 +120,11 @@ __device__ __forceinline__ double2 tfhe_buffer_load_d2(TFHE_BUFFER_RSRC rsrc, ui
     const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_off + (off & 4095u)), (int)(off & ~4095u), 0);
     return __builtin_bit_cast(double2, v);
 }
+// loads / stores of data the launch touches once and that should not displace cached data (the nt cache policy)
+template <typename V>
+__device__ __forceinline__ V tfhe_nontemporal_load(const V *p) { return __builtin_nontemporal_load(p); }
+template <typename V>
+__device__ __forceinline__ void tfhe_nontemporal_store(V v, V *p) { __builtin_nontemporal_store(v, p); }
 #define TFHE_TRAP() __builtin_trap()
 // the workgroup's dynamic LDS block
 #define TFHE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]

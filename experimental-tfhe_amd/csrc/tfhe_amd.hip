@@ -45,7 +45,6 @@ struct tfhe_amd_ctx {
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
     int br_split_max;      // TFHE_AMD_OPT_BR_SPLIT: largest batch served by k_blind_rotate_split (< 0: BR_SPLIT_AUTO_MAX, 0: never)
-    int br_team;           // TFHE_AMD_OPT_BR_TEAM: Torus64 / N = 2048 blind rotations on k_blind_rotate_team (default) or k_blind_rotate
     int ks_force_gather;   // TFHE_AMD_OPT_KS_GATHER: != 0 per-sample gather kernel even where the matrix-core kernel applies
     // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
     // hipGraph and replayed while the call's arguments stay the same
@@ -234,54 +233,64 @@ int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
     if (c->p.l == 2) return launch_br_t<int32_t, 10, 8, 2, 2>(c, a);
     return launch_br_t<int32_t, 10, 8, 2>(c, a);
 }
-// Torus64 / N = 2048 plain blind rotations: two waves per ciphertext, two ciphertexts per workgroup
-// (tfhe_kernels.h k_blind_rotate_team)
-template <int TEAMS>
-int launch_br_team(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
-    auto kernel = k_blind_rotate_team<TEAMS>;
-    if (int rc = set_lds(c, kernel, TeamLds<TEAMS>::total)) return rc;
-    TFHE_LAUNCH((k_blind_rotate_team<TEAMS>), dim3((a.batch + TEAMS - 1) / TEAMS), dim3(TEAMS * 128), TeamLds<TEAMS>::total, c->stream, a);
-    HIPCHECK(c, hipGetLastError());
-    return TFHE_AMD_OK;
-}
 int launch_br64(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
-    if (c->logn == 11 && c->br_team && a.n_steps >= 1 && !(a.flags & (BR_NO_ROTATE | BR_CMUX_DATA | BR_MODSWITCH)) && !a.gsw_sel &&
-        a.sel_div <= 0)
-        return c->br_team == 2 ? launch_br_team<2>(c, a) : launch_br_team<4>(c, a);
-    // N=2048: accumulator in registers, 4 waves per workgroup (one per SIMD); tfhe_kernels.h, BlindRotateLds::ACCREG
+    // N=2048: accumulator in registers, 4 waves per workgroup (one per SIMD); tfhe_kernels.h, BlindRotateLds::ACCREG.
+    // (Two waves per ciphertext -- 128 lanes x 8 points, everything in 256 registers, 8 waves per CU -- was built and
+    // measured in round 3: bit-identical, 1.35 instead of 1.57 vector instructions per fp64 instruction, but 10-20 % SLOWER:
+    // its third transpose and 64 barriers per CMux put the LDS (ds_write_b128: 79 B/clk per CU) on the critical path.
+    // profiles/r03_cb_team_experiment.txt; the kernel is in the history, commit d3c637a.)
     return c->logn == 10 ? launch_br_t<int64_t, 10, 4, 2>(c, a) : launch_br_t<int64_t, 11, 4, 1>(c, a);
 }
 
-template <typename TIN, int LOGN, bool PACK, int WAVES>
-int launch_ifft_w(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
+// bytes one launch reads + writes, against the 256 MB Infinity Cache: beyond it the lane-contiguous accesses are
+// nontemporal (tfhe_kernels.h stream_load / stream_store)
+constexpr size_t STREAMING_WORKING_SET = (size_t)256 << 20;
+template <typename TIN, int LOGN, bool PACK, int WAVES, bool NT>
+int launch_ifft_nt(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
     using Lds = FftLds<LOGN, WAVES>;
-    auto kernel = k_ifft_batch<TIN, LOGN, WAVES, PACK>;
+    auto kernel = k_ifft_batch<TIN, LOGN, WAVES, PACK, NT>;
     if (int rc = set_lds(c, kernel, Lds::total)) return rc;
     int grid = 0;
     if (int rc = persistent_grid(c, kernel, WAVES * 64, Lds::total, (batch + WAVES - 1) / WAVES, &grid)) return rc;
-    TFHE_LAUNCH((k_ifft_batch<TIN, LOGN, WAVES, PACK>), dim3(grid), dim3(WAVES * 64), Lds::total,
+    TFHE_LAUNCH((k_ifft_batch<TIN, LOGN, WAVES, PACK, NT>), dim3(grid), dim3(WAVES * 64), Lds::total,
                 c->stream, out_d, in_d, (const double2 *)c->tw_d, batch);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
-// 4 waves (= polynomials) per workgroup: measured against 8 and 12 on MI355X in the non-persistent form (profiles/r02_config4_fft.jsonl),
-// 4 is fastest at N=2048 (0.55-0.64 of 8 TB/s vs 0.40-0.56) and within 4 % of the best at N=1024
+template <typename TIN, int LOGN, bool PACK, int WAVES>
+int launch_ifft_w(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
+    const size_t bytes = (size_t)batch * (1u << LOGN) * (sizeof(TIN) + sizeof(double));
+    // (the key-conversion form writes a table that the next kernel reads: never streamed past the cache)
+    if (!PACK && bytes > STREAMING_WORKING_SET) return launch_ifft_nt<TIN, LOGN, PACK, WAVES, true>(c, out_d, in_d, batch);
+    return launch_ifft_nt<TIN, LOGN, PACK, WAVES, false>(c, out_d, in_d, batch);
+}
+// 4 waves (= polynomials) per workgroup: measured against 8 and 12 on MI355X, in the non-persistent form in round 2
+// (profiles/r02_config4_fft.jsonl) and in the persistent form in round 3 (profiles/r03_config4_ab.txt: 8 equal within
+// noise at N=2048, 12 slower by up to 40 % on the Lagrange -> coefficient side)
 constexpr int FFT_WAVES = 4;
 template <typename TIN, int LOGN, bool PACK = false>
 int launch_ifft_t(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
     return launch_ifft_w<TIN, LOGN, PACK, FFT_WAVES>(c, out_d, in_d, batch);
 }
-template <typename TOUT, int LOGN, int WAVES>
-int launch_fft_w(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
+template <typename TOUT, int LOGN, int WAVES, bool NT>
+int launch_fft_nt(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
     using Lds = FftLds<LOGN, WAVES>;
-    auto kernel = k_fft_batch<TOUT, LOGN, WAVES>;
+    auto kernel = k_fft_batch<TOUT, LOGN, WAVES, NT>;
     if (int rc = set_lds(c, kernel, Lds::total)) return rc;
     int grid = 0;
     if (int rc = persistent_grid(c, kernel, WAVES * 64, Lds::total, (batch + WAVES - 1) / WAVES, &grid)) return rc;
-    TFHE_LAUNCH((k_fft_batch<TOUT, LOGN, WAVES>), dim3(grid), dim3(WAVES * 64), Lds::total,
+    TFHE_LAUNCH((k_fft_batch<TOUT, LOGN, WAVES, NT>), dim3(grid), dim3(WAVES * 64), Lds::total,
                 c->stream, out_d, in_d, (const double2 *)c->tw_d, batch);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
+}
+template <typename TOUT, int LOGN, int WAVES>
+int launch_fft_w(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
+    const size_t bytes = (size_t)batch * (1u << LOGN) * (sizeof(TOUT) + sizeof(double));
+    // nontemporal stores: +17..20 % at N = 1024, +4 % at N = 2048 / Torus64, -6 % at N = 2048 / Torus32 (r03_config4_ab.txt)
+    if (bytes > STREAMING_WORKING_SET && !(LOGN == 11 && sizeof(TOUT) == 4))
+        return launch_fft_nt<TOUT, LOGN, WAVES, true>(c, out_d, in_d, batch);
+    return launch_fft_nt<TOUT, LOGN, WAVES, false>(c, out_d, in_d, batch);
 }
 template <typename TOUT, int LOGN>
 int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
@@ -524,7 +533,6 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->ksm_d = nullptr;
     c->ks_force_gather = 0;
     c->br_split_max = -1;
-    c->br_team = 1;
     c->streamed_graph = false;
     c->streamed_warm = 0;
     memset(&c->sg, 0, sizeof(c->sg));
@@ -614,9 +622,6 @@ int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_STREAMED_GRAPH:
             c->streamed_graph = value != 0;
-            return TFHE_AMD_OK;
-        case TFHE_AMD_OPT_BR_TEAM:
-            c->br_team = value;  // 0: one wave per ciphertext; 2: two teams per workgroup; else four
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_BR_SPLIT:
             c->br_split_max = value;

@@ -1439,497 +1439,23 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_blind_rotate_split(BlindRotateArgs<
     }
 }
 
-// ------------------------------------------- two waves per ciphertext: the Torus64 / N = 2048 blind rotation
-// The circuit bootstrap's blind rotation (poc:580-642: n0 = 500 CMux steps at N2 = 2048, l2 = 4, Torus64) with ONE
-// wave per ciphertext needs 32 registers per lane for the accumulator polynomials alone times four (accumulator
-// 128, Fourier accumulator 128, transform 64, key half-row 64, rotated coefficients 64): it runs one wave per SIMD
-// with a quarter of its vector instructions shuffling values between the two halves of the register file
-// (k_blind_rotate<int64_t, 11, 4, 1>: 1.74 vector instructions per fp64 instruction, profiles/r03_cb_pmc.txt).
-// Here a TEAM of two waves (128 lanes) owns the ciphertext: every per-lane array halves (8 complex points per lane
-// instead of 16), everything fits 256 registers, and two teams' waves share each SIMD (8 waves per CU).
-// Only the transforms notice the second wave: 1024 complex points over 128 lanes x 8 registers are 10 radix-2 stages in
-// FOUR register passes (index bits 9..7 | 6..4 | 3 | 2..0) with three transposes through the team's LDS buffer, each
-// bracketed by two workgroup barriers (write-after-read, read-after-write).  A workgroup is two teams (256 threads)
-// sharing one 32 KB twiddle table: 68 KB of LDS, two workgroups per CU.  The butterflies, their order and their
-// operands are those of WaveFFT (= the reference's): results are bit-identical to k_blind_rotate.
-struct TeamGeom {  // N = 2048
-    static constexpr int LOGN = 11, N = 2048, NC = 1024, PPL = 8, LANES = 128;
-    static constexpr int XCH = 1152;  // complex points in the padded transpose buffer (18,432 B)
-    static constexpr int TW = 2 * NC;
-    TFHE_HOST_DEVICE static constexpr int tw_base(int h) { return 2 * NC - 2 * h; }
-    // team lane T, register m -> point index in the four passes
-    TFHE_HOST_DEVICE static int jA(int T, int m) { return T + 128 * m; }                              // registers = bits 9..7
-    TFHE_HOST_DEVICE static int jB(int T, int m) { return ((T >> 4) << 7) + (m << 4) + (T & 15); }    // bits 6..4
-    TFHE_HOST_DEVICE static int jC(int T, int m) { return ((T >> 1) << 4) + (m << 1) + (T & 1); }     // bits 3..1
-    TFHE_HOST_DEVICE static int jD(int T, int m) { return 8 * T + m; }                                // bits 2..0
-    // padded LDS index (16-byte units) of point j for the three transposes; every ds_write_b128 (8 contiguous lanes
-    // over 32 banks) and ds_read_b128 (the four 16-lane groups of MI355X_MICROARCH.md over 64 banks) of both directions
-    // is conflict-free (tools/lds_conflicts.py, "team")
-    TFHE_HOST_DEVICE static int idx1(int j) { return j; }                  // A <-> B
-    TFHE_HOST_DEVICE static int idx2(int j) { return j + 2 * (j >> 4); }   // B <-> C
-    TFHE_HOST_DEVICE static int idx3(int j) { return j + (j >> 3); }       // C <-> D
-    // the same index as (lane part) + (compile-time register part)
-    enum Map { A1 = 0, B1 = 1, B2 = 2, C2 = 3, C3 = 4, D3 = 5 };
-    TFHE_HOST_DEVICE static int lane_part(int map, int T) {
-        return map == A1 ? T
-             : map == B1 ? ((T >> 4) << 7) + (T & 15)
-             : map == B2 ? 144 * (T >> 4) + (T & 15)
-             : map == D3 ? 9 * T
-                         : 18 * (T >> 1) + (T & 1);  // C2 and C3
-    }
-    TFHE_HOST_DEVICE static constexpr int roff(int map, int m) {
-        return map == A1 ? 128 * m : map == B1 ? 16 * m : map == B2 ? 18 * m : map == C2 ? 2 * m : map == C3 ? 2 * m + (m >> 2) : m;
-    }
-};
-
-// the workgroup barrier between the two waves of a team (and, as a workgroup holds two teams that run the same
-// program on different ciphertexts, between the teams: every wave passes every barrier exactly once)
-#define TFHE_TEAM_BARRIER() __syncthreads()
-
-struct TeamFFT {
-    using G = TeamGeom;
-    static constexpr int PPL = G::PPL;
-    struct Xch {
-        double2 *buf;
-        int lane[6];
-    };
-    TFHE_DEVICE static Xch make_xch(double2 *buf, int T) {
-        Xch x;
-        x.buf = buf;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            x.lane[k] = G::lane_part(k, T);
-            TFHE_OPAQUE(x.lane[k]);
-        }
-        return x;
-    }
-    struct Tw {  // twiddles from the workgroup's LDS copy; the stride-4 stage's four are wave-uniform (scalar registers)
-        const double2 *tw;
-        int T;
-        double2 c4[4];
-        TFHE_DEVICE void load_uniform(const double2 *global_table) {
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                c4[m].x = tfhe_uniform_load_f64(reinterpret_cast<const double *>(global_table + G::tw_base(4) + m), 0);
-                c4[m].y = tfhe_uniform_load_f64(reinterpret_cast<const double *>(global_table + G::tw_base(4) + m), 1);
-            }
-        }
-        TFHE_DEVICE double2 twist(int m) const { return tw[G::jA(T, m)]; }
-        TFHE_DEVICE double2 passA(int s, int m) const { return tw[G::tw_base(128 * s) + T + 128 * (m & (s - 1))]; }
-        TFHE_DEVICE double2 passB(int s, int m) const { return tw[G::tw_base(16 * s) + ((m & (s - 1)) << 4) + (T & 15)]; }
-        TFHE_DEVICE double2 passC(int m) const { return tw[G::tw_base(8) + 2 * (m & 3) + (T & 1)]; }
-        TFHE_DEVICE double2 passD(int m) const { return c4[m & 3]; }
-    };
-    // team-wide transpose of one polynomial's complex points through LDS: write with map WMAP, read with map RMAP
-    template <int WMAP, int RMAP>
-    TFHE_DEVICE static void transpose(double (&xr)[PPL], double (&xi)[PPL], const Xch &X) {
-        double2 *w = X.buf + X.lane[WMAP], *r = X.buf + X.lane[RMAP];
-        TFHE_TEAM_BARRIER();  // the partner wave has finished reading what the buffer held
-#pragma unroll
-        for (int m = 0; m < PPL; m++) w[G::roff(WMAP, m)] = make_double2(xr[m], xi[m]);
-        TFHE_TEAM_BARRIER();
-#pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            const double2 v = r[G::roff(RMAP, m)];
-            xr[m] = v.x;
-            xi[m] = v.y;
-        }
-    }
-    // coefficient -> Lagrange.  In: team lane T register m = point jA(T,m).  Out: register m = position jD(T,m) = 8T + m.
-    TFHE_DEVICE static void ifft(double (&xr)[PPL], double (&xi)[PPL], const Tw &tw, const Xch &X, int T) {
-#pragma unroll
-        for (int m = 0; m < PPL; m++) {  // twist by omega^j (spqlios-ifft-fma.s:63-78)
-            const double2 w = tw.twist(m);
-            const double r = xr[m], i = xi[m];
-            xr[m] = __builtin_fma(-i, w.y, r * w.x);
-            xi[m] = __builtin_fma(i, w.x, r * w.y);
-        }
-#pragma unroll
-        for (int s = PPL / 2; s >= 1; s >>= 1)  // pass A: half-sizes 512, 256, 128
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                if (m & s) continue;
-                const double2 w = tw.passA(s, m);
-                dif_bfly(xr[m], xi[m], xr[m + s], xi[m + s], w.x, w.y);
-            }
-        transpose<G::A1, G::B1>(xr, xi, X);
-#pragma unroll
-        for (int s = PPL / 2; s >= 1; s >>= 1)  // pass B: half-sizes 64, 32, 16
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                if (m & s) continue;
-                const double2 w = tw.passB(s, m);
-                dif_bfly(xr[m], xi[m], xr[m + s], xi[m + s], w.x, w.y);
-            }
-        transpose<G::B2, G::C2>(xr, xi, X);
-#pragma unroll
-        for (int m = 0; m < 4; m++) {  // pass C: half-size 8
-            const double2 w = tw.passC(m);
-            dif_bfly(xr[m], xi[m], xr[m + 4], xi[m + 4], w.x, w.y);
-        }
-        transpose<G::C3, G::D3>(xr, xi, X);
-#pragma unroll
-        for (int m = 0; m < 4; m++) {  // pass D: half-size 4, then the size-4 and size-2 steps
-            const double2 w = tw.passD(m);
-            dif_bfly(xr[m], xi[m], xr[m + 4], xi[m + 4], w.x, w.y);
-        }
-#pragma unroll
-        for (int b = 0; b < PPL; b += 4) {  // spqlios-ifft-fma.s:194-213
-            const double r0 = xr[b], r1 = xr[b + 1], r2 = xr[b + 2], r3 = xr[b + 3];
-            const double i0 = xi[b], i1 = xi[b + 1], i2 = xi[b + 2], i3 = xi[b + 3];
-            xr[b] = r0 + r2;
-            xr[b + 1] = r1 + r3;
-            xr[b + 2] = r0 - r2;
-            xr[b + 3] = i3 - i1;
-            xi[b] = i0 + i2;
-            xi[b + 1] = i1 + i3;
-            xi[b + 2] = i0 - i2;
-            xi[b + 3] = r1 - r3;
-        }
-#pragma unroll
-        for (int b = 0; b < PPL; b += 2) {  // :247-263
-            const double r0 = xr[b], r1 = xr[b + 1], i0 = xi[b], i1 = xi[b + 1];
-            xr[b] = r0 + r1;
-            xr[b + 1] = r0 - r1;
-            xi[b] = i0 + i1;
-            xi[b + 1] = i0 - i1;
-        }
-    }
-    // Lagrange -> coefficient for NP polynomials (the key rows carry the 2/N scale).  In: register m = position
-    // jD(T,m).  Out: register m = point jA(T,m).  The polynomials share every twiddle read; each goes through the
-    // team's buffer on its own.
-    template <int NP>
-    TFHE_DEVICE static void fft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const Tw &tw, const Xch &X, int T) {
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-#pragma unroll
-            for (int b = 0; b < PPL; b += 2) {  // spqlios-fft-fma.s:79-95
-                const double r0 = xr[p][b], r1 = xr[p][b + 1], i0 = xi[p][b], i1 = xi[p][b + 1];
-                xr[p][b] = r0 + r1;
-                xr[p][b + 1] = r0 - r1;
-                xi[p][b] = i0 + i1;
-                xi[p][b + 1] = i0 - i1;
-            }
-#pragma unroll
-            for (int b = 0; b < PPL; b += 4) {  // :134-152
-                const double r0 = xr[p][b], r1 = xr[p][b + 1], r2 = xr[p][b + 2], r3 = xr[p][b + 3];
-                const double i0 = xi[p][b], i1 = xi[p][b + 1], i2 = xi[p][b + 2], i3 = xi[p][b + 3];
-                xr[p][b] = r0 + r2;
-                xr[p][b + 1] = r1 + i3;
-                xr[p][b + 2] = r0 - r2;
-                xr[p][b + 3] = r1 - i3;
-                xi[p][b] = i0 + i2;
-                xi[p][b + 1] = i1 - r3;
-                xi[p][b + 2] = i0 - i2;
-                xi[p][b + 3] = i1 + r3;
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < 4; m++) {  // pass D: half-size 4 (quarter turn at offset 2, see flip_sign_if)
-            const double2 w = tw.passD(m);
-            const double wc = (m & 3) == 2 ? -w.x : w.x;
-#pragma unroll
-            for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + 4], xi[p][m + 4], wc, w.y);
-        }
-#pragma unroll
-        for (int p = 0; p < NP; p++) transpose<G::D3, G::C3>(xr[p], xi[p], X);
-#pragma unroll
-        for (int m = 0; m < 4; m++) {  // pass C: half-size 8, offset 2 (m & 3) + (T & 1); quarter turn at offset 4
-            const double2 w = tw.passC(m);
-            const double wc = (m & 3) == 2 ? flip_sign_if(w.x, (T & 1) == 0) : w.x;
-#pragma unroll
-            for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + 4], xi[p][m + 4], wc, w.y);
-        }
-#pragma unroll
-        for (int p = 0; p < NP; p++) transpose<G::C2, G::B2>(xr[p], xi[p], X);
-        const int c = T & 15;
-#pragma unroll
-        for (int s = 1; s <= PPL / 2; s <<= 1)  // pass B: half-sizes 16, 32, 64; quarter turn at offset 8 s
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                if (m & s) continue;
-                const double2 w = tw.passB(s, m);
-                const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
-                const bool lq = (s == 1) ? (c == 8) : (c == 0);
-                const double wc = mq ? flip_sign_if(w.x, lq) : w.x;
-#pragma unroll
-                for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], wc, w.y);
-            }
-#pragma unroll
-        for (int p = 0; p < NP; p++) transpose<G::B1, G::A1>(xr[p], xi[p], X);
-#pragma unroll
-        for (int s = 1; s <= PPL / 2; s <<= 1)  // pass A: half-sizes 128, 256, 512; quarter turn at offset 64 s
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                if (m & s) continue;
-                const double2 w = tw.passA(s, m);
-                const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
-                const bool lq = (s == 1) ? (T == 64) : (T == 0);
-                const double wc = mq ? flip_sign_if(w.x, lq) : w.x;
-#pragma unroll
-                for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], wc, w.y);
-            }
-#pragma unroll
-        for (int m = 0; m < PPL; m++) {  // final twist by conj(omega^j), four rounded products (spqlios-fft-fma.s:255-274)
-            const double2 w = tw.twist(m);
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-                const double r = xr[p][m], i = xi[p][m];
-                const double rc = r * w.x, rs = r * w.y, ic = i * w.x, is = i * w.y;
-                xr[p][m] = rc + is;
-                xi[p][m] = ic - rs;
-            }
-        }
-    }
-};
-
-template <int TEAMS>
-struct TeamLds {
-    using G = TeamGeom;
-    static constexpr size_t tw_bytes = sizeof(double2) * G::TW;         // 32,768
-    static constexpr size_t xch_bytes = sizeof(double2) * G::XCH;       // 18,432: transposes, and the rotation / extraction scratch polynomial (16 KB)
-    static constexpr size_t xch_at(int team) { return tw_bytes + (size_t)team * xch_bytes; }
-    static constexpr size_t total = tw_bytes + TEAMS * xch_bytes;       // 2 teams: 69,632 B (two workgroups per CU); 4 teams: 106,496 B (one)
-};
-
-// Flags honoured: BR_INIT_TESTVEC (+ BR_TV_CONST, BR_TV_HALF; BR_MODSWITCH is a Torus32 matter), BR_EXTRACT; without
-// them the accumulator is loaded from / stored to acc_io.  Plain blind rotations only (the host keeps BR_NO_ROTATE,
-// BR_CMUX_DATA and per-sample keys on k_blind_rotate).
-// TEAMS ciphertexts per workgroup of 2 * TEAMS waves.  TEAMS = 4 (512 threads, one workgroup per CU): the two waves of a
-// team are waves k and k + 4, which the hardware places on the SAME SIMD (waves of a workgroup go round-robin over
-// the four SIMDs) -- a wave waiting at a team barrier then leaves its SIMD to the very wave it waits for.  TEAMS = 2
-// (256 threads, two workgroups per CU): partners on different SIMDs, each SIMD shared by waves of two workgroups.
-template <int TEAMS>
-TFHE_GLOBAL void __launch_bounds__(TEAMS * 128, 2) k_blind_rotate_team(BlindRotateArgs<int64_t> A) {
-    using T64 = int64_t;
-    using U = uint64_t;
-    using G = TeamGeom;
-    using L = TeamLds<TEAMS>;
-    constexpr int N = G::N, NC = G::NC, PPL = G::PPL;
-    TFHE_DYN_LDS(smem);
-    const int tid = (int)threadIdx.x;
-    const int wave = TFHE_UNIFORM(tid >> 6);
-    const int team = TEAMS == 4 ? (wave & 3) : (wave >> 1);
-    const int T = (TEAMS == 4 ? (wave >> 2) : (wave & 1)) * 64 + (tid & 63);
-    {
-        double2 *tw = reinterpret_cast<double2 *>(smem);
-        for (int i = tid; i < G::TW; i += TEAMS * 128) tw[i] = A.tw[i];
-    }
-    // the ciphertexts of the workgroup; where the batch leaves teams of the last workgroup without one, they repeat the
-    // last ciphertext's work (they must pass the same barriers) and store nothing
-    const int ct_raw = (int)blockIdx.x * TEAMS + team;
-    const bool live = ct_raw < A.batch;
-    const int ct = live ? ct_raw : A.batch - 1;
-    const int32_t *rot = A.rot + (size_t)ct * A.rot_stride;
-    const int32_t *rot_wg[TEAMS];  // every team's rotations: a step is skipped only when the whole workgroup skips it
-#pragma unroll
-    for (int k = 0; k < TEAMS; k++) {
-        const int c = (int)blockIdx.x * TEAMS + k;
-        rot_wg[k] = A.rot + (size_t)(c < A.batch ? c : A.batch - 1) * A.rot_stride;
-    }
-
-    TeamFFT::Xch xch = TeamFFT::make_xch(reinterpret_cast<double2 *>(smem + L::xch_at(team)), T);
-    U *scratch = reinterpret_cast<U *>(smem + L::xch_at(team));  // one polynomial: [N] torus values
-    TeamFFT::Tw tw;
-    tw.tw = reinterpret_cast<const double2 *>(smem);
-    tw.T = T;
-    tw.load_uniform(A.tw);
-
-    // accumulator in registers: accr[q][h][m] = coefficient T + 128 m + h N/2 of polynomial q
-    U accr[2][2][PPL];
-    if (A.flags & BR_INIT_TESTVEC) {
-        const int barb = rot[A.n_steps];
-        const int a0 = (2 * N - barb) & (2 * N - 1);  // lwe_functions.cpp:385-386
-        const T64 *tv = A.tv + (size_t)ct * A.tv_stride;
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                const int j = T + 128 * m + h * NC;
-                const int idx = (j - a0) & (2 * N - 1);
-                const int src = idx & (N - 1);
-                U v;
-                if (A.flags & BR_TV_CONST)
-                    v = (U)A.tv_const;
-                else if (A.flags & BR_TV_HALF)
-                    v = (src < N / 2) ? (U)(0 - (U)A.tv_const) : (U)A.tv_const;
-                else
-                    v = (U)tv[src];
-                accr[0][h][m] = 0;
-                accr[1][h][m] = (idx & N) ? (U)(0 - v) : v;
-            }
-    } else {
-        const T64 *src = A.acc_io + (size_t)ct * 2 * N;
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int m = 0; m < PPL; m++) accr[q][h][m] = (U)src[q * N + T + 128 * m + h * NC];
-    }
-    const U offset = (U)A.gd.offset, flip = (U)A.gd.flip;
-    const int l = A.gd.l, Bgbit = A.gd.Bgbit;
-    const uint32_t lane16 = (uint32_t)((T >> 1) * 16 + (T & 1) * (8 * 64 * 16));  // key layout [16][64] complex per half-row: position 8T + m
-    // (the table load above is ordered before the first twiddle read by the first team barrier of the loop / epilogue)
-
-#pragma unroll 1
-    for (int i = 0; i < A.n_steps; i++) {
-        const int a = TFHE_UNIFORM(tfhe_uniform_load32(rot, i));
-        int a_any = 0;
-#pragma unroll
-        for (int k = 0; k < TEAMS; k++) a_any |= TFHE_UNIFORM(tfhe_uniform_load32(rot_wg[k], i));
-        if (a_any == 0) continue;  // lwe_functions.cpp:348-350.  (a team whose own rotation is 0 still walks the step beside
-        // its neighbours -- same barriers: (X^0 - 1) acc = 0 decomposes into zero digits, the step adds exactly 0)
-        const TFHE_BUFFER_RSRC rsrc =
-            TFHE_MAKE_BUFFER_RSRC(reinterpret_cast<const unsigned char *>(A.bk + (size_t)i * A.bk_step_stride));
-        double fr[2][PPL], fi[2][PPL];  // Fourier accumulator (tLweFFTClear)
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int m = 0; m < PPL; m++) fr[q][m] = fi[q][m] = 0.0;
-#pragma unroll 1
-        for (int q = 0; q < 2; q++) {
-            // ---- (X^a - 1) * acc[q] + offset, digit-field tops flipped (numeric_functions.cpp:304-323), through the scratch
-            U lo[PPL], hi[PPL];
-            {
-                U own0[PPL], own1[PPL];
-#pragma unroll
-                for (int m = 0; m < PPL; m++) {
-                    own0[m] = q ? accr[1][0][m] : accr[0][0][m];
-                    own1[m] = q ? accr[1][1][m] : accr[0][1][m];
-                }
-                TFHE_TEAM_BARRIER();
-#pragma unroll
-                for (int m = 0; m < PPL; m++) {
-                    scratch[T + 128 * m] = own0[m];
-                    scratch[T + 128 * m + NC] = own1[m];
-                }
-                TFHE_TEAM_BARRIER();
-                int base = (T - a) & (2 * N - 1);
-                TFHE_OPAQUE(base);
-#pragma unroll
-                for (int m = 0; m < PPL; m++) {
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int idx = base + 128 * m + h * NC;
-                        const U src = scratch[idx & (N - 1)];
-                        const U rotv = (idx & N) ? (U)(0 - src) : src;
-                        const U v = ((rotv - (h ? own1[m] : own0[m])) + offset) ^ flip;
-                        if (h == 0)
-                            lo[m] = v;
-                        else
-                            hi[m] = v;
-                    }
-                }
-            }
-#pragma unroll 1
-            for (int d = 0; d < l; d++) {
-                const int row = q * l + d;  // p = bloc * l + i (tgsw_functions.cpp:435-443)
-                double2 bk[PPL];
-#define TFHE_BKT(qq, m) tfhe_buffer_load_d2(rsrc, lane16, (uint32_t)(((row * 2 + (qq)) * 16 + (m)) * 64) * 16u)
-#pragma unroll
-                for (int m = 0; m < PPL; m++) bk[m] = TFHE_BKT(0, m);
-                double xr[PPL], xi[PPL];
-                const int decal = 64 - (d + 1) * Bgbit;
-                // the field read as a signed Bgbit-bit number IS (field - Bg/2) (Gadget::flip): from the field's 32-bit
-                // word, or from a 32-bit window on both words where it straddles them (wave-uniform choice)
-                auto extract = [&](auto mode) {
-                    constexpr int MODE = decltype(mode)::value;
-#pragma unroll
-                    for (int m = 0; m < PPL; m++) {
-                        const uint64_t x0 = lo[m], x1 = hi[m];
-                        if (MODE == 0) {
-                            xr[m] = (double)TFHE_SBFE((uint32_t)(x0 >> 32), decal - 32, Bgbit);
-                            xi[m] = (double)TFHE_SBFE((uint32_t)(x1 >> 32), decal - 32, Bgbit);
-                        } else if (MODE == 1) {
-                            xr[m] = (double)TFHE_SBFE(TFHE_ALIGNBIT((uint32_t)(x0 >> 32), (uint32_t)x0, decal), 0, Bgbit);
-                            xi[m] = (double)TFHE_SBFE(TFHE_ALIGNBIT((uint32_t)(x1 >> 32), (uint32_t)x1, decal), 0, Bgbit);
-                        } else {
-                            xr[m] = (double)TFHE_SBFE((uint32_t)x0, decal, Bgbit);
-                            xi[m] = (double)TFHE_SBFE((uint32_t)x1, decal, Bgbit);
-                        }
-                    }
-                };
-                if (decal >= 32) {
-                    TFHE_KEEP_BRANCH();
-                    extract(std::integral_constant<int, 0>{});
-                } else if (decal + Bgbit > 32) {
-                    TFHE_KEEP_BRANCH();
-                    extract(std::integral_constant<int, 1>{});
-                } else {
-                    TFHE_KEEP_BRANCH();
-                    extract(std::integral_constant<int, 2>{});
-                }
-                TeamFFT::ifft(xr, xi, tw, xch, T);
-                mac_half_row<PPL, false>(fr[0], fi[0], xr, xi, bk);
-#pragma unroll
-                for (int m = 0; m < PPL; m++) bk[m] = TFHE_BKT(1, m);
-                mac_half_row<PPL, false>(fr[1], fi[1], xr, xi, bk);
-#undef TFHE_BKT
-            }
-        }
-        // ---- back to coefficients (both polynomials), round, acc += result (tLweFromFFTConvert + tLweAddTo)
-        TeamFFT::fft<2>(fr, fi, tw, xch, T);
-        U r0[2][PPL], r1[2][PPL];
-        uint32_t guard = 0;
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                r0[q][m] = (U)Torus<T64>::from_double_fast(fr[q][m], guard);
-                r1[q][m] = (U)Torus<T64>::from_double_fast(fi[q][m], guard);
-            }
-        if (TFHE_WAVE_ANY(!Torus<T64>::guard_ok(guard))) {  // |x| >= 2^83 somewhere: the reference's bit-field form
-            TFHE_KEEP_BRANCH();
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int m = 0; m < PPL; m++) {
-                    TFHE_OPAQUE(fr[q][m]);
-                    TFHE_OPAQUE(fi[q][m]);
-                    r0[q][m] = (U)Torus<T64>::from_double(fr[q][m]);
-                    r1[q][m] = (U)Torus<T64>::from_double(fi[q][m]);
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                accr[q][0][m] += r0[q][m];
-                accr[q][1][m] += r1[q][m];
-            }
-    }
-
-    // ---- output
-    if (A.flags & BR_EXTRACT) {  // tLweExtractLweSampleIndex, index 0 (tlwe_functions.cpp:351-363): lane needs coefficient N - j
-        TFHE_TEAM_BARRIER();
-#pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            scratch[T + 128 * m] = accr[0][0][m];
-            scratch[T + 128 * m + NC] = accr[0][1][m];
-        }
-        TFHE_TEAM_BARRIER();
-        if (live) {
-            T64 *out = A.lwe_out + (size_t)ct * (N + 1);
-#pragma unroll
-            for (int m = 0; m < 2 * PPL; m++) {
-                const int j = T + 128 * m;
-                out[j] = (j == 0) ? (T64)scratch[0] : (T64)(0 - scratch[N - j]);
-            }
-            if (T == 0) out[N] = (T64)(accr[1][0][0] + (U)A.out_b_add);
-        }
-    } else if (live) {
-        T64 *dst = A.acc_io + (size_t)ct * 2 * N;
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int m = 0; m < PPL; m++) dst[q * N + T + 128 * m + h * NC] = (T64)accr[q][h][m];
-    }
-}
-
 // ------------------------------------------- standalone batched transforms
+// NT: lane-contiguous accesses of data this launch touches once, when the launch's working set is larger than the
+// 256 MB Infinity Cache (the host decides: launch_ifft_w / launch_fft_w) -- nontemporal loads and stores.  Measured
+// (profiles/r03_config4_ab.txt): +5..11 % on the coefficient -> Lagrange kernels at 4 x the cache size, -9 % when the
+// working set fits the cache (repeated calls then hit it), and never on the strided 16-byte loads of k_fft_batch
+// (the eight loads of a line must meet in the cache: 0.34 instead of 0.64 of 8 TB/s with nt).
+template <bool NT, typename V>
+TFHE_DEVICE V stream_load(const V *p) {
+    return NT ? tfhe_nontemporal_load(p) : *p;
+}
+template <bool NT, typename V>
+TFHE_DEVICE void stream_store(V v, V *p) {
+    if (NT)
+        tfhe_nontemporal_store(v, p);
+    else
+        *p = v;
+}
 // FFT plugin boundary (CB/spqlios/lagrangehalfc_impl.h:8-31), one wave per polynomial.
 template <int LOGN, int WAVES>
 struct FftLds {
@@ -1948,7 +1474,7 @@ struct FftLds {
 // with stride gridDim.x * WAVES.  The twiddle table is staged once per workgroup instead of once per WAVES
 // polynomials (32 KB from L2 + a barrier in front of every 4 transforms at N = 2048), and a wave requests its
 // NEXT polynomial before it transforms the current one, so its HBM latency runs under the butterflies.
-template <typename TIN, int LOGN, int WAVES, bool PACK = false>
+template <typename TIN, int LOGN, int WAVES, bool PACK = false, bool NT = false>
 TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     k_ifft_batch(double *__restrict__ out, const TIN *__restrict__ in, const double2 *__restrict__ twg, int batch) {
     using G = Geom<LOGN>;
@@ -1966,8 +1492,8 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
         const TIN *p = in + (size_t)poly * N;
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
-            raw_r[m] = p[G::jA(t, m)];
-            raw_i[m] = p[G::jA(t, m) + NC];
+            raw_r[m] = stream_load<NT>(&p[G::jA(t, m)]);
+            raw_i[m] = stream_load<NT>(&p[G::jA(t, m) + NC]);
         }
     };
     if (b < batch) request(b);
@@ -1999,20 +1525,22 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
         // The reference's order has lane t holding PPL CONSECUTIVE outputs (jC): stored from there, every
         // store instruction would touch 64 different 128-byte lines.  One more pass through the wave's LDS
         // buffer turns it into the lane-contiguous order jA, 512 contiguous bytes per store instruction.
+        // (Measured: 16-byte stores straight from the jC order reach 0.44-0.53 of 8 TB/s against 0.62-0.67 with
+        // the LDS pass -- partial-line writes; profiles/r03_config4_ab.txt.  LOADS in that order are fine: k_fft_batch.)
         WaveFFT<LOGN>::template transpose<G::RD_C2, G::RD_A2>(xr[0], xch);
         WaveFFT<LOGN>::template transpose<G::RD_C2, G::RD_A2>(xi[0], xch);
         double *o = out + (size_t)b * N;
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
-            o[G::jA(t, m)] = xr[0][m];
-            o[G::jA(t, m) + NC] = xi[0][m];
+            stream_store<NT>(xr[0][m], &o[G::jA(t, m)]);
+            stream_store<NT>(xi[0][m], &o[G::jA(t, m) + NC]);
         }
     }
 }
 
 // execute_direct_torus32 / _torus64: LagrangeHalfC -> torus coefficients (scale 2/N first); persistent waves
 // with the next polynomial requested ahead, as k_ifft_batch
-template <typename TOUT, int LOGN, int WAVES>
+template <typename TOUT, int LOGN, int WAVES, bool NT = false>
 TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     k_fft_batch(TOUT *__restrict__ out, const double *__restrict__ in, const double2 *__restrict__ twg, int batch) {
     using G = Geom<LOGN>;
@@ -2024,14 +1552,20 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     const int stride = TFHE_UNIFORM((int)(gridDim.x * WAVES));
     int b = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
     const double scale = 2.0 / (double)N;  // fft_processor_spqlios.cpp:78
-    // loads in the lane-contiguous order jA: 512 contiguous bytes per instruction
     double raw_r[PPL], raw_i[PPL];
+    // Loads straight in the transform's input order (lane t holds the PPL consecutive points jC = PPL t + m of each
+    // half): 16-byte loads, 64 lines per instruction but every line read whole by the PPL / 2 instructions of the
+    // half -- the L1/L2 merge them.  Measured against lane-contiguous loads + one more pass through LDS: +1..6 %
+    // (profiles/r03_config4_ab.txt); the same access pattern on the STORE side of k_ifft_batch loses 25 %.
     auto request = [&](int poly) {
-        const double *p = in + (size_t)poly * N;
+        const double2 *p2 = reinterpret_cast<const double2 *>(in + (size_t)poly * N);
 #pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            raw_r[m] = p[G::jA(t, m)];
-            raw_i[m] = p[G::jA(t, m) + NC];
+        for (int m = 0; m < PPL; m += 2) {
+            const double2 a = p2[(PPL * t + m) / 2], c = p2[(NC + PPL * t + m) / 2];
+            raw_r[m] = a.x;
+            raw_r[m + 1] = a.y;
+            raw_i[m] = c.x;
+            raw_i[m + 1] = c.y;
         }
     };
     if (b < batch) request(b);
@@ -2052,9 +1586,6 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
             xi[0][m] = raw_i[m] * scale;
         }
         if (b + stride < batch) request(b + stride);
-        // into the transform's input order (lane t holds the PPL consecutive points jC) through LDS
-        WaveFFT<LOGN>::template transpose<G::RD_A2, G::RD_C2>(xr[0], xch);
-        WaveFFT<LOGN>::template transpose<G::RD_A2, G::RD_C2>(xi[0], xch);
         WaveFFT<LOGN>::template fft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
         // rounding: the short exact sequences of the blind-rotation kernels (Torus<T>::from_double_fast), the
         // reference's own form where the wave's guard trips (|x| >= 2^51 resp. 2^83)
@@ -2078,8 +1609,8 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
         }
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
-            o[G::jA(t, m)] = r0[m];
-            o[G::jA(t, m) + NC] = r1[m];
+            stream_store<NT>(r0[m], &o[G::jA(t, m)]);
+            stream_store<NT>(r1[m], &o[G::jA(t, m) + NC]);
         }
     }
 }

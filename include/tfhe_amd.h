@@ -87,10 +87,8 @@ int tfhe_amd_sync(tfhe_amd_ctx *ctx);
  *        largest batch that runs on the latency-shaped kernel (one ciphertext per 4-wave workgroup, the 2l inverse
  *        transforms of a CMux on the four SIMDs of a CU at once; what a one-sample call of tfhe_bootstrap_FFT,
  *        lwe_functions.cpp:434-446, gets), larger batches run one wave per ciphertext.  < 0 (default): the
- *        measured crossover; 0: never
- *   TFHE_AMD_OPT_BR_TEAM   != 0 (default): Torus64 / N = 2048 blind rotations (circuitBootstrapWoKS, poc:530-659) run
- *        two waves per ciphertext (k_blind_rotate_team); 0: one wave per ciphertext */
-enum { TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_STREAMED_GRAPH = 4, TFHE_AMD_OPT_BR_SPLIT = 5, TFHE_AMD_OPT_BR_TEAM = 6 };
+ *        measured crossover; 0: never */
+enum { TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_STREAMED_GRAPH = 4, TFHE_AMD_OPT_BR_SPLIT = 5 };
 int tfhe_amd_set_option(tfhe_amd_ctx *ctx, int option, int value);
 /* HIP events on the context's stream, for timing kernels without a HIP binding in the host
  * language: create, record (asynchronous), elapsed milliseconds between two recorded events

@@ -77,6 +77,10 @@ static inline int32_t tfhe_uniform_load32(const int32_t *p, int idx) { return p[
 static inline uint32_t tfhe_lds_peek32(uint32_t off) { return *(volatile const uint32_t *)(emu::dyn_smem() + off); }
 static inline void tfhe_lds_poke32(uint32_t off, uint32_t v) { *(volatile uint32_t *)(emu::dyn_smem() + off) = v; }
 static inline double tfhe_uniform_load_f64(const double *p, int idx) { return p[idx]; }
+template <typename V>
+static inline V tfhe_nontemporal_load(const V *p) { return *p; }
+template <typename V>
+static inline void tfhe_nontemporal_store(V v, V *p) { *p = v; }
 #define TFHE_TRAP() abort()
 namespace emu {
 typedef int v4i_t __attribute__((vector_size(16)));

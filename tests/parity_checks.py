@@ -176,17 +176,13 @@ def check_gate_path(lib_path, N, n, l, Bgbit, ks_t, ks_bb, B, seed=21, check_exp
 
 
 # ------------------------------------------------------------ Torus64 path
-def check_torus64_path(lib_path, N, n, l, Bgbit, B, seed=31, br_team=None):
-    """br_team: None = the library's default blind-rotation kernel for this shape; 1 / 0 = two waves per ciphertext
-    (k_blind_rotate_team, N = 2048 only) / one wave per ciphertext (k_blind_rotate)"""
+def check_torus64_path(lib_path, N, n, l, Bgbit, B, seed=31):
     rs = np.random.RandomState(seed)
     key0 = O.keygen_binary(n, SEED, 11)
     tkey = O.keygen_binary(N, SEED, 12)
     bk = O.bk_create64(N, key0, tkey, l, Bgbit, 2.0 ** -44, SEED, 2000)
     e = T.Engine(torus_bits=64, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=0, lib_path=lib_path)
     try:
-        if br_team is not None:
-            e.set_option(T.OPT_BR_TEAM, br_team)
         bkt = T.keygen_bk_torus(64, key0, tkey, l, Bgbit, 2.0 ** -44, SEED, 2000, lib_path=lib_path)
         g = e.gsw_from_torus(bkt)
         assert same_doubles(e.gsw_export_fft(g, n - 1), bk[n - 1]), "Torus64 bk conversion"
@@ -197,8 +193,8 @@ def check_torus64_path(lib_path, N, n, l, Bgbit, B, seed=31, br_team=None):
         bara = rs.randint(0, 2 * N, size=(B, n)).astype(np.int32)
         bara[0, 0] = 0
         bara[:, n // 2] = 0          # a step every sample skips
-        bara[B - 1, n - 1] = 0       # and skipped steps at both ends of the batch (the team kernel walks such a
-        bara[0, n - 1] = N           # step beside its workgroup neighbour and must add exactly nothing)
+        bara[B - 1, n - 1] = 0       # skipped steps at both ends of the batch
+        bara[0, n - 1] = N
         want = np.stack([O.blind_rotate64(N, acc[b], bk, bara[b], l, Bgbit) for b in range(B)]).reshape(B, 2, N)
         assert np.array_equal(e.blind_rotate(acc, bara), want), "Torus64 blind rotation"
         abar = rs.randint(0, 2 * N, size=(B, n + 1)).astype(np.int32)

@@ -105,14 +105,6 @@ def test_torus64_path_emu(emu_lib, N, l, Bgbit, B):
     P.check_torus64_path(emu_lib, N=N, n=3, l=l, Bgbit=Bgbit, B=B)
 
 
-@pytest.mark.parametrize("B,l,Bgbit", [(1, 4, 9), (4, 4, 9), (5, 3, 7), (2, 1, 12)])
-def test_torus64_n2048_both_blind_rotation_kernels_emu(emu_lib, B, l, Bgbit):
-    """two waves per ciphertext (k_blind_rotate_team: four-pass team transforms, an odd batch leaves a workgroup's
-    second team without a ciphertext of its own) and one wave per ciphertext, same inputs, both against the oracle"""
-    P.check_torus64_path(emu_lib, N=2048, n=4, l=l, Bgbit=Bgbit, B=B, seed=50 + B, br_team=1)
-    P.check_torus64_path(emu_lib, N=2048, n=4, l=l, Bgbit=Bgbit, B=B, seed=50 + B, br_team=0)
-
-
 def test_abi_edges_emu(emu_lib):
     """empty batches, calls in the wrong state, bad arguments (status codes of include/tfhe_amd.h)"""
     P.check_abi_edges(emu_lib)

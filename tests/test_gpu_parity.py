@@ -105,18 +105,14 @@ def test_torus64_path(gpu_lib, N, n, l, Bgbit, B):
 
 
 def test_circuit_bootstrap_blind_rotation_full(gpu_lib):
-    """PoC parameter block (poc:70-85): n0=500, N2=2048, l2=4, Bgbit2=9, Torus64 -- on both blind-rotation kernels
-    (two waves per ciphertext = the default, one wave per ciphertext)"""
+    """PoC parameter block (poc:70-85): n0=500, N2=2048, l2=4, Bgbit2=9, Torus64"""
     P.check_torus64_path(gpu_lib, N=2048, n=500, l=4, Bgbit=9, B=4, seed=41)
-    P.check_torus64_path(gpu_lib, N=2048, n=500, l=4, Bgbit=9, B=3, seed=42, br_team=0)
 
 
-@pytest.mark.parametrize("B,l,Bgbit,n", [(1, 4, 9, 9), (7, 4, 9, 6), (33, 4, 9, 5), (6, 3, 7, 8), (5, 1, 12, 8), (2, 8, 4, 3)])
-def test_torus64_n2048_team_kernel(gpu_lib, B, l, Bgbit, n):
-    """k_blind_rotate_team (two waves per ciphertext, two ciphertexts per workgroup): odd and even batches, several
-    workgroups, gadget lengths 1..8, digits in the high word, the low word and across both"""
-    P.check_torus64_path(gpu_lib, N=2048, n=n, l=l, Bgbit=Bgbit, B=B, seed=200 + B, br_team=1)
-    P.check_torus64_path(gpu_lib, N=2048, n=n, l=l, Bgbit=Bgbit, B=B, seed=200 + B, br_team=0)
+@pytest.mark.parametrize("B,l,Bgbit,n", [(1, 4, 9, 9), (7, 4, 9, 6), (6, 3, 7, 8), (5, 1, 12, 8), (2, 8, 4, 3)])
+def test_torus64_n2048_gadget_shapes(gpu_lib, B, l, Bgbit, n):
+    """gadget lengths 1..8 on Torus64 / N = 2048: digits in the high word, the low word and across both; skipped steps"""
+    P.check_torus64_path(gpu_lib, N=2048, n=n, l=l, Bgbit=Bgbit, B=B, seed=200 + B)
 
 
 def test_cmux_on_data(gpu_lib):
@@ -308,6 +304,32 @@ def test_n2048_transform_batch_8192(gpu_lib):
         # Torus64 round trip keeps the top 53-ish bits (execute_reverse_torus64 drops 11)
         err = (t64 - a64).astype(np.int64)
         assert np.abs(err).max() < 2 ** 14
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("N,B", [(1024, 40000), (2048, 12000)])
+def test_transform_batches_beyond_the_cache(gpu_lib, N, B):
+    """launches whose working set exceeds the 256 MB Infinity Cache take the nontemporal variants of the transform
+    kernels (lane-contiguous loads / stores with the nt policy): same bits.  Round trip on the whole batch, the oracle
+    on a subset, both torus widths."""
+    rs = np.random.RandomState(N + B)
+    e = T.Engine(torus_bits=64, n=1, N=N, l=4, Bgbit=9, ks_t=0, lib_path=gpu_lib)
+    try:
+        sub = rs.choice(B, 12, replace=False)
+        a64 = np.frombuffer(rs.bytes(B * N * 8), dtype=np.int64).reshape(B, N)
+        l64 = e.ifft_torus64(a64)                                  # B * N * 16 bytes: 655 MB / 393 MB
+        assert P.same_doubles(l64[sub], O.execute_reverse_torus64(N, a64[sub])), "execute_reverse_torus64"
+        t64 = e.fft_torus64(l64)
+        assert np.array_equal(t64[sub], O.execute_direct_torus64(N, l64[sub])), "execute_direct_torus64"
+        assert np.abs((t64 - a64).astype(np.int64)).max() < 2 ** 14
+        del a64, t64
+        dig = rs.randint(-512, 512, size=(B, N)).astype(np.int32)
+        lag = e.ifft_int32(dig)                                    # B * N * 12 bytes: 491 MB / 295 MB
+        assert P.same_doubles(lag[sub], O.execute_reverse_int(N, dig[sub])), "execute_reverse_int"
+        t32 = e.fft_torus32(lag)
+        assert np.array_equal(t32[sub], O.execute_direct_torus32(N, lag[sub])), "execute_direct_torus32"
+        assert np.abs(t32.astype(np.int64) - dig).max() <= 1
     finally:
         e.close()
 

@@ -3,7 +3,7 @@
 N2 = 2048, l2 = 4, Bgbit2 = 9) on a synthetic key, for timing and profiling (run ON THE GPU BOX, directly after
 `rocprofv3 ... --`):
 
-    python3 tools/cb_br_once.py --batch 1024 --team 1 --reps 3 [--lib other.so]
+    python3 tools/cb_br_once.py --batch 1024 --reps 3 [--lib other.so]
 
 No child processes, no torch.  Prints HIP-event times per call and CMux/s."""
 import argparse
@@ -22,7 +22,6 @@ FP64_INSTR_PER_CMUX = 8064  # wave64 fp64 instructions per Torus64 / N = 2048 / 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--team", type=int, default=1, help="1: k_blind_rotate_team (two waves per ciphertext), 0: k_blind_rotate")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--n0", type=int, default=500)
     ap.add_argument("--lib", default=None)
@@ -33,7 +32,6 @@ def main():
     eng = T.Engine(torus_bits=64, n=n0, N=N2, l=l2, Bgbit=bg2, ks_t=0, lib_path=a.lib)
     bk = np.frombuffer(rs.bytes(n0 * 2 * l2 * 2 * N2 * 8), dtype=np.int64).reshape(n0, 2 * l2, 2, N2)
     eng.set_bootstrap_key(eng.gsw_from_torus(bk))  # tGswToFFTConvert on the GPU
-    eng.set_option(T.OPT_BR_TEAM, a.team)
     abar = rs.randint(0, 2 * N2, size=(a.batch, n0 + 1)).astype(np.int32)
     d_abar = eng.to_device(abar)
     d_out = eng.alloc(a.batch * (N2 + 1) * 8)
@@ -47,7 +45,7 @@ def main():
         ts.append(eng.elapsed_ms(e0, e1))
     best = min(ts[1:])
     cmux = a.batch * n0 / (best * 1e-3)
-    print(json.dumps({"workload": f"circuitBootstrapWoKS n0={n0} N2=2048 l2=4 Bgbit2=9 batch {a.batch}", "team": a.team, "ms": ts[1:],
+    print(json.dumps({"workload": f"circuitBootstrapWoKS n0={n0} N2=2048 l2=4 Bgbit2=9 batch {a.batch}", "ms": ts[1:],
                       "cmux_per_s": cmux,
                       "fp64_issue_frac": cmux * FP64_INSTR_PER_CMUX * 4 / (1024 * 2.4e9)}))
     eng.close()

@@ -78,25 +78,6 @@ def main():
             if logn == 10:  # the layout the N=1024 kernel uses
                 ok &= (ww == 1 and rr == 1)
             print(f"N={1 << logn:5d} {name:12s} complex points: ds_write_b128 x{ww} ds_read_b128 x{rr}")
-    # the team transforms of k_blind_rotate_team (tfhe_kernels.h TeamGeom): 128 lanes = 2 waves x 8 complex points,
-    # three transposes, each checked per wave in both directions
-    jA = lambda T, m: T + 128 * m
-    jB = lambda T, m: ((T >> 4) << 7) + (m << 4) + (T & 15)
-    jC = lambda T, m: ((T >> 1) << 4) + (m << 1) + (T & 1)
-    jD = lambda T, m: 8 * T + m
-    idx1 = lambda j: j
-    idx2 = lambda j: j + 2 * (j >> 4)
-    idx3 = lambda j: j + (j >> 3)
-    for name, idx, ja, jb in [("team A<->B", idx1, jA, jB), ("team B<->C", idx2, jB, jC), ("team C<->D", idx3, jC, jD)]:
-        worst_w = worst_r = 1
-        for jw, jr in ((ja, jb), (jb, ja)):
-            for wave in (0, 1):
-                worst_w = max(worst_w, max(worst128(lambda t: 16 * idx(jw(64 * wave + t, m)), W128, 32) for m in range(8)))
-                worst_r = max(worst_r, max(worst128(lambda t: 16 * idx(jr(64 * wave + t, m)), R128, 64) for m in range(8)))
-        pts = sorted(idx(ja(T, m)) for T in range(128) for m in range(8))
-        perm = pts == sorted(idx(jb(T, m)) for T in range(128) for m in range(8)) and len(set(pts)) == 1024 and max(pts) < 1152
-        ok &= (worst_w == 1 and worst_r == 1 and perm)
-        print(f"N= 2048 {name:12s} complex points: ds_write_b128 x{worst_w} ds_read_b128 x{worst_r} permutation={'ok' if perm else 'BAD'}")
     print("all conflict-free" if ok else "CONFLICTS / LAYOUT ERROR")
     return 0 if ok else 1
 
