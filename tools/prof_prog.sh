@@ -2,6 +2,8 @@
 # ONE purpose: one rocprofv3 pass over an arbitrary program of this repository (run ON THE GPU BOX):
 #   gpurun -- 'bash tools/prof_prog.sh r03 lat1_sq "--pmc SQ_WAVE_CYCLES SQ_WAIT_ANY" python3 tools/lat_once.py --batch 1'
 #   gpurun -- 'bash tools/prof_prog.sh r03 cb_trace "--kernel-trace --stats" python3 tools/bench_configs.py cb --reps 2'
+# PROF_TIMEOUT (seconds, default 600) bounds the pass.  TCC has 4 counter slots per pass: FETCH_SIZE takes 3, WRITE_SIZE 2 -- one of them per pass
+# (a request that does not fit aborts inside the first dispatch and the process then hangs until the timeout).
 # $3 = the profiler's mode flags (counters only, or trace only: never both); the program itself follows directly
 # after `--` (no shell hop between the profiler and the program).  Prints per-kernel counter means.
 set -u
@@ -11,7 +13,7 @@ R=$1; TAG=$2; MODE=$3; shift 3
 OUT=gpurun_out/prof_$R
 mkdir -p "$OUT"
 # shellcheck disable=SC2086
-timeout 600 rocprofv3 $MODE --output-format csv -d "$OUT/$TAG" -- "$@" > "$OUT/$TAG.out" 2> "$OUT/$TAG.err"
+timeout "${PROF_TIMEOUT:-600}" rocprofv3 $MODE --output-format csv -d "$OUT/$TAG" -- "$@" > "$OUT/$TAG.out" 2> "$OUT/$TAG.err"
 echo "rc=$?"
 find "$OUT/$TAG" -name '*.db' -delete 2>/dev/null
 python3 - "$OUT/$TAG" <<'PY'
