@@ -63,10 +63,11 @@ struct tfhe_amd_ctx {
 
 namespace {
 
-// Batches up to this size run the blind rotation on k_blind_rotate_split (one ciphertext per workgroup, one
-// workgroup per CU: 256 ciphertexts per round of ~2 ms); above it one wave per ciphertext (k_blind_rotate) has the
-// higher throughput.  Measured crossover: profiles/r03_latency.jsonl.
-constexpr int BR_SPLIT_AUTO_MAX = 512;
+// Batches up to this size run the blind rotation on k_blind_rotate_split (one ciphertext per 4-wave workgroup, two
+// workgroups per CU: 2.65 ms for up to 256 ciphertexts, 3.9 ms for up to 512, 7.2 ms for 1024); above it one wave per
+// ciphertext (k_blind_rotate: 7.7 ms up to 1024, 8.3 ms for 2048, 16.8 ms for 4096) has the higher throughput.
+// Measured crossover: profiles/r03_latency.jsonl.
+constexpr int BR_SPLIT_AUTO_MAX = 1024;
 
 int fail(tfhe_amd_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;

@@ -1206,9 +1206,14 @@ struct SplitLds {
     static constexpr size_t tw_bytes = sizeof(double2) * G::TW;
     static constexpr size_t xch_bytes = sizeof(double2) * G::XCH;      // complex-point transposes
     static constexpr size_t xch_at(int wave) { return tw_at + tw_bytes + (size_t)wave * xch_bytes; }
+    // hand-over buffer: the Lagrange-domain digits of waves 0 and 1 get 2 x 8 KB of their own (those waves need their
+    // transpose buffers again in phase 2); waves 2 and 3 are idle in phase 2 and leave their digit in their own
+    // transpose buffer
     static constexpr size_t hand_at = tw_at + tw_bytes + WAVES * xch_bytes;
-    static constexpr size_t hand_bytes = sizeof(double2) * WAVES * G::NC;  // four Lagrange-domain digits
-    static constexpr size_t total = hand_at + hand_bytes;              // 94,208 B: one workgroup per CU
+    static constexpr size_t hand_bytes = sizeof(double2) * 2 * G::NC;
+    static constexpr size_t hand_row(int p) { return p < 2 ? hand_at + (size_t)p * sizeof(double2) * G::NC : xch_at(p); }
+    static constexpr size_t total = hand_at + hand_bytes;              // 77,824 B: two workgroups per CU
+    static_assert(xch_bytes >= sizeof(double2) * G::NC, "a digit fits a transpose buffer");
 };
 
 // BGC: Bgbit when known at compile time (0: read A.gd.Bgbit).  Gadget length 2, Torus32, N = 1024.
@@ -1279,7 +1284,6 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_blind_rotate_split(BlindRotateArgs<
     const int q = wave >> 1, d = wave & 1;          // phase 1: row p = q * l + d = wave
     const int decal = 32 - (d + 1) * Bgbit;         // wave-uniform
     const bool fwd = wave < 2;                      // phase 2: this wave owns output polynomial `wave`
-    double2 *hand = reinterpret_cast<double2 *>(smem + L::hand_at);
 
     // rotation of step i (0 = skipped, lwe_functions.cpp:348-350); wave-uniform scalar loads
     auto rotation = [&](int i) {
@@ -1339,7 +1343,7 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_blind_rotate_split(BlindRotateArgs<
                 xi[0][m] = (double)TFHE_SBFE(hi[m], decal, Bgbit);
             }
             WaveFFT<10>::template ifft<1, TwLds<10>, true>(xr, xi, w.tw, w.xch, t);
-            double2 *h = hand + wave * NC + t;
+            double2 *h = reinterpret_cast<double2 *>(smem + L::hand_row(wave)) + t;
 #pragma unroll
             for (int m = 0; m < PPL; m++) h[64 * m] = make_double2(xr[0][m], xi[0][m]);
         }
@@ -1357,7 +1361,7 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_blind_rotate_split(BlindRotateArgs<
             // all four rows' reads up front: 128 registers next to the 128 of the key rows, and spills)
             double ar[2][PPL], ai[2][PPL];
             auto read_digit = [&](int p) {
-                const double2 *h = hand + p * NC + t;
+                const double2 *h = reinterpret_cast<const double2 *>(smem + L::hand_row(p)) + t;
 #pragma unroll
                 for (int m = 0; m < PPL; m++) {
                     const double2 v = h[64 * m];
