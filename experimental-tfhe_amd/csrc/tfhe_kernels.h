@@ -172,6 +172,8 @@ struct WaveFFT {
     template <int WMAP, int RMAP>
     TFHE_DEVICE static void transpose_cplx(double (&xr)[PPL], double (&xi)[PPL], const Xch &X) {
         double2 *w = reinterpret_cast<double2 *>(X.buf) + X.lane[WMAP], *r = reinterpret_cast<double2 *>(X.buf) + X.lane[RMAP];
+        // (one ds_write_b128 per point: two ds_write_b64 -- 6 LDS cycles each against 13 -- measured equal, 17.15 vs 17.14 ms
+        // per 4096 blind rotations on one box, round 3)
 #pragma unroll
         for (int m = 0; m < PPL; m++) w[G::roff(WMAP, m)] = make_double2(xr[m], xi[m]);
         TFHE_WAVE_FENCE();

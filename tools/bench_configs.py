@@ -153,6 +153,17 @@ def bench_cb(T, a):
         "circuitPrivKS (one plane, batch samples; the pipeline runs 2 launches of l1*batch)": lambda: cb._chk(lib.tfhe_amd_privks(cb.cb, d_row, 0, d_boot, B)),
     }
     line["stages_ms"] = {k: timed(ev, a.reps, f)[0] for k, f in stages.items()}
+    # the dominant kernel (87 % of the call): Torus64 / N2 blind rotation, bound by fp64 ISSUE -- 8,064 wave64 fp64
+    # instructions per CMux per sample (8 inverse + 2 forward transforms, 16 half-row MACs, conversions; N2 = 2048, l2 = 4)
+    # against 1024 SIMDs x 2.4 GHz / 4 cycles; the flop view beside it (647,168 flop per CMux vs 78.6 TF)
+    t_br = line["stages_ms"]["circuitBootstrapWoKS (one of l1)"] * 1e-3
+    cmux = B * n0 / t_br
+    if N2 == 2048 and l2 == 4:
+        line["blind_rotation_roofline"] = {"kernel": "k_blind_rotate<int64,N=2048>", "bound": "fp64_issue", "cmux_per_s": cmux,
+                                           "achieved": cmux * 8064 / 1e9, "peak": 1024 * 2.4e9 / 4 / 1e9, "unit": "G fp64 wave-instr/s",
+                                           "frac": cmux * 8064 * 4 / (1024 * 2.4e9),
+                                           "fp64_valu_frac": cmux * 647168 / 78.6e12,
+                                           "algorithmic_bytes_per_cmux": 65544, "hbm_contract_frac": cmux * 65544 / HBM_PEAK}
     plane_bytes = (N2 + 1) * t21 * (1 << bb21) * 2 * N1 * 4
     t_priv = line["stages_ms"]["circuitPrivKS (one plane, batch samples; the pipeline runs 2 launches of l1*batch)"] * 1e-3
     line["privks_hbm"] = {"note": "batch-major: one launch streams one table plane once (SURVEY 8a a19: 2.69 GB in two planes)",
