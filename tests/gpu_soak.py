@@ -41,8 +41,10 @@ def main():
         if kind == "gate":      # N=1024 Torus32: compile-time and run-time gadgets, ragged batches 1..41
             l, bg = rnd.choice([(2, 10), (2, 10), (2, 8), (2, 9), (3, 7), (4, 6), (1, 12)])
             t, bb = rnd.choice([(8, 2), (16, 1), (5, 3), (6, 2)])
+            # which blind-rotation kernel: the library's choice, the latency-shaped one (it applies where l == 2), or
+            # one wave per ciphertext whatever the batch
             P.check_gate_path(lib, N=1024, n=rnd.randrange(2, 9), l=l, Bgbit=bg, ks_t=t, ks_bb=bb, B=rnd.randrange(1, 42),
-                              seed=seed, check_export=False)
+                              seed=seed, check_export=False, br_split=rnd.choice([None, 1 << 30, 0]))
         elif kind == "t64":     # Torus64, both ring sizes (short rounding + guard)
             N = rnd.choice([1024, 2048])
             l, bg = rnd.choice([(4, 9), (3, 10), (2, 16), (4, 8)])

@@ -43,8 +43,9 @@ if max_stage >= 3:
     P.check_gate_path(T.DEFAULT_LIB, N=1024, n=4, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=3)
     say("   ok")
 if max_stage >= 4:
-    say("stage 4: gate path, n=630, B=4")
-    P.check_gate_path(T.DEFAULT_LIB, N=1024, n=630, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=4, check_export=False)
+    say("stage 4: gate path, n=630, B=4, on the latency-shaped kernel and on one wave per ciphertext")
+    P.check_gate_path(T.DEFAULT_LIB, N=1024, n=630, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=4, check_export=False, br_split=1 << 30)
+    P.check_gate_path(T.DEFAULT_LIB, N=1024, n=630, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=4, check_export=False, br_split=0)
     say("   ok")
 if max_stage >= 5:
     say("stage 5: Torus64 N=2048 l=4, n=5, B=4")
