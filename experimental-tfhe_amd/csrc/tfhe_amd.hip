@@ -333,6 +333,17 @@ int pack_rows(tfhe_amd_ctx *c, double2 *dst_d, const double *src_d, long long ro
 
 // ---- key switch on the matrix cores (k_ks_mfma): any row length, basebit 1..3, t * basebit <= 32,
 // t * base <= 96
+// Small batches: how many slices to cut K into so that the launch has a few hundred workgroups (a lone 256-sample
+// tile is 8 * ceil(hblocks / 8) of them, each streaming its columns of the WHOLE key).  1 = no split (plain stores).
+int ks_mfma_ksplit(int count, int row_ints, int n_in, int t, int bb) {
+    const int kpi = ks_mfma_kpi(t, bb);
+    const int chunks = ks_mfma_steps(n_in, kpi) / ks_mfma_chunk(kpi);
+    const int base = 8 * ((count + 255) / 256) * (((row_ints + 31) / 32 + 7) / 8);
+    int ks = 384 / (base > 0 ? base : 1);
+    if (ks > chunks / 4) ks = chunks / 4;  // at least four chunks per slice
+    if (ks > 16) ks = 16;
+    return ks < 1 ? 1 : ks;
+}
 bool ks_mfma_supported(int t, int bb) { return bb >= 1 && bb <= 3 && t * bb <= 32 && ks_mfma_kpi(t, bb) <= 3; }
 size_t ks_mfma_bytes(int n_in, int t, int bb, int row_ints) {
     return (size_t)((row_ints + 31) / 32) * ks_mfma_steps(n_in, ks_mfma_kpi(t, bb)) * 4096;
@@ -358,8 +369,9 @@ template <typename XT>
 int launch_ks_mfma(hipStream_t stream, KsMfmaArgs a, int bb) {
     a.hblocks = (a.row_ints + 31) / 32;
     const int mtiles = (a.count + 255) / 256;
-    const unsigned grid = 8u * (unsigned)mtiles * (unsigned)((a.hblocks + 7) / 8);
     const int kpi = ks_mfma_kpi(a.t, bb);
+    if (a.ksplit < 1) a.ksplit = 1;
+    const unsigned grid = 8u * (unsigned)mtiles * (unsigned)((a.hblocks + 7) / 8) * (unsigned)a.ksplit;
     switch (bb) {
         case 1: return launch_ks_mfma_b<XT, 1>(stream, a, kpi, grid);
         case 2: return launch_ks_mfma_b<XT, 2>(stream, a, kpi, grid);
@@ -1010,6 +1022,9 @@ int tfhe_amd_keyswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *in_d, int
         a.count = batch;
         a.b_index = c->p.N;
         a.b_col = c->p.ks_n_out;
+        a.ksplit = ks_mfma_ksplit(batch, a.row_ints, a.n_in, a.t, c->p.ks_basebit);
+        if (a.ksplit > 1)  // the slices add into the output
+            HIPCHECK(c, hipMemsetAsync(out_d, 0, (size_t)batch * (c->p.ks_n_out + 1) * 4, c->stream));
         if (int rc = launch_ks_mfma<int32_t>(c->stream, a, c->p.ks_basebit)) return fail(c, rc, "k_ks_mfma launch");
         return TFHE_AMD_OK;
     }

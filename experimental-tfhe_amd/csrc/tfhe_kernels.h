@@ -644,7 +644,7 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
 // coefficient (Torus32): one add (x = B + 4K), one AND-OR (wrap inside the polynomial | its LDS
 // offset), one signed bit-field extract (s = the sign as 0 / -1), then ((src ^ s) + (offset - acc[j]))
 // as one XOR-ADD, - s, ^ flip: 7 VALU operations, where the plain expression compiles to 10.
-template <typename T, int LOGN>
+template <typename T, int LOGN, int GRP32 = 8>
 TFHE_DEVICE void rotated_minus_one(const WaveLds<T, LOGN> &w, int q, int a, typename Torus<T>::U offset,
                                    typename Torus<T>::U flip, typename Torus<T>::U (&lo)[Geom<LOGN>::PPL],
                                    typename Torus<T>::U (&hi)[Geom<LOGN>::PPL], int t) {
@@ -657,8 +657,9 @@ TFHE_DEVICE void rotated_minus_one(const WaveLds<T, LOGN> &w, int q, int a, type
         const uint32_t poly_lds = w.acc_lds + (uint32_t)q * PB;
         const uint32_t B = ((uint32_t)(t - a) & (2 * N - 1)) * 4;
         // the rotated reads are issued GRP at a time and then consumed (left to itself hipcc waits for each
-        // read right behind its issue: one LDS round trip per coefficient); 8 measured best of 4 / 8 / 16
-        constexpr int GRP = 8;
+        // read right behind its issue: one LDS round trip per coefficient); 8 measured best of 4 / 8 / 16 with two
+        // waves per SIMD; the lone waves of k_blind_rotate_split: 16 measured equal to 8 (2.48 vs 2.47 ms, round 3)
+        constexpr int GRP = GRP32;
 #pragma unroll
         for (int g = 0; g < 2 * PPL; g += GRP) {
             uint32_t src[GRP];
@@ -2035,6 +2036,9 @@ struct KsMfmaArgs {
     const int8_t *bm;         // packed key
     int32_t group, x_stride, n_in, t, row_ints, hblocks, count;
     int32_t b_index, b_col;   // seed: out[s][b_col] starts from x[s][b_index] (LWE key switch); b_col < 0: all zero (privKS)
+    int32_t ksplit;           // > 1: the K dimension is cut into this many slices, one workgroup each, results added
+                              // atomically into a ZEROED out (small batches: a 256-sample tile alone is 24 workgroups
+                              // streaming the whole key -- 0.18 ms for one gate key switch; integer sums: any order, same bits)
 };
 
 // KPI = ks_mfma_kpi(t, BB) as a template parameter: a chunk of CH K-steps then covers CH / KPI whole input
@@ -2052,10 +2056,16 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_ks_mfma(KsMfmaArgs A) {
     // workgroups that share a key slice (same hblock) get consecutive ids of one XCD (ids b, b+8, ...
     // run on the same XCD): the slice is then served by that XCD's L2
     const int mtiles = (A.count + TILE - 1) / TILE;
-    const int bid = blockIdx.x, y = bid >> 3;
+    const int per_slice = 8 * mtiles * ((A.hblocks + 7) / 8);
+    const int kz = TFHE_UNIFORM((int)blockIdx.x / per_slice);
+    const int bid = (int)blockIdx.x - kz * per_slice, y = bid >> 3;
     const int hb = (bid & 7) + 8 * (y / mtiles), mt = y % mtiles;
     if (hb >= A.hblocks) return;
-    const int steps = ks_mfma_steps(A.n_in, KPI), chunks = steps / CH;
+    const int steps = ks_mfma_steps(A.n_in, KPI), chunks_all = steps / CH;
+    const int ksplit = A.ksplit > 1 ? A.ksplit : 1;
+    const int c_begin = (int)((long long)kz * chunks_all / ksplit), c_end = (int)((long long)(kz + 1) * chunks_all / ksplit);
+    const int chunks = c_end - c_begin;  // this workgroup's slice of K: chunks c_begin .. c_end - 1
+    if (chunks <= 0) return;
     const int s0 = mt * TILE + wave * 64;
     const bool live = s0 < A.count;  // wave-uniform: a wave without samples only helps staging the key
     const UX prec = (UX)1 << (W - (1 + BB * A.t));
@@ -2122,8 +2132,8 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_ks_mfma(KsMfmaArgs A) {
     UX wraw[2][WPC];
     const int lane_shift = hl * ((16 >> BB) * BB);  // digit bits covered by the lower lane half's 16 k's
     v4i stage[CH];
-    load_key(0, stage);
-    load_words(0, wraw);
+    load_key(c_begin, stage);
+    load_words(c_begin, wraw);
     finish_words(wcur, wraw);
     store_key(0, stage);
     __syncthreads();
@@ -2136,8 +2146,8 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_ks_mfma(KsMfmaArgs A) {
       for (int c = 0; c < chunks; c++) {
         const bool more = c + 1 < chunks;
         if (more) {  // next chunk's key slice and input words: in flight underneath this chunk's MFMAs
-            load_key(c + 1, stage);
-            load_words(c + 1, wraw);
+            load_key(c_begin + c + 1, stage);
+            load_words(c_begin + c + 1, wraw);
         }
         const v4i *kb = reinterpret_cast<const v4i *>(smem) + (c & 1) * (CH * 256) + lane;
         if (COMPUTE) {
@@ -2207,7 +2217,9 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_ks_mfma(KsMfmaArgs A) {
     // epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int h = hb * 32 + r;
     if (h >= A.row_ints) return;
-    const uint32_t bias = 128u * (uint32_t)A.n_in * (uint32_t)A.t;
+    // every (i, j) position of this workgroup's input coefficients contributed one row stored as (limb - 128)
+    const int i_begin = c_begin * WPC, i_end = c_end * WPC < A.n_in ? c_end * WPC : A.n_in;
+    const uint32_t bias = 128u * (uint32_t)(i_end > i_begin ? i_end - i_begin : 0) * (uint32_t)A.t;
     if (!live) return;
 #pragma unroll
     for (int rb = 0; rb < 2; rb++) {
@@ -2219,9 +2231,12 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_ks_mfma(KsMfmaArgs A) {
 #pragma unroll
             for (int l = 0; l < 4; l++) sum += ((uint32_t)acc[rb][l][e] + bias) << (8 * l);
             uint32_t seed = 0;
-            if (h == A.b_col) seed = (uint32_t)reinterpret_cast<const XT *>(A.x)[(size_t)s * A.x_stride + A.b_index];
-            A.out[(size_t)(s % A.group) * A.stride_in_group + (size_t)(s / A.group) * A.stride_of_group + h] =
-                (int32_t)(seed - sum);
+            if (h == A.b_col && kz == 0) seed = (uint32_t)reinterpret_cast<const XT *>(A.x)[(size_t)s * A.x_stride + A.b_index];
+            int32_t *o = A.out + (size_t)(s % A.group) * A.stride_in_group + (size_t)(s / A.group) * A.stride_of_group + h;
+            if (ksplit > 1)
+                atomicAdd(reinterpret_cast<unsigned *>(o), (unsigned)(seed - sum));  // out was zeroed by the host
+            else
+                *o = (int32_t)(seed - sum);
         }
     }
 }

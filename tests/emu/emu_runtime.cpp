@@ -258,6 +258,22 @@ static void launch_flat_now(const std::function<void()> &body, Dim3 grid, Dim3 b
 
 }  // namespace emu
 
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) {
+    if (emu::t_capture) {
+        emu::t_capture->nodes.push_back([d, s, n]() { memcpy(d, s, n); });
+        return hipSuccess;
+    }
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
+    if (emu::t_capture) {
+        emu::t_capture->nodes.push_back([d, v, n]() { memset(d, v, n); });
+        return hipSuccess;
+    }
+    memset(d, v, n);
+    return hipSuccess;
+}
 hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
     if (emu::t_capture) return hipErrorInvalidValue;
     emu::t_capture = new EmuGraph();

@@ -121,9 +121,9 @@ static inline hipError_t hipGetDeviceCount(int *d) { *d = 1; return hipSuccess; 
 hipError_t hipMalloc(void **p, size_t bytes);
 hipError_t hipFree(void *p);
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t);  // recorded while a capture is open
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
-static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t);  // recorded while a capture is open
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 // events: wall-clock stamps (the emulator runs launches synchronously)
