@@ -196,6 +196,18 @@ def bench_latency(T, a):
     import time
     shard = importlib.import_module("experimental-tfhe_amd.shard")
     cfg = shard.GateConfig() if not a.small else shard.GateConfig(n=6)
+    # the reference's own latency beside it: ONE process of oracle/_ref/ref_driver bench32 (tfhe_bootstrap_FFT composed
+    # from the reference's FFT / AddMul object code) on one host core -- a child process, so it runs BEFORE the engine
+    # touches the GPU (bench_latency is the first GPU user of this program when run as `lat`; `all` runs it first too)
+    cpu_ref = None
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not a.small and a.lib is None and os.access(ref, os.X_OK) and not getattr(a, "_gpu_touched", False):
+        import subprocess
+        out = subprocess.run([ref, "bench32", "/dev/null", "/dev/null", str(cfg.n), str(cfg.l), str(cfg.Bgbit), str(cfg.ks_t),
+                              str(cfg.ks_basebit), "4"], capture_output=True, text=True).stdout.split()
+        if len(out) >= 2 and float(out[0]) > 0:
+            cpu_ref = {"ms_per_bootstrap": 1e3 * float(out[1]) / float(out[0]), "cores": 1, "kind": "reference",
+                       "sample": f"{out[0]} bootstraps in {float(out[1]):.1f} s, one process of ref_driver bench32"}
     job = shard.GateJob(cfg, 0x5446484500000001, device=0, lib_path=a.lib)
     eng, lib = job.eng, job.eng.lib
     sizes = [1, 2, 3] if a.small else [int(x) for x in a.lat_batches.split(",")]
@@ -226,6 +238,8 @@ def bench_latency(T, a):
             line[name] = {"ms_min": best, "ms_mean": mean, "host_wall_ms_min": 1e3 * min(walls),
                           "bootstraps_per_s": B / (best * 1e-3), "decrypt_check": bool(ok), "identical_to_split": same}
         line["speedup_split_over_one_wave"] = line["one_wave_per_ciphertext"]["ms_min"] / line["split"]["ms_min"]
+        if cpu_ref is not None and B == 1:
+            line["cpu_baseline"] = cpu_ref
         print(json.dumps(line), flush=True)
     eng.set_option(T.OPT_BR_SPLIT, -1)
     job.close()
@@ -246,12 +260,12 @@ def main():
     T = importlib.import_module("experimental-tfhe_amd")
     if a.lib is None and not os.path.exists(T.DEFAULT_LIB):
         importlib.import_module("experimental-tfhe_amd.build").build()  # child process before any GPU use
+    if a.what in ("lat", "all"):   # first: it times the reference in a child process before the GPU is in use
+        bench_latency(T, a)
     if a.what in ("fft", "all"):
         bench_fft(T, a)
     if a.what in ("cb", "all"):
         bench_cb(T, a)
-    if a.what in ("lat", "all"):
-        bench_latency(T, a)
 
 
 if __name__ == "__main__":
