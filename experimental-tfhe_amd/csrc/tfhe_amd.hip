@@ -44,7 +44,6 @@ struct tfhe_amd_ctx {
     size_t ws_acc_bytes;
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
-    int br_split_form;     // experiment (option 7): 2 = phase 2 on two waves (k_blind_rotate_split), 4 = on four (k_blind_rotate_split4)
     int br_split_max;      // TFHE_AMD_OPT_BR_SPLIT: largest batch served by k_blind_rotate_split (< 0: BR_SPLIT_AUTO_MAX, 0: never)
     int ks_force_gather;   // TFHE_AMD_OPT_KS_GATHER: != 0 per-sample gather kernel even where the matrix-core kernel applies
     // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
@@ -213,14 +212,6 @@ int launch_br_split(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
-template <int BGC>
-int launch_br_split4(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
-    auto kernel = k_blind_rotate_split4<BGC>;
-    if (int rc = set_lds(c, kernel, SplitLds4::total)) return rc;
-    TFHE_LAUNCH((k_blind_rotate_split4<BGC>), dim3(a.batch), dim3(256), SplitLds4::total, c->stream, a);
-    HIPCHECK(c, hipGetLastError());
-    return TFHE_AMD_OK;
-}
 bool br_split_applies(const tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
     if (c->logn != 10 || c->p.l != 2 || a.n_steps < 1) return false;
     if ((a.flags & (BR_NO_ROTATE | BR_CMUX_DATA)) || a.gsw_sel || a.sel_div > 0) return false;
@@ -228,11 +219,6 @@ bool br_split_applies(const tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) 
     return a.batch <= limit;
 }
 int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
-    if (br_split_applies(c, a) && c->br_split_form == 4) {
-        if (c->p.Bgbit == 10) return launch_br_split4<10>(c, a);
-        if (c->p.Bgbit == 8) return launch_br_split4<8>(c, a);
-        return launch_br_split4<0>(c, a);
-    }
     if (br_split_applies(c, a)) {
         if (c->p.Bgbit == 10) return launch_br_split<10>(c, a);
         if (c->p.Bgbit == 8) return launch_br_split<8>(c, a);
@@ -560,7 +546,6 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->ksm_d = nullptr;
     c->ks_force_gather = 0;
     c->br_split_max = -1;
-    c->br_split_form = 4;
     c->streamed_graph = false;
     c->streamed_warm = 0;
     memset(&c->sg, 0, sizeof(c->sg));
@@ -650,10 +635,6 @@ int tfhe_amd_set_option(tfhe_amd_ctx *c, int option, int value) {
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_STREAMED_GRAPH:
             c->streamed_graph = value != 0;
-            return TFHE_AMD_OK;
-        case 7:  // experiment switch, not in the header
-            c->br_split_form = value;
-            drop_streamed_graph(c);
             return TFHE_AMD_OK;
         case TFHE_AMD_OPT_BR_SPLIT:
             c->br_split_max = value;

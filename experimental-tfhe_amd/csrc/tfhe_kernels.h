@@ -1446,295 +1446,6 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_blind_rotate_split(BlindRotateArgs<
     }
 }
 
-struct SplitLds4 {  // k_blind_rotate_split4: digits stored with a register stride of 66 points (conflict-free for the 4-point readers)
-    using G = Geom<10>;
-    static constexpr int WAVES = 4, HSTRIDE = 66;
-    static constexpr size_t acc_bytes = sizeof(int32_t) * 2 * G::N;
-    static constexpr size_t tw_at = acc_bytes;
-    static constexpr size_t tw_bytes = sizeof(double2) * G::TW;
-    static constexpr size_t xch_bytes = sizeof(double2) * G::XCH;      // 9,216 B: phase-1 transposes, digit of waves 2 / 3, phase-2 transposes (5 KB)
-    static constexpr size_t xch_at(int wave) { return tw_at + tw_bytes + (size_t)wave * xch_bytes; }
-    static constexpr size_t row_bytes = sizeof(double2) * (HSTRIDE * 7 + 64 + 2);   // 8,448 B per digit
-    static constexpr size_t hand_at = tw_at + tw_bytes + WAVES * xch_bytes;
-    static constexpr size_t hand_bytes = 2 * row_bytes;                // digits of waves 0, 1; then the 4 x 4 KB exchange area
-    static constexpr size_t hand_row(int p) { return p < 2 ? hand_at + (size_t)p * row_bytes : xch_at(p); }
-    static constexpr size_t total = hand_at + hand_bytes;              // 78,336 B: two workgroups per CU
-    static_assert(xch_bytes >= row_bytes && hand_bytes >= sizeof(double2) * 4 * 256 && xch_bytes >= sizeof(double2) * 320, "layout");
-};
-
-// The same with phase 2 on ALL FOUR waves: wave (q' = wave & 1, h = wave >> 1) owns positions [256 h, 256 h + 256) of
-// output polynomial q'.  The reference's forward transform is a decimation-in-time network (spqlios-fft-fma.s): its
-// stages up to half-size 128 act inside the two blocks of 256 positions independently, only the last one (half-size
-// 256) pairs position u of block 0 with position u of block 1.  So each wave multiply-accumulates HALF of the bins
-// (64 instead of 128 fp64 instructions), runs a 256-point network on 64 lanes x 4 registers (size-2 and size-4 steps,
-// then three passes of two stages with three wave-internal transposes of 4 points), and the two waves of a pair
-// exchange their 4 points per lane once (through the rows-0/1 hand-over area, dead by then) for the last stage, the
-// twist, the rounding and the accumulate -- of which each again does half.  Two more workgroup barriers per CMux
-// (hand-over buffer dead / exchange complete).  Same butterflies, same operands, same order: same bits.
-template <int BGC>
-TFHE_GLOBAL void __launch_bounds__(256, 2) k_blind_rotate_split4(BlindRotateArgs<int32_t> A) {
-    using T = int32_t;
-    using U = uint32_t;
-    using G = Geom<10>;
-    using L = SplitLds4;
-    constexpr int N = G::N, NC = G::NC, PPL = G::PPL;
-    TFHE_DYN_LDS(smem);
-    const int tid = (int)threadIdx.x;
-    const int wave = TFHE_UNIFORM(tid >> 6);
-    const int t = tid & 63;
-    const int ct = (int)blockIdx.x;
-    if (ct >= A.batch) return;  // whole workgroup
-    T *acc = reinterpret_cast<T *>(smem);
-    {
-        double2 *tw = reinterpret_cast<double2 *>(smem + L::tw_at);
-        for (int i = tid; i < G::TW; i += 256) tw[i] = A.tw[i];
-    }
-    const int32_t *rot = A.rot + (size_t)ct * A.rot_stride;
-    // ---- accumulator initialisation, 8 coefficients per thread (flat index e over [2][N])
-    if (A.flags & BR_INIT_TESTVEC) {
-        int barb = rot[A.n_steps];
-        if (A.flags & BR_MODSWITCH) barb = modswitch_2N<10>(barb);
-        const int a0 = (2 * N - barb) & (2 * N - 1);  // lwe_functions.cpp:385-386
-        const T *tv = A.tv + (size_t)ct * A.tv_stride;
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int j = tid + 256 * m;
-            const int idx = (j - a0) & (2 * N - 1);
-            const int src = idx & (N - 1);
-            U v;
-            if (A.flags & BR_TV_CONST)
-                v = (U)A.tv_const;
-            else if (A.flags & BR_TV_HALF)
-                v = (src < N / 2) ? (U)(0 - (U)A.tv_const) : (U)A.tv_const;
-            else
-                v = (U)tv[src];
-            acc[j] = 0;
-            acc[N + j] = (T)((idx & N) ? (U)(0 - v) : v);
-        }
-    } else {
-        const T *src = A.acc_io + (size_t)ct * 2 * N;
-#pragma unroll
-        for (int m = 0; m < 8; m++) acc[tid + 256 * m] = src[tid + 256 * m];
-    }
-    __syncthreads();
-
-    WaveLds<T, 10> w;
-    w.smem = smem;
-    w.acc = acc;
-    w.acc_lds = tfhe_lds_offset(acc);
-    if (w.acc_lds & (uint32_t)(sizeof(T) * N - 1)) TFHE_TRAP();  // rotated_minus_one relies on it: fail loudly
-    w.xch = WaveFFT<10>::make_xch(reinterpret_cast<double *>(smem + L::xch_at(wave)), t);
-    w.tw.tw = reinterpret_cast<const double2 *>(smem + L::tw_at);
-    w.tw.t = t;
-    w.tw.load_uniform(A.tw);
-    w.progress_lds = 0;
-    w.self = w.partner = wave;
-
-    const U offset = (U)A.gd.offset, flip = (U)A.gd.flip;
-    const int Bgbit = BGC ? BGC : A.gd.Bgbit;
-    const int q = wave >> 1, d = wave & 1;          // phase 1: row p = q * l + d = wave
-    const int decal = 32 - (d + 1) * Bgbit;         // wave-uniform
-
-    // rotation of step i (0 = skipped, lwe_functions.cpp:348-350); wave-uniform scalar loads
-    auto rotation = [&](int i) {
-        int a = tfhe_uniform_load32(rot, i);
-        if (A.flags & BR_MODSWITCH) a = modswitch_2N<10>(a);
-        return TFHE_UNIFORM(a);
-    };
-    auto next_step = [&](int i) {  // first step >= i with a non-zero rotation
-        while (i < A.n_steps && rotation(i) == 0) i++;
-        return i;
-    };
-    // This wave's quarter of the key row of a step: rows p = 0..3 of output polynomial q2 at its 256 positions, 4 complex
-    // per lane and row (64 registers): requested for the NEXT step right after the MAC, carried through phase 1.
-    const int q2 = wave & 1, hb = wave >> 1;  // phase 2: output polynomial, block of positions
-    double2 bk[4][4];
-    // position P = 256 hb + 4 t + r sits at [m' = P & 7][t' = P >> 3] of the [8][64] half-row: m' = 4 (t & 1) + r, t' = 32 hb + (t >> 1)
-    const uint32_t lane16 = (uint32_t)(((4 * (t & 1)) * 64 + 32 * hb + (t >> 1)) * 16) + (uint32_t)q2 * (uint32_t)(PPL * 64 * 16);
-    auto request_key = [&](int i) {
-        const TFHE_BUFFER_RSRC rsrc =
-            TFHE_MAKE_BUFFER_RSRC(reinterpret_cast<const unsigned char *>(A.bk + (size_t)i * A.bk_step_stride));
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) bk[p][r] = tfhe_buffer_load_d2(rsrc, lane16, (uint32_t)(((p * 2) * PPL + r) * 64) * 16u);
-    };
-    // the wave's transposes of 4 complex points (units of 16 bytes in its own transpose buffer); index of local position u
-    // under the three paddings u + (u >> 2) | u + 4 (u >> 4) | u, as lane part + register part (tools/lds_conflicts.py)
-    double2 *xb = reinterpret_cast<double2 *>(smem + L::xch_at(wave));
-    int laneC = 5 * t, laneP1 = 20 * (t >> 2) + (t & 3), laneP2r = 80 * (t >> 4) + (t & 15), laneP2w = 64 * (t >> 4) + (t & 15);
-    TFHE_OPAQUE(laneC);
-    TFHE_OPAQUE(laneP1);
-    TFHE_OPAQUE(laneP2r);
-    TFHE_OPAQUE(laneP2w);
-    const double2 *twl = reinterpret_cast<const double2 *>(smem + L::tw_at);
-    const int handlane = L::HSTRIDE * (4 * (t & 1)) + 32 * hb + (t >> 1);  // + HSTRIDE * r: where position 256 hb + 4 t + r of a digit lies
-    double2 *exch = reinterpret_cast<double2 *>(smem + L::hand_at);          // [q2][hb][256] points, after barrier X
-
-    int i = next_step(0);
-    if (i < A.n_steps) request_key(i);
-#pragma unroll 1
-    while (i < A.n_steps) {
-        const int a = rotation(i);
-        const int inext = next_step(i + 1);
-        // ---- phase 1: digit d of polynomial q of (X^a - 1) * acc, to the Lagrange domain
-        {
-            U lo[PPL], hi[PPL];
-            rotated_minus_one<T, 10>(w, q, a, offset, flip, lo, hi, t);
-            double xr[1][PPL], xi[1][PPL];
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {  // field tops are flipped: the signed field IS digit - Bg/2 (Gadget::flip)
-                xr[0][m] = (double)TFHE_SBFE(lo[m], decal, Bgbit);
-                xi[0][m] = (double)TFHE_SBFE(hi[m], decal, Bgbit);
-            }
-            WaveFFT<10>::template ifft<1, TwLds<10>, true>(xr, xi, w.tw, w.xch, t);
-            double2 *h = reinterpret_cast<double2 *>(smem + L::hand_row(wave)) + t;
-#pragma unroll
-            for (int m = 0; m < PPL; m++) h[L::HSTRIDE * m] = make_double2(xr[0][m], xi[0][m]);
-        }
-        __syncthreads();  // the four digits are in the hand-over buffer
-        // ---- phase 2, all four waves: MAC of this wave's 256 positions in row order
-        double fr[4], fi[4];
-        {
-            double ar[2][4], ai[2][4];
-            auto read_digit = [&](int p) {
-                const double2 *h = reinterpret_cast<const double2 *>(smem + L::hand_row(p)) + handlane;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double2 v = h[L::HSTRIDE * r];
-                    ar[p & 1][r] = v.x;
-                    ai[p & 1][r] = v.y;
-                }
-            };
-            read_digit(0);
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                if (p < 3) read_digit(p + 1);
-                TFHE_ORDER();
-                if (p == 0)
-                    mac_half_row<4, true>(fr, fi, ar[0], ai[0], bk[0]);
-                else
-                    mac_half_row<4, false>(fr, fi, ar[p & 1], ai[p & 1], bk[p]);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    TFHE_OPAQUE(fr[r]);
-                    TFHE_OPAQUE(fi[r]);
-                }
-                TFHE_ORDER();
-            }
-        }
-        if (inext < A.n_steps) {
-            TFHE_KEEP_BRANCH();
-            request_key(inext);  // in flight for the rest of this step and the whole of the next phase 1
-        }
-        TFHE_ORDER();
-        __syncthreads();  // X: every wave has read the digits -- waves 2, 3 may reuse their transpose buffers, the rows-0/1 area is free
-        // ---- 256-point decimation-in-time network on positions 4 t + r (spqlios-fft-fma.s:79-95, :134-152, :189-234)
-        {
-            const double r0 = fr[0], r1 = fr[1], r2 = fr[2], r3 = fr[3], i0 = fi[0], i1 = fi[1], i2 = fi[2], i3 = fi[3];
-            const double a0 = r0 + r1, a1 = r0 - r1, a2 = r2 + r3, a3 = r2 - r3;   // size-2 step
-            const double b0 = i0 + i1, b1 = i0 - i1, b2 = i2 + i3, b3 = i2 - i3;
-            fr[0] = a0 + a2;                                                        // size-4 step
-            fr[1] = a1 + b3;
-            fr[2] = a0 - a2;
-            fr[3] = a1 - b3;
-            fi[0] = b0 + b2;
-            fi[1] = b1 - a3;
-            fi[2] = b0 - b2;
-            fi[3] = b1 + a3;
-        }
-        auto xpose = [&](int wl, int wo, int rl, int ro) {  // write lane part / register stride, read lane part / register stride
-            double2 *wp = xb + wl, *rp = xb + rl;
-#pragma unroll
-            for (int m = 0; m < 4; m++) wp[wo * m] = make_double2(fr[m], fi[m]);
-            TFHE_WAVE_FENCE();
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const double2 v = rp[ro * m];
-                fr[m] = v.x;
-                fi[m] = v.y;
-            }
-            TFHE_WAVE_FENCE();
-        };
-        // two stages on registers (bit0, bit1) of the lane's 4 points: half-sizes H (pairs (0,1), (2,3); offset lo) and 2H
-        // (pairs (0,2), (1,3); offsets lo and H + lo); quarter turn at offset == half-size / 2 (flip_sign_if)
-        auto two_stages = [&](int H, int lo, bool q_first, bool q_second) {
-            const double2 w1 = twl[G::tw_base(H) + lo];
-            const double c1 = flip_sign_if(w1.x, q_first);
-            dit_bfly(fr[0], fi[0], fr[1], fi[1], c1, w1.y);
-            dit_bfly(fr[2], fi[2], fr[3], fi[3], c1, w1.y);
-            const double2 w2 = twl[G::tw_base(2 * H) + lo], w3 = twl[G::tw_base(2 * H) + H + lo];
-            dit_bfly(fr[0], fi[0], fr[2], fi[2], w2.x, w2.y);
-            dit_bfly(fr[1], fi[1], fr[3], fi[3], flip_sign_if(w3.x, q_second), w3.y);
-        };
-        xpose(laneC, 1, laneP1, 5);        // positions 4t+r -> registers = position bits 3, 2
-        two_stages(4, t & 3, (t & 3) == 2, (t & 3) == 0);
-        xpose(laneP1, 4, laneP2r, 20);     // -> registers = bits 5, 4
-        two_stages(16, t & 15, (t & 15) == 8, (t & 15) == 0);
-        xpose(laneP2w, 16, t, 64);         // -> registers = bits 7, 6: local position t + 64 m
-        two_stages(64, t, t == 32, t == 0);
-        // ---- last stage (half-size 256) with the partner wave's block, final twist, rounding, acc += result: each wave its half
-        {
-            double2 *mine = exch + (q2 * 2 + hb) * 256 + t;
-            const double2 *theirs = exch + (q2 * 2 + (hb ^ 1)) * 256 + t;
-#pragma unroll
-            for (int m = 0; m < 4; m++) mine[64 * m] = make_double2(fr[m], fi[m]);
-            __syncthreads();  // Y
-            U r0[4], r1[4];
-            uint32_t guard = 0;
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const double2 o = theirs[64 * m];
-                const double ar_ = hb ? o.x : fr[m], ai_ = hb ? o.y : fi[m];   // block 0's value
-                const double br_ = hb ? fr[m] : o.x, bi_ = hb ? fi[m] : o.y;   // block 1's value
-                const double2 wt = twl[G::tw_base(256) + t + 64 * m];
-                const double wc = (m == 2) ? flip_sign_if(wt.x, t == 0) : wt.x;  // quarter turn at offset 128
-                const double tr = __builtin_fma(bi_, wt.y, br_ * wc);
-                const double ti = __builtin_fma(bi_, wc, -(br_ * wt.y));
-                const double re = hb ? ar_ - tr : ar_ + tr, im = hb ? ai_ - ti : ai_ + ti;
-                const double2 wj = twl[256 * hb + t + 64 * m];                   // twist by conj(omega^j), j = 256 hb + t + 64 m
-                const double rc = re * wj.x, rs = re * wj.y, ic = im * wj.x, is = im * wj.y;
-                fr[m] = rc + is;
-                fi[m] = ic - rs;
-                r0[m] = (U)Torus<T>::from_double_fast(fr[m], guard);
-                r1[m] = (U)Torus<T>::from_double_fast(fi[m], guard);
-            }
-            if (TFHE_WAVE_ANY(!Torus<T>::guard_ok(guard))) {  // |x| >= 2^51 somewhere: the reference's own form
-                TFHE_KEEP_BRANCH();
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    TFHE_OPAQUE(fr[m]);
-                    TFHE_OPAQUE(fi[m]);
-                    r0[m] = (U)Torus<T>::from_double(fr[m]);
-                    r1[m] = (U)Torus<T>::from_double(fi[m]);
-                }
-            }
-            U *pacc = reinterpret_cast<U *>(acc + q2 * N) + 256 * hb + t;
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                TFHE_LDS_ADD(&pacc[64 * m], r0[m]);
-                TFHE_LDS_ADD(&pacc[64 * m + NC], r1[m]);
-            }
-        }
-        __syncthreads();  // accumulator updated; exchange area free
-        i = inext;
-    }
-    // ---- output
-    if (A.flags & BR_EXTRACT) {  // tLweExtractLweSampleIndex, index 0 (tlwe_functions.cpp:351-363)
-        T *out = A.lwe_out + (size_t)ct * (N + 1);
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int j = tid + 256 * m;
-            out[j] = (j == 0) ? acc[0] : (T)(0 - (U)acc[N - j]);
-        }
-        if (tid == 0) out[N] = (T)((U)acc[N] + (U)A.out_b_add);
-    } else {
-        T *dst = A.acc_io + (size_t)ct * 2 * N;
-#pragma unroll
-        for (int m = 0; m < 8; m++) dst[tid + 256 * m] = acc[tid + 256 * m];
-    }
-}
-
 // ------------------------------------------- standalone batched transforms
 // NT: lane-contiguous accesses of data this launch touches once, when the launch's working set is larger than the
 // 256 MB Infinity Cache (the host decides: launch_ifft_w / launch_fft_w) -- nontemporal loads and stores.  Measured
