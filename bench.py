@@ -386,7 +386,7 @@ def main():
                        "scaling_note": "--gpus 1 without flags is config 2 (4096 per step); --gpus N > 1 without flags is config 5 "
                                        "(2^20 per step cut into N slices, strong); a strict strong-scaling series takes its "
                                        "N = 1 point from `--gpus 1 --total 1048576` (per-GPU throughput at 4096 and at 2^20 per "
-                                       "launch agree within 1 %: profiles/r03_config5_one_gpu.json)",
+                                       "launch agree within 1 %: profiles/r03_bench_dist_world1_config5.json)",
                        "process_group": (f"torch.distributed {a.backend}, world {world}" if dist is not None else "none (single process)"),
                        "ks_kernel": "gather" if a.ks_gather else "matrix-core (k_ks_mfma)",
                        "library": os.path.basename(a.lib) if a.lib else "libtfhe_amd.so"},
