@@ -63,11 +63,14 @@ struct tfhe_amd_ctx {
 
 namespace {
 
-// Batches up to this size run the blind rotation on k_blind_rotate_split (one ciphertext per 4-wave workgroup, two
-// workgroups per CU: 2.65 ms for up to 256 ciphertexts, 3.9 ms for up to 512, 7.2 ms for 1024); above it one wave per
-// ciphertext (k_blind_rotate: 7.7 ms up to 1024, 8.3 ms for 2048, 16.8 ms for 4096) has the higher throughput.
-// Measured crossover: profiles/r03_latency.jsonl.
-constexpr int BR_SPLIT_AUTO_MAX = 1024;
+// Which blind-rotation form serves a Torus32 / N = 1024 batch (all three give the same bits; measured on one box,
+// profiles/r03_latency.jsonl, blind rotation + extraction of n = 630):
+//   up to BR_SPLIT_AUTO_MAX   k_blind_rotate_split: one ciphertext per 4-wave workgroup, two workgroups per CU
+//                             (2.5 ms up to 256 ciphertexts, 3.6 ms up to 512; l = 2 only)
+//   up to BR_LONE_WAVE_MAX    k_blind_rotate in 4-wave workgroups: one wave per SIMD on every CU (5.0 ms up to 1024)
+//   above                     k_blind_rotate in 8-wave workgroups: two waves per SIMD (7.5 ms up to 2048, 16.6 ms for 4096)
+constexpr int BR_SPLIT_AUTO_MAX = 512;
+constexpr int BR_LONE_WAVE_MAX = 1024;
 
 int fail(tfhe_amd_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg;
@@ -224,13 +227,22 @@ int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
         if (c->p.Bgbit == 8) return launch_br_split<8>(c, a);
         return launch_br_split<0>(c, a);
     }
-    // N=1024/Torus32: 2 waves per SIMD (256 VGPRs), digits in pairs.  PPL=16 shapes transform
-    // one digit at a time (a pair would need 128 more registers than the file has).
+    // N=1024/Torus32: digits in pairs.  PPL=16 shapes transform one digit at a time (a pair would need 128 more
+    // registers than the file has).
     if (c->logn == 11) return launch_br_t<int32_t, 11, 4, 1>(c, a);
-    // gadget length (and, for the gate set, Bgbit) fixed at compile time: the two transform groups
+    // Workgroup width: 8 waves (2 per SIMD, one workgroup per CU) is the throughput form; up to BR_LONE_WAVE_MAX
+    // ciphertexts 4-wave workgroups put ONE wave on every SIMD of every CU instead of two on half of them -- a lone wave
+    // walks a CMux in 19 k clocks instead of 28 k: 5.0 ms for any batch up to 1024 against 7.4 ms (profiles/r03_latency.jsonl).
+    // Gadget length (and, for the gate set, Bgbit) fixed at compile time: the two transform groups
     // of a CMux are unrolled and each digit is one bit-field extract (tfhe_kernels.h, cmux_step)
-    if (c->p.l == 2 && c->p.Bgbit == 10) return launch_br_t<int32_t, 10, 8, 2, 2, 10>(c, a);  // gate set
-    if (c->p.l == 2 && c->p.Bgbit == 8) return launch_br_t<int32_t, 10, 8, 2, 2, 8>(c, a);    // circuit bootstrap's output gadget
+    if (a.batch <= BR_LONE_WAVE_MAX) {
+        if (c->p.l == 2 && c->p.Bgbit == 10) return launch_br_t<int32_t, 10, 4, 2, 2, 10>(c, a);  // gate set
+        if (c->p.l == 2 && c->p.Bgbit == 8) return launch_br_t<int32_t, 10, 4, 2, 2, 8>(c, a);    // circuit bootstrap's output gadget
+        if (c->p.l == 2) return launch_br_t<int32_t, 10, 4, 2, 2>(c, a);
+        return launch_br_t<int32_t, 10, 4, 2>(c, a);
+    }
+    if (c->p.l == 2 && c->p.Bgbit == 10) return launch_br_t<int32_t, 10, 8, 2, 2, 10>(c, a);
+    if (c->p.l == 2 && c->p.Bgbit == 8) return launch_br_t<int32_t, 10, 8, 2, 2, 8>(c, a);
     if (c->p.l == 2) return launch_br_t<int32_t, 10, 8, 2, 2>(c, a);
     return launch_br_t<int32_t, 10, 8, 2>(c, a);
 }

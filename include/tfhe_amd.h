@@ -86,8 +86,9 @@ int tfhe_amd_sync(tfhe_amd_ctx *ctx);
  *   TFHE_AMD_OPT_BR_SPLIT   which blind-rotation kernel serves a Torus32 / N = 1024 / l = 2 batch: value = the
  *        largest batch that runs on the latency-shaped kernel (one ciphertext per 4-wave workgroup, the 2l inverse
  *        transforms of a CMux on the four SIMDs of a CU at once; what a one-sample call of tfhe_bootstrap_FFT,
- *        lwe_functions.cpp:434-446, gets), larger batches run one wave per ciphertext.  < 0 (default): the
- *        measured crossover; 0: never */
+ *        lwe_functions.cpp:434-446, gets), larger batches run one wave per ciphertext (in 4-wave workgroups -- one
+ *        wave per SIMD -- up to 1024 samples, 8-wave workgroups above).  < 0 (default): the measured crossover
+ *        (512); 0: never */
 enum { TFHE_AMD_OPT_KS_GATHER = 2, TFHE_AMD_OPT_STREAMED_GRAPH = 4, TFHE_AMD_OPT_BR_SPLIT = 5 };
 int tfhe_amd_set_option(tfhe_amd_ctx *ctx, int option, int value);
 /* HIP events on the context's stream, for timing kernels without a HIP binding in the host

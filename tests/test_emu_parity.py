@@ -30,6 +30,29 @@ def test_gate_path_emu_both_blind_rotation_kernels(emu_lib, B):
     P.check_gate_path(emu_lib, N=1024, n=5, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=B, check_export=False, br_split=0)
 
 
+def test_gate_path_emu_eight_wave_workgroups(emu_lib):
+    """batches above 1024 run one wave per ciphertext in 8-wave workgroups (two per SIMD, the issue balance between
+    partner waves): 1027 samples of a 2-step blind rotation = 128 full workgroups and a ragged one, against the
+    latency-shaped kernel on the same inputs and the oracle on a subset"""
+    import importlib
+    import numpy as np
+    import oracle_py as O
+    T = importlib.import_module("experimental-tfhe_amd")
+    s = P.GateSetup(emu_lib, 1024, 2, 2, 10, 8, 2)
+    try:
+        rs = np.random.RandomState(77)
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(1027, 3)).astype(np.int32)
+        s.eng.set_option(T.OPT_BR_SPLIT, 0)
+        got = s.eng.bootstrap_woks(1 << 29, x)
+        sub = [0, 7, 8, 1023, 1024, 1026]
+        want = np.stack([O.bootstrap_woks32(1024, s.bk, 1 << 29, x[i], 2, 10) for i in sub])
+        assert np.array_equal(got[sub], want)
+        s.eng.set_option(T.OPT_BR_SPLIT, 1 << 30)
+        assert np.array_equal(s.eng.bootstrap_woks(1 << 29, x[:40]), got[:40])
+    finally:
+        s.close()
+
+
 def test_gate_path_emu_split_kernel_runtime_bgbit(emu_lib):
     """k_blind_rotate_split<0> (Bgbit read at run time) and <8> (the circuit bootstrap's output gadget)"""
     P.check_gate_path(emu_lib, N=1024, n=3, l=2, Bgbit=9, ks_t=8, ks_bb=2, B=2, check_export=False, seed=12, br_split=1 << 30)

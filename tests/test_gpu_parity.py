@@ -274,6 +274,28 @@ def test_gate_path_latency_kernel_full_parameters(gpu_lib):
         s.close()
 
 
+def test_gate_path_workgroup_widths(gpu_lib):
+    """one wave per ciphertext in its two workgroup widths: 4 waves (batches up to 1024, here 1000) and 8 waves
+    (above: 1031 = 128 full workgroups + a ragged one), both against the latency-shaped kernel on the same inputs
+    and the oracle on a subset"""
+    N, n, l, Bgbit, t, bb = 1024, 40, 2, 10, 8, 2
+    s = P.GateSetup(gpu_lib, N, n, l, Bgbit, t, bb)
+    try:
+        rs = np.random.RandomState(1031)
+        for B in (1000, 1031):
+            x = rs.randint(-2 ** 31, 2 ** 31, size=(B, n + 1)).astype(np.int32)
+            s.eng.set_option(T.OPT_BR_SPLIT, 0)
+            one_wave = s.eng.bootstrap(1 << 29, x)
+            s.eng.set_option(T.OPT_BR_SPLIT, 1 << 30)
+            split = s.eng.bootstrap(1 << 29, x)
+            assert np.array_equal(one_wave, split), B
+            sub = rs.choice(B, 6, replace=False)
+            want = np.stack([O.bootstrap32(N, s.bk, s.ks, 1 << 29, x[i], l, Bgbit, t, bb) for i in sub])
+            assert np.array_equal(one_wave[sub], want), B
+    finally:
+        s.close()
+
+
 def test_gate_path_latency_kernel_other_bgbit(gpu_lib):
     """k_blind_rotate_split<8> (the circuit bootstrap's output gadget) and <0> (Bgbit read at run time)"""
     P.check_gate_path(gpu_lib, N=1024, n=7, l=2, Bgbit=8, ks_t=8, ks_bb=2, B=5, check_export=False, seed=14, br_split=1 << 30)
