@@ -91,6 +91,22 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def rank_census(rank, device_index, batch, seconds, device):
+    """who took part: (ranks_seen, [{rank, device, batch, seconds}...]).  ranks_seen is a SUM all-reduce of ones on the
+    same kind of tensor max_over_ranks uses (the device tensor under RCCL), so a bench line cannot claim ranks
+    that did not run; the table is an all_gather of each rank's (device ordinal, samples per step, timed seconds)."""
+    import torch
+    import torch.distributed as dist
+    one = torch.ones(1, dtype=torch.float64, device=device)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([float(rank), float(device_index), float(batch), float(seconds)], dtype=torch.float64, device=device)
+    rows = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, mine)
+    table = [{"rank": int(r[0].item()), "device": int(r[1].item()), "batch": int(r[2].item()), "seconds": float(r[3].item())}
+             for r in rows]
+    return int(round(one.item())), table
+
+
 def gather_rows(local_rows, total, rank, world, device):
     """all-gather ragged row blocks into the full [total][cols] array (tests / verification only)"""
     import torch

@@ -15,7 +15,8 @@ CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 def test_bench_line_on_emulator(emu_lib):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", emu_lib, "--batch", "2", "--steps", "1",
-                          "--warmup", "0", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--warmup", "0", "--cpu-seconds", "1", "--headline-only"], capture_output=True, text=True, timeout=600,
+                         cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -26,9 +27,17 @@ def test_bench_line_on_emulator(emu_lib):
     assert d["unit"] == "bootstraps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    # the binding unit is fp64 issue; the north-star HBM accounting rides along as hbm_contract
-    assert r["bound"] == "fp64_issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["peak"] - 1024 * 2.4 / 4) < 1e-9 and r["fp64_wave_instr_per_cmux"] == 2144
+    # SURVEY 8(d), persistent variant: compute-bound, flops against the fp64 vector peak; the north-star HBM accounting
+    # rides along as hbm_contract, the issue-slot diagnostic as fp64_issue
+    assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["peak"] - 78.6) < 1e-9 and r["flop_per_cmux"] == 173056 and r["flops_frac"] == r["frac"]
+    assert abs(r["achieved"] * 1e12 - 2 * 630 * 173056 / (r["kernel_ms"] * 1e-3)) < 1e-6 * r["achieved"] * 1e12
+    assert r["persistent_algorithmic_bytes"] == 2 * (2524 + 4100) + 630 * 65536
+    i = r["fp64_issue"]
+    assert i["bound"] == "fp64_issue" and abs(i["frac"] - i["achieved"] / i["peak"]) < 1e-12
+    assert abs(i["peak"] - 1024 * 2.4 / 4) < 1e-9 and i["fp64_wave_instr_per_cmux"] == 2144
+    assert d["ranks_seen"] == 1 and d["ranks"] == [{"rank": 0, "device": 0, "batch": 2, "seconds": d["ranks"][0]["seconds"]}]
+    assert "config1_latency" not in d and "streamed_schedule" not in d  # --headline-only
     h = r["hbm_contract"]
     assert h["bound"] == "hbm" and h["unit"] == "GB/s" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
     # 16,388 B per CMux per sample + 65,536 B key row per CMux per launch, n = 630 CMux
@@ -49,7 +58,7 @@ def test_bench_multi_rank_path_on_emulator(emu_lib):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--lib", emu_lib, "--backend", "gloo", "--total", "5", "--steps", "1", "--warmup", "0",
-                          "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                          "--cpu-seconds", "1", "--lwe-n", "24"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout  # rank 0 only
@@ -57,6 +66,8 @@ def test_bench_multi_rank_path_on_emulator(emu_lib):
     for k in CONTRACT:
         assert k in d, k
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["ranks_seen"] == 2 and [(r["rank"], r["batch"]) for r in d["ranks"]] == [(0, 3), (1, 2)]
+    assert "rank 0, before torch" in d["cpu_baseline"]["measured_by"]
     assert d["config"]["total_per_step"] == 5 and d["config"]["batch_per_gpu"] == 3  # ragged: 3 + 2
     assert "gloo, world 2" in d["config"]["process_group"]
     assert d["decrypt_check"] is True
@@ -67,12 +78,64 @@ def test_bench_dist_flag_single_rank_on_emulator(emu_lib):
     """--dist: the same branch with world size 1 (what a 1-GPU box can run of the driver's N > 1 launch)"""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + (os.getpid() % 90)))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", emu_lib, "--dist", "--backend", "gloo", "--total", "2",
-                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--lwe-n", "24"], capture_output=True, text=True, timeout=600,
                          cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and "gloo, world 1" in d["config"]["process_group"]
     assert "cpu_baseline" not in d
+
+
+def test_bench_starts_its_own_ranks_on_emulator(emu_lib):
+    """`bench.py --gpus 2` with NO launcher: the GPU-free parent takes the CPU baseline, starts the two ranks as a child
+    torch.distributed.run and relays rank 0's line -- n_gpus 2, ranks_seen 2 (the way the driver launches --gpus 1)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TFHE_BENCH_HANDOFF")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lib", emu_lib, "--backend", "gloo",
+                          "--total", "5", "--steps", "1", "--warmup", "0", "--cpu-seconds", "1", "--lwe-n", "24"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "strong"
+    assert [(r["rank"], r["batch"]) for r in d["ranks"]] == [(0, 3), (1, 2)]
+    assert "parent" in d["cpu_baseline"]["measured_by"] and d["cpu_baseline"]["value"] > 0
+    assert "bench.py parent process" in d["config"]["launched_by"]
+    assert d["decrypt_check"] is True
+    assert abs(d["value"] - 5 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_never_reports_ranks_that_did_not_run(emu_lib):
+    """--gpus 2 with the self-launch disabled and no launcher, and --gpus 2 under a one-rank world: non-zero exit, no line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TFHE_BENCH_HANDOFF")}
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lib", emu_lib, "--backend", "gloo", "--total", "5",
+            "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--lwe-n", "24"]
+    out = subprocess.run(args + ["--no-self-launch"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "refusing" in out.stderr
+    out = subprocess.run(args, capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "WORLD_SIZE=1" in out.stderr
+
+
+def test_bench_post_region_sections_on_emulator(emu_lib):
+    """what the default one-GPU command measures after the timed region: BASELINE config 1 (latency through
+    tfhe_amd_bootstrap) and config 2's literal schedule (one launch per CMux), both bit-compared with the headline outputs"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", emu_lib, "--batch", "2", "--steps", "1",
+                          "--warmup", "0", "--no-cpu-baseline", "--extras-reps", "1", "--latency-batches", "1,2", "--lwe-n", "24"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    lat = d["config1_latency"]
+    assert lat["latency_batch1_ms"] > 0 and lat["latency_batch2_ms"] > 0
+    assert lat["batch1_identical_to_headline_outputs"] is True and lat["batch2_identical_to_headline_outputs"] is True
+    st = d["streamed_schedule"]
+    assert st["launches"] == 24 + 3 and st["identical_to_persistent"] is True and st["roofline"]["bound"] == "hbm"
+    assert st["roofline"]["algorithmic_bytes_per_launch"] == 2 * 16388 + 65536
+    assert st["hipgraph"].get("identical_to_persistent") is True
+    assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # never inside `value`
 
 
 def test_smoke_logic_on_emulator(emu_lib, monkeypatch):

@@ -9,7 +9,7 @@ OUT=gpurun_out/prof_$R
 mkdir -p "$OUT"
 # shellcheck disable=SC2068
 timeout 300 rocprofv3 --pmc $@ --output-format csv -d "$OUT/pmc_$TAG" -- \
-    python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/pmc_$TAG.json" 2> "$OUT/pmc_$TAG.err"
+    python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --headline-only ${BENCH_ARGS:-} > "$OUT/pmc_$TAG.json" 2> "$OUT/pmc_$TAG.err"
 echo "rc=$?"
 find "$OUT/pmc_$TAG" -name '*.db' -delete 2>/dev/null
 python3 - "$OUT/pmc_$TAG" <<'PY'

@@ -10,7 +10,7 @@ R=${1:-r02}; shift
 OUT=gpurun_out/prof_$R
 mkdir -p "$OUT"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
-    python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
+    python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only "$@" > "$OUT/bench_traced.json" 2> "$OUT/trace.err"
 echo "rc=$?"
 find "$OUT/trace" -name '*.db' -delete 2>/dev/null
 find "$OUT/trace" -name '*kernel_stats.csv' | head -1 | xargs -r head -12
