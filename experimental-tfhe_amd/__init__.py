@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_from_torus_d", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
     "tfhe_amd_set_bootstrap_key", "tfhe_amd_load_keyswitch_key",
     "tfhe_amd_ifft_int32", "tfhe_amd_ifft_torus64", "tfhe_amd_fft_torus32", "tfhe_amd_fft_torus64",
+    "tfhe_amd_ifft_f64", "tfhe_amd_fft_f64", "tfhe_amd_build_tables",
     "tfhe_amd_lagrange_addmul", "tfhe_amd_extern_mul", "tfhe_amd_device_info", "tfhe_amd_hp_twiddles", "tfhe_amd_hp_ifft", "tfhe_amd_hp_fft",
     "tfhe_amd_mux_rotate", "tfhe_amd_extern_mul_exact", "tfhe_amd_cmux", "tfhe_amd_lut_eval",
     "tfhe_amd_blind_rotate", "tfhe_amd_blind_rotate_extract", "tfhe_amd_bootstrap_woks",
@@ -103,6 +104,9 @@ def load_library(path=None):
     lib.tfhe_amd_ifft_torus64.argtypes = [vp, f64p, i64p, C.c_int]
     lib.tfhe_amd_fft_torus32.argtypes = [vp, i32p, f64p, C.c_int]
     lib.tfhe_amd_fft_torus64.argtypes = [vp, i64p, f64p, C.c_int]
+    lib.tfhe_amd_ifft_f64.argtypes = [vp, f64p, f64p, C.c_int]
+    lib.tfhe_amd_fft_f64.argtypes = [vp, f64p, f64p, C.c_int]
+    lib.tfhe_amd_build_tables.argtypes = [C.c_int, f64p, f64p]
     lib.tfhe_amd_lagrange_addmul.argtypes = [vp, f64p, f64p, f64p, C.c_int, C.c_int]
     lib.tfhe_amd_extern_mul.argtypes = [vp, vp, vp, C.c_int, C.c_int]
     lib.tfhe_amd_mux_rotate.argtypes = [vp, vp, vp, C.c_int, i32p, C.c_int]
@@ -319,6 +323,16 @@ class Engine:
     def fft_torus64(self, a):
         a = np.ascontiguousarray(a, np.float64).reshape(-1, self.params.N)
         return self._roundtrip(self.lib.tfhe_amd_fft_torus64, a, np.int64, a.shape, a.shape[0])
+
+    def ifft_f64(self, a):
+        """the reference's bare `ifft` (spqlios-fft.h:53) on [batch][N] doubles"""
+        a = np.ascontiguousarray(a, np.float64).reshape(-1, self.params.N)
+        return self._roundtrip(self.lib.tfhe_amd_ifft_f64, a, np.float64, a.shape, a.shape[0])
+
+    def fft_f64(self, a):
+        """the reference's bare `fft` (spqlios-fft.h:52): no 2/N scale, no rounding"""
+        a = np.ascontiguousarray(a, np.float64).reshape(-1, self.params.N)
+        return self._roundtrip(self.lib.tfhe_amd_fft_f64, a, np.float64, a.shape, a.shape[0])
 
     def lagrange_addmul(self, res, a, b, b_shared=False):
         res = np.ascontiguousarray(res, np.float64).reshape(-1, self.params.N)
@@ -554,6 +568,14 @@ class CircuitBootstrap:
 
 
 # ---- harness wrappers (host side of the ABI; usable without a GPU) --------------------
+def build_tables(N, lib_path=None):
+    """the reference-layout twiddle tables (fft, ifft) from the host-only builder: no context, no device"""
+    lib = load_library(lib_path)
+    f, r = np.empty(2 * N - 8), np.empty(2 * N - 8)
+    assert lib.tfhe_amd_build_tables(int(N), _np_ptr(f), _np_ptr(r)) == OK
+    return f, r
+
+
 def keygen_binary(n, seed, stream, lib_path=None):
     lib = load_library(lib_path)
     key = np.empty(n, np.int32)

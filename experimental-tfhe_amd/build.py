@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtfhe_amd.so")
 OUT_DROPIN = os.path.join(HERE, "libtfhe_amd_dropin.so")  # global-scope reference entry points (csrc/dropin_library.cpp)
+OUT_SPQLIOS = os.path.join(HERE, "libtfhe_amd_spqlios.so")  # the reference's FFT plugin symbols (csrc/spqlios_seam.cpp)
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SOURCES = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp"), os.path.join(CSRC, "hp_twiddles.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "devport.h"),
@@ -54,6 +55,27 @@ def build_dropin(engine_lib=None, out=None, force=False):
     return out
 
 
+def build_spqlios(engine_lib=None, out=None, force=False):
+    """libtfhe_amd_spqlios.so: FFT_Processor_Spqlios / fftp1024 / fftp2048 / LagrangeHalfCPolynomialAddMulASM / the
+    spqlios-fft.h C core, by the reference's own symbol names (include/tfhe_amd_spqlios.h), forwarding to the engine
+    library (default: the shipped one; tests link it against the emulation build).  rpath = $ORIGIN: it finds the
+    engine library next to itself wherever the tree is copied."""
+    engine_lib = engine_lib or OUT
+    out = out or OUT_SPQLIOS
+    src = os.path.join(CSRC, "spqlios_seam.cpp")
+    deps = [src, engine_lib, os.path.join(INCLUDE, "tfhe_amd_spqlios.h"), os.path.join(INCLUDE, "tfhe_amd.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    libdir, libname = os.path.dirname(engine_lib), os.path.basename(engine_lib)
+    rpath = "$ORIGIN" if os.path.abspath(libdir) == os.path.abspath(os.path.dirname(out)) else libdir
+    res = subprocess.run(["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-Wall", "-I" + INCLUDE, src, "-o", out, "-L" + libdir,
+                          "-l:" + libname, "-Wl,-rpath," + rpath], capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("g++ failed (spqlios seam library)")
+    return out
+
+
 def build(force=False, verbose=False, out=None, defines=()):
     """default: the shipped library.  `out` + `defines`: an experiment build for A/B timing (tools/ab.py),
     never loaded by default"""
@@ -65,6 +87,7 @@ def build(force=False, verbose=False, out=None, defines=()):
         return out
     if not force and not stale():
         build_dropin()
+        build_spqlios()
         return OUT
     cmd = [hipcc()] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + SOURCES + ["-o", OUT]
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -73,6 +96,7 @@ def build(force=False, verbose=False, out=None, defines=()):
     if res.returncode != 0:
         raise RuntimeError("hipcc failed")
     build_dropin(force=True)
+    build_spqlios(force=True)
     return OUT
 
 

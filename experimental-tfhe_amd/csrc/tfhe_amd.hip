@@ -690,6 +690,16 @@ int tfhe_amd_event_destroy(tfhe_amd_ctx *c, void *event) {
     return TFHE_AMD_OK;
 }
 
+int tfhe_amd_build_tables(int N, double *fft_trig, double *ifft_trig) {  // host only: no context, no device
+    if (N != 1024 && N != 2048) return TFHE_AMD_ERR_PARAM;
+    std::vector<double> f, r;
+    std::vector<double2> tw;
+    if (!build_tables(N, f, r, tw)) return TFHE_AMD_ERR_PARAM;
+    if (fft_trig) memcpy(fft_trig, f.data(), f.size() * 8);
+    if (ifft_trig) memcpy(ifft_trig, r.data(), r.size() * 8);
+    return TFHE_AMD_OK;
+}
+
 int tfhe_amd_get_tables(const tfhe_amd_ctx *c, double *fft_trig, double *ifft_trig) {
     if (!c) return TFHE_AMD_ERR_PARAM;
     if (fft_trig) memcpy(fft_trig, c->fft_trig.data(), c->fft_trig.size() * 8);
@@ -877,17 +887,37 @@ int tfhe_amd_ifft_torus64(tfhe_amd_ctx *c, double *out_d, const int64_t *in_d, i
     if (batch == 0) return TFHE_AMD_OK;
     return c->logn == 10 ? launch_ifft_t<int64_t, 10>(c, out_d, in_d, batch) : launch_ifft_t<int64_t, 11>(c, out_d, in_d, batch);
 }
+// k_fft_batch reads its input with 16-byte loads (tfhe_kernels.h): Lagrange-domain inputs must be 16-byte aligned
+#define REQUIRE_ALIGNED16(c, p) REQUIRE(c, ((uintptr_t)(p) & 15) == 0, "Lagrange-domain input must be 16-byte aligned")
 int tfhe_amd_fft_torus32(tfhe_amd_ctx *c, int32_t *out_d, const double *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
     ENTER(c);
+    REQUIRE_ALIGNED16(c, in_d);
     if (batch == 0) return TFHE_AMD_OK;
     return c->logn == 10 ? launch_fft_t<int32_t, 10>(c, out_d, in_d, batch) : launch_fft_t<int32_t, 11>(c, out_d, in_d, batch);
 }
 int tfhe_amd_fft_torus64(tfhe_amd_ctx *c, int64_t *out_d, const double *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
     ENTER(c);
+    REQUIRE_ALIGNED16(c, in_d);
     if (batch == 0) return TFHE_AMD_OK;
     return c->logn == 10 ? launch_fft_t<int64_t, 10>(c, out_d, in_d, batch) : launch_fft_t<int64_t, 11>(c, out_d, in_d, batch);
+}
+// the bare core transforms of spqlios-fft.h:52-53 (`ifft`, `fft`): N doubles -> N doubles, no conversion, no scale
+int tfhe_amd_ifft_f64(tfhe_amd_ctx *c, double *out_d, const double *in_d, int batch) {
+    if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    REQUIRE(c, out_d != in_d, "the transforms are out of place on the device");
+    if (batch == 0) return TFHE_AMD_OK;
+    return c->logn == 10 ? launch_ifft_t<double, 10>(c, out_d, in_d, batch) : launch_ifft_t<double, 11>(c, out_d, in_d, batch);
+}
+int tfhe_amd_fft_f64(tfhe_amd_ctx *c, double *out_d, const double *in_d, int batch) {
+    if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    REQUIRE_ALIGNED16(c, in_d);
+    REQUIRE(c, out_d != in_d, "the transforms are out of place on the device");
+    if (batch == 0) return TFHE_AMD_OK;
+    return c->logn == 10 ? launch_fft_t<double, 10>(c, out_d, in_d, batch) : launch_fft_t<double, 11>(c, out_d, in_d, batch);
 }
 int tfhe_amd_lagrange_addmul(tfhe_amd_ctx *c, double *res_d, const double *a_d, const double *b_d, int batch, int b_shared) {
     if (!c || !res_d || !a_d || !b_d || batch < 0) return TFHE_AMD_ERR_PARAM;

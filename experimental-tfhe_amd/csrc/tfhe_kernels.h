@@ -1546,7 +1546,8 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
 }
 
 // execute_direct_torus32 / _torus64: LagrangeHalfC -> torus coefficients (scale 2/N first); persistent waves
-// with the next polynomial requested ahead, as k_ifft_batch
+// with the next polynomial requested ahead, as k_ifft_batch.  TOUT = double: the bare core transform `fft` of
+// spqlios-fft.h:52 (no 2/N scale, no rounding: N doubles in, N doubles out) -- what the reference's C core exposes.
 template <typename TOUT, int LOGN, int WAVES, bool NT = false>
 TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     k_fft_batch(TOUT *__restrict__ out, const double *__restrict__ in, const double2 *__restrict__ twg, int batch) {
@@ -1558,6 +1559,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
     const int t = threadIdx.x & 63;
     const int stride = TFHE_UNIFORM((int)(gridDim.x * WAVES));
     int b = TFHE_UNIFORM((int)(blockIdx.x * WAVES) + wave);
+    constexpr bool RAW = std::is_same<TOUT, double>::value;
     const double scale = 2.0 / (double)N;  // fft_processor_spqlios.cpp:78
     double raw_r[PPL], raw_i[PPL];
     // Loads straight in the transform's input order (lane t holds the PPL consecutive points jC = PPL t + m of each
@@ -1589,35 +1591,44 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64)
         double xr[1][PPL], xi[1][PPL];
 #pragma unroll
         for (int m = 0; m < PPL; m++) {
-            xr[0][m] = raw_r[m] * scale;
-            xi[0][m] = raw_i[m] * scale;
+            xr[0][m] = RAW ? raw_r[m] : raw_r[m] * scale;
+            xi[0][m] = RAW ? raw_i[m] : raw_i[m] * scale;
         }
         if (b + stride < batch) request(b + stride);
         WaveFFT<LOGN>::template fft<1, TwLds<LOGN>>(xr, xi, twp, xch, t);
-        // rounding: the short exact sequences of the blind-rotation kernels (Torus<T>::from_double_fast), the
-        // reference's own form where the wave's guard trips (|x| >= 2^51 resp. 2^83)
-        TOUT *o = out + (size_t)b * N;
-        TOUT r0[PPL], r1[PPL];
-        uint32_t guard = 0;
-#pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            r0[m] = Torus<TOUT>::from_double_fast(xr[0][m], guard);
-            r1[m] = Torus<TOUT>::from_double_fast(xi[0][m], guard);
-        }
-        if (TFHE_WAVE_ANY(!Torus<TOUT>::guard_ok(guard))) {
-            TFHE_KEEP_BRANCH();
+        if constexpr (RAW) {
+            double *o = out + (size_t)b * N;
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
-                TFHE_OPAQUE(xr[0][m]);
-                TFHE_OPAQUE(xi[0][m]);
-                r0[m] = Torus<TOUT>::from_double(xr[0][m]);
-                r1[m] = Torus<TOUT>::from_double(xi[0][m]);
+                stream_store<NT>(xr[0][m], &o[G::jA(t, m)]);
+                stream_store<NT>(xi[0][m], &o[G::jA(t, m) + NC]);
             }
-        }
+        } else {
+            // rounding: the short exact sequences of the blind-rotation kernels (Torus<T>::from_double_fast), the
+            // reference's own form where the wave's guard trips (|x| >= 2^51 resp. 2^83)
+            TOUT *o = out + (size_t)b * N;
+            TOUT r0[PPL], r1[PPL];
+            uint32_t guard = 0;
 #pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            stream_store<NT>(r0[m], &o[G::jA(t, m)]);
-            stream_store<NT>(r1[m], &o[G::jA(t, m) + NC]);
+            for (int m = 0; m < PPL; m++) {
+                r0[m] = Torus<TOUT>::from_double_fast(xr[0][m], guard);
+                r1[m] = Torus<TOUT>::from_double_fast(xi[0][m], guard);
+            }
+            if (TFHE_WAVE_ANY(!Torus<TOUT>::guard_ok(guard))) {
+                TFHE_KEEP_BRANCH();
+#pragma unroll
+                for (int m = 0; m < PPL; m++) {
+                    TFHE_OPAQUE(xr[0][m]);
+                    TFHE_OPAQUE(xi[0][m]);
+                    r0[m] = Torus<TOUT>::from_double(xr[0][m]);
+                    r1[m] = Torus<TOUT>::from_double(xi[0][m]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                stream_store<NT>(r0[m], &o[G::jA(t, m)]);
+                stream_store<NT>(r1[m], &o[G::jA(t, m) + NC]);
+            }
         }
     }
 }

@@ -101,6 +101,8 @@ int tfhe_amd_event_destroy(tfhe_amd_ctx *ctx, void *event);
 /* twiddle tables as the reference lays them out (new_fft_table / new_ifft_table,
  * CB/spqlios/spqlios-fft-impl.cpp:158-193,400-437): 2N-8 doubles each; for SHA pinning. */
 int tfhe_amd_get_tables(const tfhe_amd_ctx *ctx, double *fft_trig, double *ifft_trig);
+/* the same two tables without a context or a device (host libm only), N in {1024, 2048}; either pointer may be NULL */
+int tfhe_amd_build_tables(int N, double *fft_trig, double *ifft_trig);
 
 /* device memory helpers so a host language needs no HIP binding of its own */
 int tfhe_amd_malloc(tfhe_amd_ctx *ctx, void **dptr, size_t bytes);
@@ -135,10 +137,18 @@ int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *ctx, const int32_t *ks);
 int tfhe_amd_ifft_int32(tfhe_amd_ctx *ctx, double *out_d, const int32_t *in_d, int batch);
 /* execute_reverse_torus64 */
 int tfhe_amd_ifft_torus64(tfhe_amd_ctx *ctx, double *out_d, const int64_t *in_d, int batch);
-/* execute_direct_torus32: scale by 2/N, fft, int32_t(int64_t(x)) */
+/* execute_direct_torus32: scale by 2/N, fft, int32_t(int64_t(x)).
+ * ALIGNMENT: the Lagrange-domain INPUT of the two direct transforms (and of tfhe_amd_fft_f64) is read with 16-byte
+ * loads: in_d must be 16-byte aligned (any hipMalloc / tfhe_amd_malloc pointer, and every polynomial of a batch
+ * behind it, is); a misaligned pointer is refused with TFHE_AMD_ERR_PARAM. */
 int tfhe_amd_fft_torus32(tfhe_amd_ctx *ctx, int32_t *out_d, const double *in_d, int batch);
 /* execute_direct_torus64 */
 int tfhe_amd_fft_torus64(tfhe_amd_ctx *ctx, int64_t *out_d, const double *in_d, int batch);
+/* the bare core transforms of the reference's C layer, `ifft(tables, data)` / `fft(tables, data)`
+ * (CB/spqlios/spqlios-fft.h:52-53; spqlios-ifft-fma.s, spqlios-fft-fma.s): [batch][N] doubles -> [batch][N] doubles,
+ * no integer conversion, no 2/N scale; out of place (out_d != in_d) */
+int tfhe_amd_ifft_f64(tfhe_amd_ctx *ctx, double *out_d, const double *in_d, int batch);
+int tfhe_amd_fft_f64(tfhe_amd_ctx *ctx, double *out_d, const double *in_d, int batch);
 /* LagrangeHalfCPolynomialAddMulASM: res[i] += a[i]*b[i] (b_shared != 0: b[0] for every i) */
 int tfhe_amd_lagrange_addmul(tfhe_amd_ctx *ctx, double *res_d, const double *a_d, const double *b_d,
                              int batch, int b_shared);

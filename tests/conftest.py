@@ -100,7 +100,7 @@ def _rank(item):
         return 0
     if fn == "test_gpu_parity.py":
         return 1
-    if fn in ("test_compat.py", "test_dropin.py"):
+    if fn in ("test_compat.py", "test_dropin.py", "test_spqlios_seam.py"):
         return 3
     return 2
 
@@ -117,7 +117,7 @@ def pytest_collection_finish(session):
     _install_tripwire()
     if not gpu_present():
         return
-    for mod in ("test_ref_batch", "test_compat", "test_dropin"):
+    for mod in ("test_ref_batch", "test_compat", "test_dropin", "test_spqlios_seam"):
         if any(os.path.basename(str(i.fspath)) == mod + ".py" for i in gpu_items):
             try:
                 importlib.import_module(mod).prerun_gpu_drivers()

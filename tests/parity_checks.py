@@ -82,6 +82,22 @@ def check_fft_plugin(lib_path, N, count=4, seed=11):
         # execute_direct_torus32 around and beyond the 2^51 bound of the short rounding sequence (per-wave fallback)
         for sc in (2.0 ** -40, 2.0 ** 8, 2.0 ** 11, 2.0 ** 14, 2.0 ** 40):
             assert np.array_equal(e.fft_torus32(lag32 * sc), O.execute_direct_torus32(N, lag32 * sc)), f"direct_torus32 x {sc}"
+        # the bare core transforms (spqlios-fft.h `ifft` / `fft`: doubles in, doubles out, no scale, no rounding)
+        raw = rs.standard_normal((count, N)) * 2.0 ** 20
+        assert same_doubles(e.ifft_f64(raw), O.ifft(N, raw)), "ifft (C core)"
+        assert same_doubles(e.fft_f64(raw), O.fft(N, raw)), "fft (C core)"
+        # spqlios-bench.cpp:76-77: fft(ifft(x)) = N/2 x (up to fp64 rounding)
+        assert np.abs(e.fft_f64(e.ifft_f64(dig.astype(np.float64))) - dig.astype(np.float64) * (N / 2)).max() < 1e-6
+        # host-only table builder == the context's tables
+        fb, rb = T.build_tables(N, lib_path=lib_path)
+        assert np.array_equal(fb.view(np.uint64), fo.view(np.uint64)) and np.array_equal(rb.view(np.uint64), ro.view(np.uint64))
+        # Lagrange-domain inputs are read with 16-byte loads: a misaligned device pointer is refused, not mis-read
+        d_in, d_out = e.to_device(np.zeros((2, N))), e.alloc(N * 8)
+        assert e.lib.tfhe_amd_fft_torus64(e.ctx, d_out.ptr, d_in.ptr + 8, 1) == T.ERR_PARAM
+        assert e.lib.tfhe_amd_fft_torus32(e.ctx, d_out.ptr, d_in.ptr + 8, 1) == T.ERR_PARAM
+        assert e.lib.tfhe_amd_fft_f64(e.ctx, d_out.ptr, d_in.ptr + 8, 1) == T.ERR_PARAM
+        d_in.free()
+        d_out.free()
         assert np.array_equal(e.fft_torus32(np.zeros((1, N))), np.zeros((1, N), np.int32))
         assert np.array_equal(e.fft_torus64(np.zeros((1, N))), np.zeros((1, N), np.int64))
         got = e.lagrange_addmul(lag32, O.execute_reverse_int(N, dig), O.execute_reverse_int(N, a32))
