@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "tfhe_amd_ctx_create", "tfhe_amd_ctx_destroy", "tfhe_amd_last_error", "tfhe_amd_version",
     "tfhe_amd_set_stream", "tfhe_amd_sync", "tfhe_amd_set_option", "tfhe_amd_get_tables",
     "tfhe_amd_event_create", "tfhe_amd_event_record", "tfhe_amd_event_elapsed_ms", "tfhe_amd_event_destroy",
-    "tfhe_amd_malloc", "tfhe_amd_free", "tfhe_amd_memcpy_h2d", "tfhe_amd_memcpy_d2h",
+    "tfhe_amd_malloc", "tfhe_amd_free", "tfhe_amd_memcpy_h2d", "tfhe_amd_memcpy_d2h", "tfhe_amd_host_alloc", "tfhe_amd_host_free",
     "tfhe_amd_gsw_from_fft", "tfhe_amd_gsw_from_torus", "tfhe_amd_gsw_from_torus_d", "tfhe_amd_gsw_free", "tfhe_amd_gsw_export_fft",
     "tfhe_amd_set_bootstrap_key", "tfhe_amd_load_keyswitch_key",
     "tfhe_amd_ifft_int32", "tfhe_amd_ifft_torus64", "tfhe_amd_fft_torus32", "tfhe_amd_fft_torus64",
@@ -90,6 +90,8 @@ def load_library(path=None):
     lib.tfhe_amd_event_destroy.argtypes = [vp, vp]
     lib.tfhe_amd_malloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
     lib.tfhe_amd_free.argtypes = [vp, vp]
+    lib.tfhe_amd_host_alloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
+    lib.tfhe_amd_host_free.argtypes = [vp, vp]
     lib.tfhe_amd_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
     lib.tfhe_amd_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     lib.tfhe_amd_gsw_from_fft.argtypes = [vp, f64p, C.c_int, C.POINTER(vp)]

@@ -29,6 +29,17 @@ void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, const T
 void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample) {
     tfhe_amd_compat::lweKeySwitch(result, ks, sample);
 }
+void tfhe_bootstrap_woKS_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
+                                   const LweSample *const *xs, int count) {
+    tfhe_amd_compat::tfhe_bootstrap_woKS_FFT_array(results, bk, mu, xs, count);
+}
+void tfhe_bootstrap_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
+                              const LweSample *const *xs, int count) {
+    tfhe_amd_compat::tfhe_bootstrap_FFT_array(results, bk, mu, xs, count);
+}
+void lweKeySwitch_array(LweSample *const *results, const LweKeySwitchKey *ks, const LweSample *const *samples, int count) {
+    tfhe_amd_compat::lweKeySwitch_array(results, ks, samples, count);
+}
 void tfhe_amd_dropin_release(const void *key_object) {
     if (key_object)
         tfhe_amd_compat::release(key_object);

@@ -4,7 +4,7 @@
 //     preModSwitch           :472-484
 //     circuitBootstrapWoKS   :530-659  (library rotation semantics)
 //     circuitPrivKS          :667-698
-//     tfhe_CircuitBootstrapFFT :823-873
+//     tfhe_CircuitBootstrapFFT :823-873  (+ _array: the driver loop :1009-1013 over `count` samples as one launch)
 //     CMux                   :877-879 (empty upstream)
 // These have C++ linkage on the PoC's own types, so this file is compiled NEXT TO the PoC's poc_types.h
 // (add it to the PoC's build in place of the bodies above) and linked with
@@ -42,6 +42,9 @@ void circuitPrivKS(TLweSample32 *result, const int u, const LweSample64 *x, cons
 }
 void tfhe_CircuitBootstrapFFT(TGswSample32 *result, const LweSample32 *sample, const Globals *env) {
     engine_of(env).tfhe_CircuitBootstrapFFT(result, sample);
+}
+void tfhe_CircuitBootstrapFFT_array(TGswSample32 *const *results, const LweSample32 *const *samples, const Globals *env, int count) {
+    engine_of(env).tfhe_CircuitBootstrapFFT_array(results, samples, count);
 }
 void CMux(TLweSample32 *out, const TGswSample32 *c, const TLweSample32 *in0, const TLweSample32 *in1, const Globals *env) {
     engine_of(env).CMux(out, c, in0, in1);

@@ -722,6 +722,21 @@ int tfhe_amd_free(tfhe_amd_ctx *c, void *dptr) {
     }
     return TFHE_AMD_OK;
 }
+int tfhe_amd_host_alloc(tfhe_amd_ctx *c, void **hptr, size_t bytes) {
+    if (!c || !hptr) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    HIPCHECK(c, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_host_free(tfhe_amd_ctx *c, void *hptr) {
+    if (!c) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    if (hptr) {
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        HIPCHECK(c, hipHostFree(hptr));
+    }
+    return TFHE_AMD_OK;
+}
 int tfhe_amd_memcpy_h2d(tfhe_amd_ctx *c, void *dst_d, const void *src, size_t bytes) {
     if (!c || (!dst_d && bytes) || (!src && bytes)) return TFHE_AMD_ERR_PARAM;
     ENTER(c);

@@ -107,6 +107,10 @@ int tfhe_amd_build_tables(int N, double *fft_trig, double *ifft_trig);
 /* device memory helpers so a host language needs no HIP binding of its own */
 int tfhe_amd_malloc(tfhe_amd_ctx *ctx, void **dptr, size_t bytes);
 int tfhe_amd_free(tfhe_amd_ctx *ctx, void *dptr);
+/* page-locked HOST memory (staging buffers of callers that hand over host data: copies from / to it run at the
+ * link's rate, and a gather into it replaces one copy per sample by one copy per batch) */
+int tfhe_amd_host_alloc(tfhe_amd_ctx *ctx, void **hptr, size_t bytes);
+int tfhe_amd_host_free(tfhe_amd_ctx *ctx, void *hptr);
 int tfhe_amd_memcpy_h2d(tfhe_amd_ctx *ctx, void *dst_d, const void *src, size_t bytes);
 int tfhe_amd_memcpy_d2h(tfhe_amd_ctx *ctx, void *dst, const void *src_d, size_t bytes);
 

@@ -21,8 +21,11 @@
 //       any structs with the same members.
 //
 // Like the reference these calls process ONE sample and are synchronous; they copy the sample
-// to the GPU and back, so they are for drop-in correctness, not throughput -- throughput code
-// calls the batch entry points of tfhe_amd.h directly.  Keys are uploaded once, the first time a
+// to the GPU and back, so they are for drop-in correctness, not throughput.  The ARRAY FORMS
+// (tfhe_bootstrap_FFT_array, tfhe_bootstrap_woKS_FFT_array, lweKeySwitch_array,
+// PocEngine::tfhe_CircuitBootstrapFFT_array) take the caller's whole loop of samples -- still on the
+// reference's struct types -- as one gather, one launch, one scatter: the batch engine's rate behind the
+// reference names; code that keeps its data on the GPU calls the batch entry points of tfhe_amd.h directly.  Keys are uploaded once, the first time a
 // key object is seen (keyed by its address), and stay resident until release().
 // Errors: the reference returns void and asserts/aborts (lwe_functions.cpp:480-481,
 // spqlios-fft-impl.cpp:92-97); the shims do the same (message on stderr, abort()).
@@ -72,6 +75,9 @@ struct Resident {
     tfhe_amd_gsw *gsw = nullptr;
     int n = 0, N = 0, l = 0;
     void *d_in = nullptr, *d_out = nullptr, *d_aux = nullptr;  // one-sample staging buffers
+    // array forms: pinned host staging + device buffers, grown on demand
+    void *h_in = nullptr, *h_out = nullptr, *da_in = nullptr, *da_out = nullptr;
+    size_t arr_in_bytes = 0, arr_out_bytes = 0;
 };
 struct ResidentKey {
     const void *obj, *ks;
@@ -155,8 +161,33 @@ inline Resident &attach_gsw(const GswT *bkFFT, int n, int N, int l, int Bgbit, c
     staging(R, sizeof(int32_t) * (size_t)(2 * N + n + 2));
     return reg.emplace(key, R).first->second;
 }
+// staging of the array forms: one gather into PINNED host memory, one copy each way
+inline void array_staging(tfhe_amd_ctx *ctx, void *&h_in, void *&da_in, size_t &have_in, size_t in_bytes, void *&h_out,
+                          void *&da_out, size_t &have_out, size_t out_bytes) {
+    if (have_in < in_bytes) {
+        if (h_in) tfhe_amd_host_free(ctx, h_in);
+        if (da_in) tfhe_amd_free(ctx, da_in);
+        check(tfhe_amd_host_alloc(ctx, &h_in, in_bytes), ctx, "host_alloc");
+        check(tfhe_amd_malloc(ctx, &da_in, in_bytes), ctx, "malloc");
+        have_in = in_bytes;
+    }
+    if (have_out < out_bytes) {
+        if (h_out) tfhe_amd_host_free(ctx, h_out);
+        if (da_out) tfhe_amd_free(ctx, da_out);
+        check(tfhe_amd_host_alloc(ctx, &h_out, out_bytes), ctx, "host_alloc");
+        check(tfhe_amd_malloc(ctx, &da_out, out_bytes), ctx, "malloc");
+        have_out = out_bytes;
+    }
+}
+inline void array_staging(Resident &R, size_t in_bytes, size_t out_bytes) {
+    array_staging(R.ctx, R.h_in, R.da_in, R.arr_in_bytes, in_bytes, R.h_out, R.da_out, R.arr_out_bytes, out_bytes);
+}
 inline void release_entry(std::map<ResidentKey, Resident>::iterator it) {
     Resident &R = it->second;
+    if (R.h_in) tfhe_amd_host_free(R.ctx, R.h_in);
+    if (R.h_out) tfhe_amd_host_free(R.ctx, R.h_out);
+    if (R.da_in) tfhe_amd_free(R.ctx, R.da_in);
+    if (R.da_out) tfhe_amd_free(R.ctx, R.da_out);
     tfhe_amd_free(R.ctx, R.d_in);
     tfhe_amd_free(R.ctx, R.d_out);
     tfhe_amd_free(R.ctx, R.d_aux);
@@ -247,7 +278,7 @@ inline void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, 
 }
 // lweKeySwitch(result, ks, sample): a key-switch key seen on its own gets its own resident engine
 // (input dimension ks->n must be a ring degree the engine supports: 1024 or 2048)
-inline void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample) {
+inline Resident &attach_ks(const LweKeySwitchKey *ks) {
     auto &reg = registry();
     const ResidentKey key{(const void *)ks, (const void *)ks, ks->out_params->n, ks->n, 0, 0};
     auto it = reg.find(key);
@@ -280,10 +311,61 @@ inline void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const Lwe
         staging(R, sizeof(int32_t) * (size_t)(2 * R.N + R.n + 2));
         it = reg.emplace(key, R).first;
     }
-    Resident &R = it->second;
+    return it->second;
+}
+inline void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample) {
+    Resident &R = attach_ks(ks);
     put_lwe(R, R.d_in, sample, R.N);
     check(tfhe_amd_keyswitch(R.ctx, (int32_t *)R.d_out, (const int32_t *)R.d_in, 1), R.ctx, "keyswitch");
     get_lwe(R, result, R.d_out, R.n);
+}
+
+// ---- array forms behind the reference names ----------------------------------------------------
+// The reference's unit is ONE sample per call (lwe_functions.cpp:434-446) and its drivers loop over samples
+// (poc:1009-1013; the only parallel construct: parallel/src/test_parallel_multiplications.cpp:62).  These take the
+// loop's `count` independent samples at once: one gather into a pinned staging buffer, one copy in, ONE launch, one
+// copy out, one scatter -- the same results as `count` one-sample calls, bit for bit, at the batch engine's rate.
+// results[c] / xs[c] are the loop's own objects (caller-allocated, as for the one-sample functions).
+inline void gather_lwe(int32_t *dst, const LweSample *const *xs, int count, int n) {
+    for (int c = 0; c < count; c++) {
+        std::memcpy(dst + (size_t)c * (n + 1), xs[c]->a, sizeof(int32_t) * (size_t)n);
+        dst[(size_t)c * (n + 1) + n] = xs[c]->b;
+    }
+}
+inline void scatter_lwe(LweSample *const *results, const int32_t *src, int count, int n) {
+    for (int c = 0; c < count; c++) {
+        std::memcpy(results[c]->a, src + (size_t)c * (n + 1), sizeof(int32_t) * (size_t)n);
+        results[c]->b = src[(size_t)c * (n + 1) + n];
+    }
+}
+template <class Launch>
+inline void lwe_array_call(Resident &R, LweSample *const *results, int n_out, const LweSample *const *xs, int n_in, int count,
+                           Launch launch, const char *what) {
+    if (count <= 0) return;
+    const size_t in_bytes = sizeof(int32_t) * (size_t)count * (n_in + 1), out_bytes = sizeof(int32_t) * (size_t)count * (n_out + 1);
+    array_staging(R, in_bytes, out_bytes);
+    gather_lwe((int32_t *)R.h_in, xs, count, n_in);
+    check(tfhe_amd_memcpy_h2d(R.ctx, R.da_in, R.h_in, in_bytes), R.ctx, "h2d");
+    check(launch((int32_t *)R.da_out, (const int32_t *)R.da_in), R.ctx, what);
+    check(tfhe_amd_memcpy_d2h(R.ctx, R.h_out, R.da_out, out_bytes), R.ctx, "d2h");
+    scatter_lwe(results, (const int32_t *)R.h_out, count, n_out);
+}
+inline void tfhe_bootstrap_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
+                                     const LweSample *const *xs, int count) {
+    Resident &R = attach(bk);
+    lwe_array_call(R, results, R.n, xs, R.n, count,
+                   [&](int32_t *o, const int32_t *i) { return tfhe_amd_bootstrap(R.ctx, o, mu, i, count); }, "bootstrap (array)");
+}
+inline void tfhe_bootstrap_woKS_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
+                                          const LweSample *const *xs, int count) {
+    Resident &R = attach(bk);
+    lwe_array_call(R, results, R.N, xs, R.n, count,
+                   [&](int32_t *o, const int32_t *i) { return tfhe_amd_bootstrap_woks(R.ctx, o, mu, i, count); }, "bootstrap_woks (array)");
+}
+inline void lweKeySwitch_array(LweSample *const *results, const LweKeySwitchKey *ks, const LweSample *const *samples, int count) {
+    Resident &R = attach_ks(ks);
+    lwe_array_call(R, results, R.n, samples, R.N, count,
+                   [&](int32_t *o, const int32_t *i) { return tfhe_amd_keyswitch(R.ctx, o, i, count); }, "keyswitch (array)");
 }
 
 // ---- FFT plugin look-alike (CB/spqlios/lagrangehalfc_impl.h:8-31) -----------------------------
@@ -354,7 +436,8 @@ class FFT_Processor_AMD {
 template <class GlobalsT>
 class PocEngine {
    public:
-    explicit PocEngine(const GlobalsT *env, int device = 0) : cb_(nullptr) {
+    explicit PocEngine(const GlobalsT *env, int device = 0)
+        : cb_(nullptr), h_in_(nullptr), h_out_(nullptr), da_in_(nullptr), da_out_(nullptr), arr_in_bytes_(0), arr_out_bytes_(0) {
         tfhe_amd_cb_params p;
         p.n0 = env->n_lvl0;
         p.N1 = env->n_lvl1;
@@ -406,6 +489,10 @@ class PocEngine {
     }
     ~PocEngine() {
         if (cb_) {
+            if (h_in_) tfhe_amd_host_free(c2_, h_in_);
+            if (h_out_) tfhe_amd_host_free(c2_, h_out_);
+            if (da_in_) tfhe_amd_free(c2_, da_in_);
+            if (da_out_) tfhe_amd_free(c2_, da_out_);
             tfhe_amd_free(c2_, d_a_);
             tfhe_amd_free(c2_, d_b_);
             tfhe_amd_cb_destroy(cb_);
@@ -423,6 +510,27 @@ class PocEngine {
                 for (int q = 0; q < 2; q++)
                     std::memcpy(result->samples[u][w].a[q].coefs, &f[(((size_t)u * p_.l1 + w) * 2 + q) * p_.N1],
                                 sizeof(int32_t) * (size_t)p_.N1);
+    }
+    // The driver loop of poc:1009-1013 over `count` samples as ONE launch: gather into pinned staging, one copy in,
+    // tfhe_amd_circuit_bootstrap on the batch, one copy out, scatter into the caller's TGswSample32 objects.
+    template <class TGswSample32T, class LweSample32T>
+    void tfhe_CircuitBootstrapFFT_array(TGswSample32T *const *results, const LweSample32T *const *samples, int count) {
+        if (count <= 0) return;
+        const size_t rin = (size_t)p_.N1 + 1, rout = (size_t)2 * p_.l1 * 2 * p_.N1;
+        array_staging(c2_, h_in_, da_in_, arr_in_bytes_, sizeof(int32_t) * rin * count, h_out_, da_out_, arr_out_bytes_,
+                      sizeof(int32_t) * rout * count);
+        int32_t *hi = (int32_t *)h_in_;
+        for (int c = 0; c < count; c++) std::memcpy(hi + (size_t)c * rin, samples[c]->a, sizeof(int32_t) * rin);
+        check(tfhe_amd_memcpy_h2d(c2_, da_in_, h_in_, sizeof(int32_t) * rin * count), c2_, "h2d");
+        die(tfhe_amd_circuit_bootstrap(cb_, (int32_t *)da_out_, (const int32_t *)da_in_, count), "circuit_bootstrap (array)");
+        check(tfhe_amd_memcpy_d2h(c2_, h_out_, da_out_, sizeof(int32_t) * rout * count), c2_, "d2h");
+        const int32_t *ho = (const int32_t *)h_out_;
+        for (int c = 0; c < count; c++)
+            for (int u = 0; u < 2; u++)
+                for (int w = 0; w < p_.l1; w++)
+                    for (int q = 0; q < 2; q++)
+                        std::memcpy(results[c]->samples[u][w].a[q].coefs,
+                                    ho + (size_t)c * rout + (((size_t)u * p_.l1 + w) * 2 + q) * p_.N1, sizeof(int32_t) * (size_t)p_.N1);
     }
     // circuitBootstrapWoKS(LweSample64* result, Torus64 mu, const int* abar, env)   poc:530-659
     template <class LweSample64T>
@@ -493,6 +601,8 @@ class PocEngine {
     tfhe_amd_cb_params p_;
     tfhe_amd_ctx *c2_, *c10_;
     void *d_a_, *d_b_;
+    void *h_in_, *h_out_, *da_in_, *da_out_;  // array form: pinned host staging + device buffers
+    size_t arr_in_bytes_, arr_out_bytes_;
 };
 
 }  // namespace tfhe_amd_compat

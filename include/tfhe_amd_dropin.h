@@ -13,7 +13,7 @@
 //   upstream headers defines TFHE_AMD_DROPIN_NO_LIBRARY_TYPES before including this file.
 // PoC form (C++ linkage, types of CB/poc_types.h, `const Globals* env` kept):
 //     preKeySwitch :437   preModSwitch :472   circuitBootstrapWoKS :530   circuitPrivKS :667
-//     tfhe_CircuitBootstrapFFT :823
+//     tfhe_CircuitBootstrapFFT :823   (+ tfhe_CircuitBootstrapFFT_array: the driver loop poc:1009-1013 as one launch)
 //   Declared here when TFHE_AMD_DROPIN_POC is defined AFTER poc_types.h has been included; they are
 //   defined by experimental-tfhe_amd/csrc/dropin_poc.cpp, which a PoC build compiles next to its own
 //   poc_types.h (C++ linkage on user types cannot be pre-built).  The engine behind an `env` is created
@@ -39,6 +39,14 @@ void tfhe_bootstrap_woKS_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk
 void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x);
 void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, const TGswParams *params);
 void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample);
+/* ARRAY FORMS: the caller's loop over `count` independent samples (the reference's drivers loop over one-sample calls,
+ * poc:1009-1013; parallel/src/test_parallel_multiplications.cpp:62) as one gather, ONE launch, one scatter.
+ * results[c] / xs[c]: the loop's own caller-allocated objects; same results as `count` one-sample calls, bit for bit. */
+void tfhe_bootstrap_woKS_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
+                                   const LweSample *const *xs, int count);
+void tfhe_bootstrap_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
+                              const LweSample *const *xs, int count);
+void lweKeySwitch_array(LweSample *const *results, const LweKeySwitchKey *ks, const LweSample *const *samples, int count);
 /* frees every GPU-resident copy made for this key object (bk, bkFFT array or ks); NULL: all of them */
 void tfhe_amd_dropin_release(const void *key_object);
 /* GPU ordinal used by engines created from now on (default 0) */
@@ -50,6 +58,8 @@ void preModSwitch(int *result, const LweSample32 *x, const Globals *env);
 void circuitBootstrapWoKS(LweSample64 *result, const Torus64 mu, const int *abar, const Globals *env);
 void circuitPrivKS(TLweSample32 *result, const int u, const LweSample64 *x, const Globals *env);
 void tfhe_CircuitBootstrapFFT(TGswSample32 *result, const LweSample32 *sample, const Globals *env);
+/* array form of the driver loop poc:1009-1013: `count` circuit bootstraps as one launch */
+void tfhe_CircuitBootstrapFFT_array(TGswSample32 *const *results, const LweSample32 *const *samples, const Globals *env, int count);
 /* the reference declares CMux and leaves its body empty (poc:877-879): out = c ? in1 : in0 */
 void CMux(TLweSample32 *out, const TGswSample32 *c, const TLweSample32 *in0, const TLweSample32 *in1, const Globals *env);
 void tfhe_amd_dropin_release(const Globals *env);

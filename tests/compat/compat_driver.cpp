@@ -5,9 +5,13 @@
 //
 //   compat_driver lib   <in.bin> <out.bin>     library-form functions + FFT plugin look-alike
 //   compat_driver poc   <in.bin> <out.bin>     PoC-form functions (PocEngine<Globals>)
+//   compat_driver arr   <in.bin> <out.bin>     ARRAY forms (tfhe_bootstrap_FFT_array, tfhe_bootstrap_woKS_FFT_array,
+//                                              lweKeySwitch_array) against the one-by-one loop over the same samples:
+//                                              exits 3 when they differ; prints count / seconds of both on stdout
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -190,6 +194,106 @@ static int run_lib(const char *inp, const char *outp) {
 #endif
 }
 
+// ---------------------------------------------------------------- array forms
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static int run_arr(const char *inp, const char *outp) {
+    auto blob = slurp(inp);
+    In in{blob.data()};
+    const int32_t *hdr = in.take<int32_t>(8);  // n N l Bgbit ks_t ks_bb count mu   (same file as `lib`)
+    const int n = hdr[0], N = hdr[1], l = hdr[2], Bgbit = hdr[3], t = hdr[4], bb = hdr[5], count = hdr[6];
+    const Torus32 mu = hdr[7];
+    const int kpl = 2 * l, base = 1 << bb;
+    const double *bkflat = in.take<double>((size_t)n * kpl * 2 * N);
+    const int32_t *ksflat = in.take<int32_t>((size_t)N * t * base * (n + 1));
+    const int32_t *xs = in.take<int32_t>((size_t)count * (n + 1));
+    LweParams in_out{n, 0, 0};
+    TLweParams tlwe{N, 1, 0, 0, LweParams{N, 0, 0}};
+    TGswParams gp;
+    memset(&gp, 0, sizeof(gp));
+    gp.l = l;
+    gp.Bgbit = Bgbit;
+    gp.Bg = 1 << Bgbit;
+    gp.tlwe_params = &tlwe;
+    gp.kpl = kpl;
+    std::vector<LagrangeHalfCPolynomial> polys((size_t)n * kpl * 2);
+    std::vector<TLweSampleFFT> rows((size_t)n * kpl);
+    std::vector<TGswSampleFFT> gsw((size_t)n);
+    for (int i = 0; i < n; i++) {
+        for (int r = 0; r < kpl; r++) {
+            for (int q = 0; q < 2; q++)
+                polys[((size_t)i * kpl + r) * 2 + q].values = (double *)bkflat + (((size_t)i * kpl + r) * 2 + q) * N;
+            TLweSampleFFT &row = rows[(size_t)i * kpl + r];
+            row.a = &polys[((size_t)i * kpl + r) * 2];
+            row.b = row.a + 1;
+            row.k = 1;
+        }
+        gsw[i].all_samples = &rows[(size_t)i * kpl];
+        gsw[i].sample = nullptr;
+        gsw[i].k = 1;
+        gsw[i].l = l;
+    }
+    std::vector<LweSample> ks0((size_t)N * t * base);
+    std::vector<LweSample *> ks1((size_t)N * t);
+    std::vector<LweSample **> ks2((size_t)N);
+    for (size_t e = 0; e < ks0.size(); e++) {
+        ks0[e].a = (Torus32 *)ksflat + e * (n + 1);
+        ks0[e].b = ksflat[e * (n + 1) + n];
+    }
+    for (size_t e = 0; e < ks1.size(); e++) ks1[e] = &ks0[e * base];
+    for (int i = 0; i < N; i++) ks2[i] = &ks1[(size_t)i * t];
+    LweKeySwitchKey ksk{N, t, bb, base, &in_out, ks0.data(), ks1.data(), ks2.data()};
+    LweBootstrappingKeyFFT bk{&in_out, &gp, &tlwe, &tlwe.extracted_lweparams, gsw.data(), &ksk};
+
+    // the caller's loop objects: count inputs, count outputs of each kind
+    std::vector<LweSample> x((size_t)count), ra((size_t)count), rl((size_t)count), ru((size_t)count), rk((size_t)count);
+    std::vector<const LweSample *> xp((size_t)count), up((size_t)count);
+    std::vector<LweSample *> rap((size_t)count), rup((size_t)count), rkp((size_t)count);
+    std::vector<Torus32> a_arr((size_t)count * n), a_loop((size_t)count * n), a_woks((size_t)count * N), a_ks((size_t)count * n);
+    for (int c = 0; c < count; c++) {
+        x[c] = LweSample{(Torus32 *)xs + (size_t)c * (n + 1), xs[(size_t)c * (n + 1) + n], 0};
+        ra[c] = LweSample{a_arr.data() + (size_t)c * n, 0, 0};
+        rl[c] = LweSample{a_loop.data() + (size_t)c * n, 0, 0};
+        ru[c] = LweSample{a_woks.data() + (size_t)c * N, 0, 0};
+        rk[c] = LweSample{a_ks.data() + (size_t)c * n, 0, 0};
+        xp[c] = &x[c];
+        rap[c] = &ra[c];
+        rup[c] = &ru[c];
+        up[c] = &ru[c];
+        rkp[c] = &rk[c];
+    }
+    // first call: uploads the keys (once per key object) and sizes the staging buffers
+    tfhe_bootstrap_FFT_array(rap.data(), &bk, mu, xp.data(), count);
+    const double t0 = now_s();
+    tfhe_bootstrap_FFT_array(rap.data(), &bk, mu, xp.data(), count);  // gather + PCIe + one launch + PCIe + scatter
+    const double t_arr = now_s() - t0;
+    // the two halves as array forms, chained: woKS then the key switch on its outputs == the full bootstrap
+    tfhe_bootstrap_woKS_FFT_array(rup.data(), &bk, mu, xp.data(), count);
+    lweKeySwitch_array(rkp.data(), &ksk, up.data(), count);
+    // the reference's own schedule: one sample per call
+    const double t1 = now_s();
+    for (int c = 0; c < count; c++) tfhe_bootstrap_FFT(&rl[c], &bk, mu, &x[c]);
+    const double t_loop = now_s() - t1;
+    bool same = a_arr == a_loop && a_ks == a_loop;
+    for (int c = 0; c < count; c++) same = same && ra[c].b == rl[c].b && rk[c].b == rl[c].b;
+    Out out;
+    for (int c = 0; c < count; c++) {
+        out.put(ra[c].a, 4 * (size_t)n);
+        out.put(&ra[c].b, 4);
+    }
+    out.save(outp);
+    printf("{\"count\": %d, \"array_seconds\": %.6f, \"array_bootstraps_per_s\": %.1f, \"loop_seconds\": %.6f, "
+           "\"loop_bootstraps_per_s\": %.1f, \"array_identical_to_loop\": %s}\n",
+           count, t_arr, count / t_arr, t_loop, count / t_loop, same ? "true" : "false");
+#ifdef DROPIN
+    tfhe_amd_dropin_release(nullptr);
+#else
+    release_all();
+#endif
+    return same ? 0 : 3;
+}
+
 #ifndef DROPIN
 // ---------------------------------------------------------------- PoC form
 // mirrors of the member names of CB/poc_types.h (the real header works the same way)
@@ -305,6 +409,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: %s lib|poc in.bin out.bin\n", argv[0]);
         return 2;
     }
+    if (std::string(argv[1]) == "arr") return run_arr(argv[2], argv[3]);
 #ifdef DROPIN
     return run_lib(argv[2], argv[3]);
 #else

@@ -18,6 +18,7 @@ void preModSwitch(int* result, const LweSample32* x, const Globals* env);
 void circuitBootstrapWoKS(LweSample64* result, const Torus64 mu, const int* abar, const Globals* env);
 void circuitPrivKS(TLweSample32* result, const int u, const LweSample64* x, const Globals* env);
 void tfhe_CircuitBootstrapFFT(TGswSample32* result, const LweSample32* sample, const Globals* env);
+void tfhe_CircuitBootstrapFFT_array(TGswSample32* const* results, const LweSample32* const* samples, const Globals* env, int count);
 void CMux(TLweSample32* out, const TGswSample32* c, const TLweSample32* in0, const TLweSample32* in1, const Globals* env);
 
 const int Globals::n_lvl0 = P_N0;
@@ -105,6 +106,7 @@ int main(int argc, char **argv) {
     }
     std::vector<uint8_t> out;
     auto put = [&](const void *q, size_t n) { out.insert(out.end(), (const uint8_t *)q, (const uint8_t *)q + n); };
+    std::vector<int32_t> loop_cb;  // the one-by-one circuit bootstraps, for the array form below
     for (int c = 0; c < count; c++) {
         LweSample32 x(N1), pre(n0);
         memcpy(x.a, xs + (size_t)c * (N1 + 1), 4 * (size_t)(N1 + 1));
@@ -124,10 +126,33 @@ int main(int argc, char **argv) {
         tfhe_CircuitBootstrapFFT(&tg, &x, env);
         for (int u = 0; u < 2; u++)
             for (int w = 0; w < l1; w++)
-                for (int q = 0; q < 2; q++) put(tg.samples[u][w].a[q].coefs, 4 * (size_t)N1);
+                for (int q = 0; q < 2; q++) {
+                    put(tg.samples[u][w].a[q].coefs, 4 * (size_t)N1);
+                    loop_cb.insert(loop_cb.end(), tg.samples[u][w].a[q].coefs, tg.samples[u][w].a[q].coefs + N1);
+                }
         TLweSample32 mux(N1);
         CMux(&mux, &tg, &tg.allsamples[0], &tg.allsamples[2 * l1 - 1], env);
         for (int q = 0; q < 2; q++) put(mux.a[q].coefs, 4 * (size_t)N1);
+    }
+    {   // the driver loop above as ONE launch: tfhe_CircuitBootstrapFFT_array must give the loop's results
+        std::vector<LweSample32 *> xin((size_t)count);
+        std::vector<TGswSample32 *> res((size_t)count);
+        for (int c = 0; c < count; c++) {
+            xin[c] = new LweSample32(N1);
+            memcpy(xin[c]->a, xs + (size_t)c * (N1 + 1), 4 * (size_t)(N1 + 1));
+            res[c] = new TGswSample32(l1, N1);
+        }
+        tfhe_CircuitBootstrapFFT_array(res.data(), xin.data(), env, count);
+        std::vector<int32_t> arr_cb;
+        for (int c = 0; c < count; c++)
+            for (int u = 0; u < 2; u++)
+                for (int w = 0; w < l1; w++)
+                    for (int q = 0; q < 2; q++)
+                        arr_cb.insert(arr_cb.end(), res[c]->samples[u][w].a[q].coefs, res[c]->samples[u][w].a[q].coefs + N1);
+        if (arr_cb != loop_cb) {
+            fprintf(stderr, "tfhe_CircuitBootstrapFFT_array differs from the one-by-one loop\n");
+            return 3;
+        }
     }
     FILE *f = fopen(argv[2], "wb");
     fwrite(out.data(), 1, out.size(), f);

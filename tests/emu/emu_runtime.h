@@ -120,6 +120,9 @@ static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *d) { *d = 1; return hipSuccess; }
 hipError_t hipMalloc(void **p, size_t bytes);
 hipError_t hipFree(void *p);
+enum { hipHostMallocDefault = 0 };
+static inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }  // "pinned" = plain host memory here
+static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t);  // recorded while a capture is open
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }

@@ -132,6 +132,46 @@ def run_poc_form(driver, tmp_path, n0=3, N1=1024, N2=1024, l1=2, bg1=8, l2=3, bg
     assert pos == len(raw)
 
 
+def run_array_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=6, phase="both", inputs=None):
+    """`compat_driver arr`: the array forms behind the reference names (tfhe_bootstrap_FFT_array, tfhe_bootstrap_woKS_FFT_array
+    + lweKeySwitch_array) against the driver's own one-by-one loop (exit code 3 if they differ) and against the oracle.
+    inputs: (bk, ks, x) to use instead of the generated ones (the GPU leg shares test_ref_batch's full-size set)."""
+    import json
+    mu = 1 << 29
+    if inputs is None:
+        lk, tk = O.keygen_binary(n, SEED, 1), O.keygen_binary(N, SEED, 2)
+        bk = O.bk_create32(N, lk, tk, l, Bgbit, 2.0 ** -25, SEED, 1000)
+        ks = O.ks_create32(tk, lk, t, bb, 2.0 ** -15, SEED, 100000)
+        x = np.stack([O.lwe_encrypt32(mu if i % 2 else -mu, 2.0 ** -15, lk, O.rng(SEED, 40 + i)) for i in range(count)])
+    else:
+        bk, ks, x = inputs
+        count = x.shape[0]
+    hdr = np.array([n, N, l, Bgbit, t, bb, count, mu], np.int32)
+    fi, fo, fs = (os.path.join(str(tmp_path), f) for f in ("arr_in.bin", "arr_out.bin", "arr_stats.json"))
+    if phase in ("run", "both"):
+        with open(fi, "wb") as f:
+            for a in (hdr, bk, ks, x):
+                f.write(np.ascontiguousarray(a).tobytes())
+        res = subprocess.run([driver, "arr", fi, fo], stdout=subprocess.PIPE, text=True)
+        os.remove(fi)
+        with open(fs, "w") as f:
+            f.write(res.stdout)
+        if res.returncode:
+            raise RuntimeError(f"compat_driver arr failed ({res.returncode}): {res.stdout}")
+        if phase == "run":
+            return None
+    stats = json.loads(open(fs).read())
+    assert stats["count"] == count and stats["array_identical_to_loop"] is True
+    got = np.fromfile(fo, np.int32).reshape(count, n + 1)
+    return stats, got, (bk, ks, x)
+
+
+def test_array_forms_emu(emu_lib, tmp_path):
+    stats, got, (bk, ks, x) = run_array_form(build_driver(emu_lib, "emu"), tmp_path)
+    want = np.stack([O.bootstrap32(1024, bk, ks, 1 << 29, x[c], 2, 10, 8, 2) for c in range(x.shape[0])])
+    assert np.array_equal(got, want), "tfhe_bootstrap_FFT_array"
+
+
 def test_library_form_shims_emu(emu_lib, tmp_path):
     run_lib_form(build_driver(emu_lib, "emu"), tmp_path)
 
@@ -159,6 +199,15 @@ def prerun_gpu_drivers():
             if os.path.exists(os.path.join(d, f)):
                 os.remove(os.path.join(d, f))
         fn(drv, d, phase="run", **args)
+    # array forms at BASELINE config 2's size: 4096 gate bootstraps (n = 630) through tfhe_bootstrap_FFT_array, the same
+    # 4096 one by one through tfhe_bootstrap_FFT; inputs = test_ref_batch's (whose reference outputs the test compares with)
+    import test_ref_batch as RB
+    d = os.path.join(GPU_RUN_DIR, "arr")
+    os.makedirs(d, exist_ok=True)
+    for f in os.listdir(d):
+        os.remove(os.path.join(d, f))
+    lk, bk, ks, x = RB._inputs()
+    run_array_form(drv, d, n=RB.n, inputs=(bk, ks, x), phase="run")
 
 
 def _need(form):
@@ -177,6 +226,33 @@ def test_library_form_shims_gpu():
 @pytest.mark.gpu
 def test_poc_form_shims_gpu():
     run_poc_form(None, _need("poc"), phase="check", **GPU_POC_ARGS)
+
+
+@pytest.mark.gpu
+def test_array_forms_gpu():
+    """4096 gate bootstraps behind the reference's struct types in ONE launch: identical to the one-by-one loop (checked by the
+    driver), to the compiled reference (all 4096, where test_ref_batch's reference run is present) or the oracle (a sample of
+    them), and >= 100 k bootstraps/s END TO END -- gather, PCIe both ways, launch, scatter -- where the loop gives ~400/s."""
+    import test_ref_batch as RB
+    d = _need_arr()
+    lk, bk, ks, x = RB._inputs()
+    stats, got, _ = run_array_form(None, d, n=RB.n, inputs=(bk, ks, x), phase="check")
+    assert stats["count"] == RB.BATCH
+    if os.path.exists(os.path.join(RB.RUN_DIR, "done")):
+        outs = sorted(f for f in os.listdir(RB.RUN_DIR) if f.startswith("out_"))
+        want = np.concatenate([np.fromfile(os.path.join(RB.RUN_DIR, f), np.int32) for f in outs]).reshape(RB.BATCH, RB.n + 1)
+        assert np.array_equal(got, want), "tfhe_bootstrap_FFT_array vs the compiled reference, 4096 samples"
+    else:
+        for c in (0, 1, 63, 64, 2047, 4095):
+            assert np.array_equal(got[c], O.bootstrap32(RB.N, bk, ks, RB.MU, x[c], RB.l, RB.Bgbit, RB.t, RB.bb)), c
+    assert stats["array_bootstraps_per_s"] >= 100e3, stats
+    assert stats["array_bootstraps_per_s"] > 50 * stats["loop_bootstraps_per_s"], stats
+
+
+def _need_arr():
+    d = os.path.join(GPU_RUN_DIR, "arr")
+    assert os.path.exists(os.path.join(d, "arr_stats.json")), "the array-form driver did not run before the session's GPU tests"
+    return d
 
 
 REF_SRC = "/root/reference/circuit-bootstrapping/src"

@@ -73,6 +73,15 @@ def test_library_form_literal_dropin_emu(emu_lib, tmp_path):
     TC.run_lib_form(build_lib_driver(emu_lib, "emu"), tmp_path, plugin=False, **LIB_EMU)
 
 
+def test_array_forms_literal_dropin_emu(emu_lib, tmp_path):
+    """extern "C" tfhe_bootstrap_FFT_array / tfhe_bootstrap_woKS_FFT_array / lweKeySwitch_array of libtfhe_amd_dropin.so"""
+    import numpy as np
+    import oracle_py as O
+    stats, got, (bk, ks, x) = TC.run_array_form(build_lib_driver(emu_lib, "emu"), tmp_path, n=4, count=5)
+    want = np.stack([O.bootstrap32(1024, bk, ks, 1 << 29, x[c], 2, 10, 8, 2) for c in range(5)])
+    assert np.array_equal(got, want)
+
+
 def test_poc_form_literal_dropin_emu(emu_lib, tmp_path):
     """driver + forwarding source compiled against the reference's OWN poc_types.h where /root/reference
     exists (this container), against the stand-in header elsewhere"""
