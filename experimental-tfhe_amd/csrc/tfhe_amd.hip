@@ -49,7 +49,7 @@ struct tfhe_amd_ctx {
     // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
     // hipGraph and replayed while the call's arguments stay the same
     bool streamed_graph;
-    unsigned streamed_warm;  // bit v: schedule variant v has run uncaptured once
+    unsigned streamed_warm;  // bit 3 * ks_gather + blind-rotation kernel class: that schedule variant has run uncaptured once
     struct {
         void *exec;  // hipGraphExec_t
         const void *x, *out;
@@ -220,6 +220,11 @@ bool br_split_applies(const tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) 
     if ((a.flags & (BR_NO_ROTATE | BR_CMUX_DATA)) || a.gsw_sel || a.sel_div > 0) return false;
     const int limit = c->br_split_max < 0 ? BR_SPLIT_AUTO_MAX : c->br_split_max;
     return a.batch <= limit;
+}
+// which of the three forms above serves this call: 0 = k_blind_rotate_split, 1 = 4-wave workgroups, 2 = 8-wave workgroups
+int br32_class(const tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
+    if (br_split_applies(c, a)) return 0;
+    return (c->logn == 10 && a.batch <= BR_LONE_WAVE_MAX) ? 1 : 2;
 }
 int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
     if (br_split_applies(c, a)) {
@@ -1151,7 +1156,11 @@ int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, con
         // and let the first call of each schedule variant run as plain launches
         if (int rc = grow(c, &c->ws_lwe, &c->ws_lwe_bytes, (size_t)batch * (c->p.N + 1) * 4)) return rc;
         if (int rc = grow(c, &c->ws_acc, &c->ws_acc_bytes, (size_t)batch * 2 * c->p.N * 4)) return rc;
-        const unsigned vbit = c->ks_force_gather ? 2u : 1u;
+        // one warm-up per (key-switch variant, blind-rotation kernel class): the class follows the batch size, and the
+        // first launch of a kernel sets its LDS attribute (hipFuncSetAttribute), which must not happen inside a capture
+        BlindRotateArgs<int32_t> probe;
+        fill_common(c, probe, c->bk, 0, 1, batch);
+        const unsigned vbit = 1u << ((c->ks_force_gather ? 3 : 0) + br32_class(c, probe));
         if (!(c->streamed_warm & vbit)) {
             c->streamed_warm |= vbit;
             return streamed_plain(c, out_d, mu, x_d, batch);

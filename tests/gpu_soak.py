@@ -37,7 +37,7 @@ def main():
     runs = 0
     while time.time() < t_end:
         seed = rnd.randrange(1, 1 << 30)
-        kind = rnd.choice(["gate", "gate", "gate", "t64", "ks", "cmux", "lut", "fft", "exact"])
+        kind = rnd.choice(["gate", "gate", "gate", "t64", "ks", "cmux", "lut", "fft", "exact", "wide"])
         if kind == "gate":      # N=1024 Torus32: compile-time and run-time gadgets, ragged batches 1..41
             l, bg = rnd.choice([(2, 10), (2, 10), (2, 8), (2, 9), (3, 7), (4, 6), (1, 12)])
             t, bb = rnd.choice([(8, 2), (16, 1), (5, 3), (6, 2)])
@@ -45,6 +45,9 @@ def main():
             # one wave per ciphertext whatever the batch
             P.check_gate_path(lib, N=1024, n=rnd.randrange(2, 9), l=l, Bgbit=bg, ks_t=t, ks_bb=bb, B=rnd.randrange(1, 42),
                               seed=seed, check_export=False, br_split=rnd.choice([None, 1 << 30, 0]))
+        elif kind == "wide":    # batches above 1024: the 8-wave workgroup instantiations of every gadget class
+            l, bg = rnd.choice([(2, 10), (2, 8), (2, 9), (3, 7), (4, 6)])
+            P.check_gate_wide_batch(lib, l=l, Bgbit=bg, B=rnd.randrange(1025, 1100), n=rnd.randrange(2, 7), seed=seed)
         elif kind == "t64":     # Torus64, both ring sizes (short rounding + guard)
             N = rnd.choice([1024, 2048])
             l, bg = rnd.choice([(4, 9), (3, 10), (2, 16), (4, 8)])

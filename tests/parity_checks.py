@@ -191,6 +191,30 @@ def check_gate_path(lib_path, N, n, l, Bgbit, ks_t, ks_bb, B, seed=21, check_exp
         s.close()
 
 
+def check_gate_wide_batch(lib_path, l, Bgbit, B=1031, N=1024, n=6, ks_t=8, ks_bb=2, seed=31):
+    """batches above 1024 run k_blind_rotate in 8-wave workgroups (two waves per SIMD, the partner balance): bootstrap and
+    in-place blind rotation of B samples against the oracle on a subset, and against the 4-wave form of the same kernel
+    (a small batch of the same inputs) on the first rows"""
+    s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb)
+    try:
+        rs = np.random.RandomState(seed)
+        s.eng.set_option(T.OPT_BR_SPLIT, 0)
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(B, n + 1)).astype(np.int32)
+        got = s.eng.bootstrap(1 << 29, x)
+        sub = sorted(set([0, 7, 8, B - 8, B - 7, B - 1] + [int(v) for v in rs.choice(B, 4, replace=False)]))
+        want = np.stack([O.bootstrap32(N, s.bk, s.ks, 1 << 29, x[i], l, Bgbit, ks_t, ks_bb) for i in sub])
+        assert np.array_equal(got[sub], want), (l, Bgbit)
+        assert np.array_equal(got[:24], s.eng.bootstrap(1 << 29, x[:24])), (l, Bgbit, "8-wave vs 4-wave workgroups")
+        acc = rs.randint(-2 ** 31, 2 ** 31, size=(B, 2, N)).astype(np.int32)
+        bara = rs.randint(0, 2 * N, size=(B, n)).astype(np.int32)
+        bara[B - 1, 0] = 0
+        rot = s.eng.blind_rotate(acc, bara)
+        for i in (0, B - 2, B - 1):
+            assert np.array_equal(rot[i], O.blind_rotate32(N, acc[i], s.bk, bara[i], l, Bgbit).reshape(2, N)), (l, Bgbit, i)
+    finally:
+        s.close()
+
+
 # ------------------------------------------------------------ Torus64 path
 def check_torus64_path(lib_path, N, n, l, Bgbit, B, seed=31):
     rs = np.random.RandomState(seed)
@@ -296,8 +320,9 @@ def check_lut_eval(lib_path, N=1024, l=3, Bgbit=8, d=12, B=3, seed=81, decrypt_t
 def check_streamed_graph(lib_path, N=1024, n=12, l=2, Bgbit=10, ks_t=8, ks_bb=2, B=5, seed=91):
     """tfhe_amd_bootstrap_streamed under TFHE_AMD_OPT_STREAMED_GRAPH: call 1 runs plain launches, call 2
     captures the n+3 launches into a hipGraph, call 3 replays it; new data written into the SAME device
-    buffers must be picked up by the replay; a different batch size must re-capture.  (On the CPU
-    emulator build the option is accepted and ignored.)"""
+    buffers must be picked up by the replay; a different batch size must re-capture.  (The CPU emulator
+    build records and replays the graph too -- EmuGraph in tests/emu/emu_runtime.cpp -- so the capture and
+    replay logic of the host code runs there as well.)"""
     s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb)
     rs = np.random.RandomState(seed)
     e = s.eng
@@ -319,6 +344,33 @@ def check_streamed_graph(lib_path, N=1024, n=12, l=2, Bgbit=10, ks_t=8, ks_bb=2,
         assert np.array_equal(out_d.download(np.int32, xb.shape)[:B - 2], want_b[:B - 2]), "re-captured for a smaller batch"
         e._chk(e.lib.tfhe_amd_bootstrap_streamed(e.ctx, out_d.ptr, -mu, x_d.ptr, B - 2))  # other mu: re-capture
         assert np.array_equal(out_d.download(np.int32, xb.shape)[:B - 2], e.bootstrap(-mu, xb[:B - 2])), "re-captured for another mu"
+    finally:
+        s.close()
+
+
+def check_streamed_graph_batch_classes(lib_path, N=1024, n=6, l=2, Bgbit=10, ks_t=8, ks_bb=2, big=1031, small=8, seed=92):
+    """graph mode with NO prior plain bootstrap on the context, at a batch served by the 8-wave kernel and then at one
+    served by the latency-shaped kernel (another kernel class: its first launch sets an LDS attribute, which must not
+    happen inside the capture -- the warm-up is per class), each: warm-up call, capturing call, replay"""
+    s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb)
+    rs = np.random.RandomState(seed)
+    e = s.eng
+    try:
+        e.set_option(T.OPT_STREAMED_GRAPH, 1)
+        mu = 1 << 29
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(big, n + 1)).astype(np.int32)
+        x_d, out_d = e.to_device(x), e.alloc(x.nbytes)
+        got = {}
+        for B in (big, small):
+            for call in range(3):
+                e._chk(e.lib.tfhe_amd_bootstrap_streamed(e.ctx, out_d.ptr, mu, x_d.ptr, B))
+                got[(B, call)] = out_d.download(np.int32, x.shape)[:B].copy()
+        e.set_option(T.OPT_STREAMED_GRAPH, 0)
+        want = e.bootstrap(mu, x)
+        for (B, call), g in got.items():
+            assert np.array_equal(g, want[:B]), (B, call)
+        for i in (0, big - 1):
+            assert np.array_equal(want[i], O.bootstrap32(N, s.bk, s.ks, mu, x[i], l, Bgbit, ks_t, ks_bb))
     finally:
         s.close()
 

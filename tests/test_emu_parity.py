@@ -94,6 +94,16 @@ def test_streamed_schedule_fixed_buffers_emu(emu_lib):
     P.check_streamed_graph(emu_lib, n=4, B=3)
 
 
+def test_streamed_graph_without_prior_plain_call_emu(emu_lib):
+    """graph mode as the FIRST thing a context does, at two batch sizes (on the GPU: two blind-rotation kernel classes)"""
+    P.check_streamed_graph_batch_classes(emu_lib, n=2, big=20, small=3)
+
+
+def test_gate_wide_batch_logic_emu(emu_lib):
+    """the wide-batch check of the GPU suite (there: B = 1031, 8-wave workgroups) at a size the emulator finishes"""
+    P.check_gate_wide_batch(emu_lib, l=3, Bgbit=7, B=30, n=2)
+
+
 @pytest.mark.parametrize("bits,N,l,Bgbit,bound", [(32, 1024, 2, 10, 4), (64, 2048, 4, 9, 2 ** 32)])
 def test_exact_external_product_emu(emu_lib, bits, N, l, Bgbit, bound):
     """FFT-free backend (poc:285-316) bit-exact vs the oracle; fp64 path within `bound` units of it"""

@@ -296,6 +296,18 @@ def test_gate_path_workgroup_widths(gpu_lib):
         s.close()
 
 
+def test_gate_path_8wave_workgroups_other_gadgets(gpu_lib):
+    """the 8-wave instantiations <10,8,2,2,8>, <10,8,2,2> and <10,8,2> (two waves per SIMD + the partner balance) are only
+    reachable above 1024 samples since the 4-wave form serves the batches below: B = 1031 (128 full workgroups + a ragged
+    one) for (l=2, Bgbit=8), (l=2, Bgbit=9) and (l=3, Bgbit=7)"""
+    for l, Bgbit, seed in ((2, 8, 31), (2, 9, 32), (3, 7, 33)):
+        P.check_gate_wide_batch(gpu_lib, l=l, Bgbit=Bgbit, B=1031, seed=seed)
+
+
+def test_streamed_graph_across_kernel_classes(gpu_lib):
+    P.check_streamed_graph_batch_classes(gpu_lib)
+
+
 def test_gate_path_latency_kernel_other_bgbit(gpu_lib):
     """k_blind_rotate_split<8> (the circuit bootstrap's output gadget) and <0> (Bgbit read at run time)"""
     P.check_gate_path(gpu_lib, N=1024, n=7, l=2, Bgbit=8, ks_t=8, ks_bb=2, B=5, check_export=False, seed=14, br_split=1 << 30)
