@@ -141,4 +141,15 @@ __device__ __forceinline__ void tfhe_nontemporal_store(V v, V *p) { __builtin_no
     hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 #endif
 
+// instrumentation hooks of k_blind_rotate: nothing in the shipped library; the probe build of tools/wave_probe.py
+// (-DTFHE_PROBE, never shipped) fills them from probe_hooks.h
+#if defined(TFHE_PROBE) && !defined(TFHE_EMU)
+#include "probe_hooks.h"
+#else
+#define TFHE_PROBE_KERNEL_BEGIN() ((void)0)
+#define TFHE_PROBE_LOOP_BEGIN() ((void)0)
+#define TFHE_PROBE_LOOP_END(wave, t) ((void)0)
+#define TFHE_PROBE_KERNEL_END(t) ((void)0)
+#endif
+
 #include <stdint.h>

@@ -508,18 +508,6 @@ int lut_eval_t(tfhe_amd_ctx *c, void *lwe_out_d, const tfhe_amd_gsw *bits, int d
 }  // namespace
 
 // ------------------------------------------------------------------ C ABI
-#ifdef TFHE_PROBE
-extern "C" int tfhe_amd_dbg_read(unsigned long long *out) {  // experiment build only: read and reset the phase totals
-    unsigned long long z[32] = {};
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tfhe::tfhe_dbg), sizeof(z)) != hipSuccess) return 1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(tfhe::tfhe_dbg), z, sizeof(z)) != hipSuccess;
-}
-extern "C" int tfhe_amd_dbg_read_wg(unsigned long long *out) {  // [1024][4], read and reset
-    static unsigned long long z[1024 * 4];
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tfhe::tfhe_dbg_wg), sizeof(z)) != hipSuccess) return 1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(tfhe::tfhe_dbg_wg), z, sizeof(z)) != hipSuccess;
-}
-#endif
 extern "C" {
 
 int tfhe_amd_device_info(int device, char *buf, size_t len) {

@@ -493,18 +493,6 @@ struct WaveLds {
     }
 };
 
-#ifdef TFHE_PROBE
-// PROBE BUILD ONLY (tools/wave_probe.py, -DTFHE_PROBE; the shipped library has none of this): shader clock and
-// in-loop lifetime of every wave, start / end / placement of every workgroup of k_blind_rotate
-__device__ unsigned long long tfhe_dbg[32];  // 0: sum of shader cycles, 1: sum of 100 MHz ticks, 2: waves, [16 + wave]: ticks per wave index
-__device__ unsigned long long tfhe_dbg_wg[1024 * 4];  // per workgroup: start, end (100 MHz ticks), HW_ID, XCC_ID
-TFHE_DEVICE unsigned long long tfhe_clk() {
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long c = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_sched_barrier(0);
-    return c;
-}
-#endif
 // Fourier-domain multiply-accumulate of one decomposed limb with one key row
 // (lagrangehalfc_impl_fma.s:96-107), bk already in registers.  FIRST: the accumulator is still the
 // +0 of tLweFFTClear (tgsw_functions.cpp:438) -- fma(a, b, -(+0)) and fma(a, b, +0) are a*b up to the
@@ -616,6 +604,10 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
     if constexpr (HALFROW) {
         static_assert(!HALFROW || ND == 1, "half-row form: one digit at a time");
         mac_half_row<PPL, FIRST>(fr[0], fi[0], xr[0], xi[0], bk[0]);
+        // (requesting this half-row earlier -- in front of the first MAC, or with the first half-row under the transform --
+        // was measured in round 4: 19.07 / 21.82 ms against 18.27 per 1024 x 500 CMux.  Its 64 registers do not exist:
+        // accumulator 128 + Fourier accumulator 128 + rotated coefficients 64 + transform 64 + one half-row 64 already
+        // fill 448 of the wave's 512, and the kernel then spills to scratch.  profiles/r04_cb_experiments.txt)
 #pragma unroll
         for (int m = 0; m < PPL; m++) bk[0][m] = TFHE_BK(row0, 1, m);
         mac_half_row<PPL, FIRST>(fr[1], fi[1], xr[0], xi[0], bk[0]);
@@ -881,13 +873,27 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
             }
     }
     if constexpr (ACCREG) {  // acc (+)= result, in registers
+        // the wave-uniform `rotate` as ONE scalar branch around the whole update (inside the loops hipcc emits a pair of
+        // v_cndmask per coefficient: 128 per CMux)
+        if (rotate) {
+            TFHE_KEEP_BRANCH();
 #pragma unroll
-        for (int q = 0; q < 2; q++)
+            for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                accr[q][0][m] = rotate ? accr[q][0][m] + r0[q][m] : r0[q][m];
-                accr[q][1][m] = rotate ? accr[q][1][m] + r1[q][m] : r1[q][m];
-            }
+                for (int m = 0; m < PPL; m++) {
+                    accr[q][0][m] += r0[q][m];
+                    accr[q][1][m] += r1[q][m];
+                }
+        } else {
+            TFHE_KEEP_BRANCH();
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int m = 0; m < PPL; m++) {
+                    accr[q][0][m] = r0[q][m];
+                    accr[q][1][m] = r1[q][m];
+                }
+        }
         return;
     }
     // (the wave-uniform `rotate` test sits outside the unrolled loops: inside them hipcc keeps one
@@ -1001,13 +1007,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
     using Lds = BlindRotateLds<T, LOGN, WAVES>;
     constexpr int N = G::N, PPL = G::PPL;
     TFHE_DYN_LDS(smem);
-#ifdef TFHE_PROBE
-    if (threadIdx.x == 0 && blockIdx.x < 1024) {
-        tfhe_dbg_wg[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
-        tfhe_dbg_wg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        tfhe_dbg_wg[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    }
-#endif
+    TFHE_PROBE_KERNEL_BEGIN();
     const uint32_t sync_lds = tfhe_lds_offset(smem + Lds::sync_at);  // int [wave]: progress; [8 + wave]: SIMD of the wave
     const int my_simd = TFHE_SIMD_ID();
     if ((threadIdx.x & 63) == 0) {
@@ -1103,9 +1103,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
         bk0 += (size_t)((ct / A.sel_div) * A.sel_mul + A.sel_add) * A.gsw_sample_stride;
 
     // ---- CMux loop (lwe_functions.cpp:337-361)
-#ifdef TFHE_PROBE
-    const unsigned long long dbg_c0 = tfhe_clk(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+    TFHE_PROBE_LOOP_BEGIN();
     // the rotation amount is requested one step ahead, as a scalar load
     int a_next = ((A.flags & BR_NO_ROTATE) || A.n_steps <= 0) ? 0 : tfhe_uniform_load32(rot, 0);
 #pragma unroll 1
@@ -1124,17 +1122,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
         cmux_step<T, LOGN, PAIR, LC, BGC, Lds::CPLX_XCH, (WAVES <= 4), ACCREG>(w, bkrow, a, rotate, A.gd, t, accr);
     }
 
-#ifdef TFHE_PROBE
-    {
-        const unsigned long long c1 = tfhe_clk(), r1 = __builtin_amdgcn_s_memrealtime();
-        if (t == 0) {
-            atomicAdd(&tfhe_dbg[0], c1 - dbg_c0);
-            atomicAdd(&tfhe_dbg[1], r1 - dbg_r0);
-            atomicAdd(&tfhe_dbg[2], 1ull);
-            atomicAdd(&tfhe_dbg[16 + (wave & 7)], r1 - dbg_r0);
-        }
-    }
-#endif
+    TFHE_PROBE_LOOP_END(wave, t);
     // ---- output
     if (A.flags & BR_EXTRACT) {  // tLweExtractLweSampleIndex, index 0 (tlwe_functions.cpp:351-363)
         T *out = A.lwe_out + (size_t)ct * (N + 1);
@@ -1180,9 +1168,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
 #undef ACC_REG
 #undef ACC_SET
 #undef ACC_GET
-#ifdef TFHE_PROBE
-    if (t == 0 && blockIdx.x < 1024) atomicMax(&tfhe_dbg_wg[blockIdx.x * 4 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
+    TFHE_PROBE_KERNEL_END(t);
 }
 
 // ------------------------------------------- latency-shaped blind rotation (small batches)
