@@ -33,6 +33,21 @@
 
 #include <type_traits>
 
+// How many steps ahead of its use a butterfly's twiddle is requested from LDS (WaveFFT::ifft / fft, TWD), by kernel form:
+// PAIR = two waves per SIMD (the 8-wave gate kernel), LONE = one wave per SIMD (Torus64 kernel, 4-wave gate form),
+// SPLIT = the latency kernel's four lone waves.  Values decided by A/B on MI355X (profiles/r04_twiddle_distance.txt:
+// distances 1 / 2 / 3 / 4: gate kernel 16.35 / 16.24 / 16.15 / 16.13 ms per 4096, Torus64 17.44 / 17.40 / 17.36 / 17.28 ms
+// (6: 17.35, 8: 19.3 -- spills), one bootstrap 2.55 / 2.52 / 2.50 / 2.46 ms).
+#ifndef TFHE_TWD_PAIR
+#define TFHE_TWD_PAIR 4
+#endif
+#ifndef TFHE_TWD_LONE
+#define TFHE_TWD_LONE 4
+#endif
+#ifndef TFHE_TWD_SPLIT
+#define TFHE_TWD_SPLIT 4
+#endif
+
 namespace tfhe {
 
 // ------------------------------------------------------------------ geometry
@@ -196,57 +211,67 @@ struct WaveFFT {
         }
     }
 
+    // ---- twiddle schedule of a register pass: entry k = (stage k / (PPL/2), butterfly group k % (PPL/2)); DESC: strides
+    // PPL/2 .. 1 (ifft), else 1 .. PPL/2 (fft).  PASS_LEN entries per pass.
+    static constexpr int PASS_LEN = (PPL / 2) * G::R;
+    template <bool DESC>
+    TFHE_HOST_DEVICE static constexpr int pass_s(int k) {
+        return DESC ? ((PPL / 2) >> (k / (PPL / 2))) : (1 << (k / (PPL / 2)));
+    }
+    TFHE_HOST_DEVICE static constexpr int pass_m(int s, int k) { return ((k % (PPL / 2)) / s) * 2 * s + ((k % (PPL / 2)) % s); }
+
     // coefficient -> Lagrange for NP polynomials at once (every twiddle is read from LDS once
     // and used by all NP).  In: lane t register m = point jA(t,m) (re = coef j, im = coef j+N/2).
     // Out: register m = position jC(t,m) of the reference's output order.
-    template <int NP, class TW, bool CPLX = false>
+    // TWD: how many steps ahead of its use a twiddle is requested from LDS.  1 is enough where a second wave shares the
+    // SIMD (its instructions fill the rest of the latency); a LONE wave (one per SIMD: the Torus64 kernel, the latency
+    // kernel, the 4-wave form) has only its own butterflies to put in front of a read -- 8 fp64 instructions per polynomial,
+    // ~40 cycles, against an LDS latency of ~100+ -- and waited at every butterfly: see DESIGN.md 2 (round 4).
+    // The first twiddles of a pass are requested BEFORE the transpose in front of it: behind it (the fences keep LDS reads
+    // in program order) they would be the LAST of the wave's outstanding LDS operations, and the first butterfly would wait
+    // with lgkmcnt(0) for every polynomial's transpose instead of for the first polynomial's reads.
+    template <int NP, class TW, bool CPLX = false, int TWD = 1>
     TFHE_DEVICE static void ifft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, const Xch &X, int t) {
-        // Every twiddle is requested one step before the step that uses it (wn), so that its LDS
-        // latency runs under the previous step's arithmetic instead of in front of its own.
-        // twist by omega^j (spqlios-ifft-fma.s:63-78)
-        double2 wn = tw.twist(0);
+        static_assert(TWD >= 1 && TWD <= 8, "twiddle prefetch distance");
+        // twist by omega^j (spqlios-ifft-fma.s:63-78), then pass A: strides 64*s, s = PPL/2 .. 1 -- one schedule
+        constexpr int LA = PPL + PASS_LEN;
+        auto tw_a = [&](int k) {
+            return k < PPL ? tw.twist(k) : tw.passA(pass_s<true>(k - PPL), pass_m(pass_s<true>(k - PPL), k - PPL));
+        };
+        double2 ra[TWD];
 #pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            const double2 w = wn;
-            wn = (m + 1 < PPL) ? tw.twist(m + 1) : tw.passA(PPL / 2, 0);
+        for (int k = 0; k < TWD; k++) ra[k] = tw_a(k);
 #pragma unroll
-            for (int p = 0; p < NP; p++) {
-                const double r = xr[p][m], i = xi[p][m];
-                xr[p][m] = __builtin_fma(-i, w.y, r * w.x);
-                xi[p][m] = __builtin_fma(i, w.x, r * w.y);
-            }
-        }
-        // pass A: strides 64*s, s = PPL/2 .. 1
+        for (int k = 0; k < LA; k++) {
+            const double2 w = ra[k % TWD];
+            if (k + TWD < LA) ra[k % TWD] = tw_a(k + TWD);
+            if (k < PPL) {
 #pragma unroll
-        for (int s = PPL / 2; s >= 1; s >>= 1) {
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                if (m & s) continue;
-                const double2 w = wn;
-                {   // next butterfly group of this stage, else the first of the next stage
-                    int mn = m + 1;
-                    while (mn < PPL && (mn & s)) mn++;
-                    if (mn < PPL)
-                        wn = tw.passA(s, mn);
-                    else if (s > 1)
-                        wn = tw.passA(s >> 1, 0);
+                for (int p = 0; p < NP; p++) {
+                    const double r = xr[p][k], i = xi[p][k];
+                    xr[p][k] = __builtin_fma(-i, w.y, r * w.x);
+                    xi[p][k] = __builtin_fma(i, w.x, r * w.y);
                 }
+            } else {
+                const int s = pass_s<true>(k - PPL), m = pass_m(s, k - PPL);
 #pragma unroll
                 for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], w.x, w.y);
             }
         }
+        // pass B: strides s<<CB
+        auto tw_b = [&](int k) { return tw.passB(pass_s<true>(k), pass_m(pass_s<true>(k), k)); };
+        double2 rb[TWD];
+#pragma unroll
+        for (int k = 0; k < TWD; k++) rb[k] = tw_b(k);
 #pragma unroll
         for (int p = 0; p < NP; p++) transpose_point<G::RD_A1, G::RD_B1, CPLX>(xr[p], xi[p], X);
-        // pass B: strides s<<CB
 #pragma unroll
-        for (int s = PPL / 2; s >= 1; s >>= 1) {
+        for (int k = 0; k < PASS_LEN; k++) {
+            const double2 w = rb[k % TWD];
+            if (k + TWD < PASS_LEN) rb[k % TWD] = tw_b(k + TWD);
+            const int s = pass_s<true>(k), m = pass_m(s, k);
 #pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                if (m & s) continue;
-                const double2 w = tw.passB(s, m);
-#pragma unroll
-                for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], w.x, w.y);
-            }
+            for (int p = 0; p < NP; p++) dif_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], w.x, w.y);
         }
 #pragma unroll
         for (int p = 0; p < NP; p++) transpose_point<G::RD_B2, G::RD_C2, CPLX>(xr[p], xi[p], X);
@@ -287,9 +312,10 @@ struct WaveFFT {
     }
 
     // Lagrange -> coefficient for NP polynomials (caller has applied the 2/N scale).
-    // In: register m = position jC(t,m).  Out: register m = point jA(t,m).
-    template <int NP, class TW, bool CPLX = false>
+    // In: register m = position jC(t,m).  Out: register m = point jA(t,m).  TWD: as in ifft.
+    template <int NP, class TW, bool CPLX = false, int TWD = 1>
     TFHE_DEVICE static void fft(double (&xr)[NP][PPL], double (&xi)[NP][PPL], const TW &tw, const Xch &X, int t) {
+        static_assert(TWD >= 1 && TWD <= 8, "twiddle prefetch distance");
 #pragma unroll
         for (int p = 0; p < NP; p++) {
 #pragma unroll
@@ -324,52 +350,58 @@ struct WaveFFT {
                 for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + 4], xi[p][m + 4], wc, w.y);
             }
         }
+        // pass B: strides (s << CB), s = 1 .. PPL/2; its first twiddles are requested before the transpose (see ifft)
+        auto tw_b = [&](int k) { return tw.passB(pass_s<false>(k), pass_m(pass_s<false>(k), k)); };
+        double2 rb[TWD];
+#pragma unroll
+        for (int k = 0; k < TWD; k++) rb[k] = tw_b(k);
 #pragma unroll
         for (int p = 0; p < NP; p++) transpose_point<G::RD_C2, G::RD_B2, CPLX>(xr[p], xi[p], X);
         const int c = t & ((1 << G::CB) - 1);
 #pragma unroll
-        for (int s = 1; s <= PPL / 2; s <<= 1) {
+        for (int k = 0; k < PASS_LEN; k++) {
+            const double2 w = rb[k % TWD];
+            if (k + TWD < PASS_LEN) rb[k % TWD] = tw_b(k + TWD);
+            const int s = pass_s<false>(k), m = pass_m(s, k);
+            // quarter turn: off == (s<<CB)/2
+            const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
+            const bool lq = (s == 1) ? (c == (1 << (G::CB - 1))) : (c == 0);
+            const double wc = mq ? flip_sign_if(w.x, lq) : w.x;
 #pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                if (m & s) continue;
-                const double2 w = tw.passB(s, m);
-                // quarter turn: off == (s<<CB)/2
-                const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
-                const bool lq = (s == 1) ? (c == (1 << (G::CB - 1))) : (c == 0);
-                const double wc = mq ? flip_sign_if(w.x, lq) : w.x;
-#pragma unroll
-                for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], wc, w.y);
-            }
+            for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], wc, w.y);
         }
+        // pass A (strides 64 s, s = 1 .. PPL/2), then the final twist by conj(omega^j), four rounded products
+        // (spqlios-fft-fma.s:255-274): re' = re*c - im*(-s) = re*c + im*s ; im' = re*(-s) + im*c = im*c - re*s
+        constexpr int LA = PASS_LEN + PPL;
+        auto tw_a = [&](int k) {
+            return k < PASS_LEN ? tw.passA(pass_s<false>(k), pass_m(pass_s<false>(k), k)) : tw.twist(k - PASS_LEN);
+        };
+        double2 ra[TWD];
+#pragma unroll
+        for (int k = 0; k < TWD; k++) ra[k] = tw_a(k);
 #pragma unroll
         for (int p = 0; p < NP; p++) transpose_point<G::RD_B1, G::RD_A1, CPLX>(xr[p], xi[p], X);
 #pragma unroll
-        for (int s = 1; s <= PPL / 2; s <<= 1) {
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                if (m & s) continue;
-                const double2 w = tw.passA(s, m);
+        for (int k = 0; k < LA; k++) {
+            const double2 w = ra[k % TWD];
+            if (k + TWD < LA) ra[k % TWD] = tw_a(k + TWD);
+            if (k < PASS_LEN) {
+                const int s = pass_s<false>(k), m = pass_m(s, k);
                 // quarter turn: off == 32*s
                 const bool mq = (s == 1) ? true : ((m & (s - 1)) == s / 2);
                 const bool lq = (s == 1) ? (t == 32) : (t == 0);
                 const double wc = mq ? flip_sign_if(w.x, lq) : w.x;
 #pragma unroll
                 for (int p = 0; p < NP; p++) dit_bfly(xr[p][m], xi[p][m], xr[p][m + s], xi[p][m + s], wc, w.y);
-            }
-        }
-        // final twist by conj(omega^j), four rounded products (spqlios-fft-fma.s:255-274):
-        // re' = re*c - im*(-s) = re*c + im*s ; im' = re*(-s) + im*c = im*c - re*s
-        double2 wn = tw.twist(0);  // requested one step ahead, as in ifft
+            } else {
+                const int m = k - PASS_LEN;
 #pragma unroll
-        for (int m = 0; m < PPL; m++) {
-            const double2 w = wn;
-            if (m + 1 < PPL) wn = tw.twist(m + 1);
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-                const double r = xr[p][m], i = xi[p][m];
-                const double rc = r * w.x, rs = r * w.y, ic = i * w.x, is = i * w.y;
-                xr[p][m] = rc + is;
-                xi[p][m] = ic - rs;
+                for (int p = 0; p < NP; p++) {
+                    const double r = xr[p][m], i = xi[p][m];
+                    const double rc = r * w.x, rs = r * w.y, ic = i * w.x, is = i * w.y;
+                    xr[p][m] = rc + is;
+                    xi[p][m] = ic - rs;
+                }
             }
         }
     }
@@ -534,7 +566,7 @@ TFHE_DEVICE void mac_half_row(double (&fr)[PPL], double (&fi)[PPL], const double
 // HALFROW (register-resident accumulator, PPL = 16): the key row is fetched in two halves of 64 registers
 // (the half for output polynomial 0 underneath the transform, the other half while the first is consumed)
 // instead of 128 at once.
-template <typename T, int LOGN, int ND, int BGC, bool FIRST, bool CPLX, bool HALFROW = false>
+template <typename T, int LOGN, int ND, int BGC, bool FIRST, bool CPLX, bool HALFROW = false, int TWD = 1>
 TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int row0, int d0,
                                  const typename Torus<T>::U (&lo)[Geom<LOGN>::PPL],
                                  const typename Torus<T>::U (&hi)[Geom<LOGN>::PPL], const Gadget &gd,
@@ -600,7 +632,7 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
             }
         }
     }
-    WaveFFT<LOGN>::template ifft<ND, TwLds<LOGN>, CPLX>(xr, xi, w.tw, w.xch, t);
+    WaveFFT<LOGN>::template ifft<ND, TwLds<LOGN>, CPLX, TWD>(xr, xi, w.tw, w.xch, t);
     if constexpr (HALFROW) {
         static_assert(!HALFROW || ND == 1, "half-row form: one digit at a time");
         mac_half_row<PPL, FIRST>(fr[0], fi[0], xr[0], xi[0], bk[0]);
@@ -754,6 +786,9 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
     const U offset = (U)gd.offset, flip = (U)gd.flip;
 
     double fr[2][PPL], fi[2][PPL];  // Fourier accumulator (tLweFFTClear)
+    // twiddle prefetch distance of the transforms (WaveFFT::ifft): KEEP_ROT marks the forms with ONE wave per SIMD
+    // (the instantiation that reads the gadget length at run time has no registers to spare at two waves per SIMD: 1)
+    constexpr int TWD = KEEP_ROT ? TFHE_TWD_LONE : (LC > 0 ? TFHE_TWD_PAIR : 1);
     constexpr bool UNROLLED = (LC > 0 && LC == PAIR);
     const int l = LC ? LC : gd.l;
     const int groups = (l + PAIR - 1) / PAIR;
@@ -791,9 +826,9 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
     auto digits = [&](int q, int d, const U (&lo)[PPL], const U (&hi)[PPL], auto first) {
         constexpr bool FIRST = decltype(first)::value;
         if (PAIR == 2 && ((LC && LC % 2 == 0) || d + 1 < l)) {
-            ifft_mac_digits<T, LOGN, 2, BGC, FIRST, CPLX>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
+            ifft_mac_digits<T, LOGN, 2, BGC, FIRST, CPLX, false, TWD>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         } else {
-            ifft_mac_digits<T, LOGN, 1, BGC, FIRST, CPLX, ACCREG>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
+            ifft_mac_digits<T, LOGN, 1, BGC, FIRST, CPLX, ACCREG, TWD>(w, bkrow, q * l + d, d, lo, hi, gd, fr, fi, t);
         }
     };
     if (UNROLLED) {
@@ -846,7 +881,7 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
     }
     // back to coefficients (both polynomials together), round, accumulate into acc
     // (tLweFromFFTConvert + tLweAddTo)
-    WaveFFT<LOGN>::template fft<2, TwLds<LOGN>, CPLX>(fr, fi, w.tw, w.xch, t);
+    WaveFFT<LOGN>::template fft<2, TwLds<LOGN>, CPLX, TWD>(fr, fi, w.tw, w.xch, t);
     U r0[2][PPL], r1[2][PPL];
     bool exact_path = true;
     if (Torus<T>::HAS_FAST) {  // Torus32: short rounding sequence, valid while every |x| < 2^51
@@ -1331,7 +1366,7 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_blind_rotate_split(BlindRotateArgs<
                 xr[0][m] = (double)TFHE_SBFE(lo[m], decal, Bgbit);
                 xi[0][m] = (double)TFHE_SBFE(hi[m], decal, Bgbit);
             }
-            WaveFFT<10>::template ifft<1, TwLds<10>, true>(xr, xi, w.tw, w.xch, t);
+            WaveFFT<10>::template ifft<1, TwLds<10>, true, TFHE_TWD_SPLIT>(xr, xi, w.tw, w.xch, t);
             double2 *h = reinterpret_cast<double2 *>(smem + L::hand_row(wave)) + t;
 #pragma unroll
             for (int m = 0; m < PPL; m++) h[64 * m] = make_double2(xr[0][m], xi[0][m]);
@@ -1380,7 +1415,7 @@ TFHE_GLOBAL void __launch_bounds__(256, 2) k_blind_rotate_split(BlindRotateArgs<
                 request_rows(bkA, inext, 0);  // in flight during the transform below and the whole of the next phase 1
             }
             TFHE_ORDER();
-            WaveFFT<10>::template fft<1, TwLds<10>, true>(fr, fi, w.tw, w.xch, t);
+            WaveFFT<10>::template fft<1, TwLds<10>, true, TFHE_TWD_SPLIT>(fr, fi, w.tw, w.xch, t);
             U r0[PPL], r1[PPL];
             uint32_t guard = 0;
 #pragma unroll
