@@ -101,7 +101,7 @@ def cpu_baseline(cfg, seconds=10.0):
         for p in procs:
             out = p.communicate()[0].split()
             total += float(out[0]) / float(out[1])
-        return {"value": total, "unit": "bootstraps/s", "cores": cores, "kind": "reference",
+        return {"value": total, "unit": "bootstraps/s", "cores": cores, "kind": "reference", "per_core_value": total / cores,
                 "sample": f"{cores} processes x {int(seconds)} s of tfhe_bootstrap_FFT composed from the reference's "
                           "spqlios FMA assembly (execute_reverse_int x4, AddMul x8, execute_direct_torus32 x2 per "
                           "CMux) + key switch, same parameters, synthetic keys/samples"}

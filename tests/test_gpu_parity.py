@@ -304,6 +304,41 @@ def test_gate_path_8wave_workgroups_other_gadgets(gpu_lib):
         P.check_gate_wide_batch(gpu_lib, l=l, Bgbit=Bgbit, B=1031, seed=seed)
 
 
+def test_two_contexts_on_two_host_threads(gpu_lib):
+    """SURVEY 8(b) threading contract: a context is bound to one stream and is not thread-safe, DISTINCT contexts are
+    independent -- two host threads, one context each (own stream, own key replicas), bootstrapping different batches at the
+    same time, several times over; every result equals the oracle-checked single-threaded one"""
+    import threading
+    N, n, l, Bgbit, t, bb = 1024, 24, 2, 10, 8, 2
+    setups = [P.GateSetup(gpu_lib, N, n, l, Bgbit, t, bb) for _ in range(2)]
+    try:
+        rs = np.random.RandomState(77)
+        xs = [rs.randint(-2 ** 31, 2 ** 31, size=(B, n + 1)).astype(np.int32) for B in (700, 37)]
+        want = [setups[0].eng.bootstrap(1 << 29, x) for x in xs]
+        for i in (0, 1):
+            assert np.array_equal(want[i][3], O.bootstrap32(N, setups[0].bk, setups[0].ks, 1 << 29, xs[i][3], l, Bgbit, t, bb))
+        bad = []
+
+        def work(k):
+            try:
+                for rep in range(6):
+                    got = setups[k].eng.bootstrap(1 << 29, xs[k])
+                    if not np.array_equal(got, want[k]):
+                        bad.append((k, rep))
+            except Exception as e:  # surfaces in the main thread's assert
+                bad.append((k, repr(e)))
+
+        th = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not bad, bad
+    finally:
+        for s in setups:
+            s.close()
+
+
 def test_streamed_graph_across_kernel_classes(gpu_lib):
     P.check_streamed_graph_batch_classes(gpu_lib)
 
