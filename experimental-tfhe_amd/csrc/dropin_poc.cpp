@@ -10,6 +10,7 @@
 // (add it to the PoC's build in place of the bodies above) and linked with
 // libtfhe_amd.so.  One engine per `env` pointer, created on first use: Globals::preKS, bkFFT and privKS
 // are flattened and uploaded once.
+#include <cstring>
 #include <map>
 
 #include "poc_types.h"
@@ -20,15 +21,46 @@
 
 namespace {
 typedef tfhe_amd_compat::PocEngine<Globals> Engine;
-std::map<const Globals *, Engine *> &engines() {
-    static std::map<const Globals *, Engine *> m;
+struct Slot {
+    Engine *eng;
+    uint64_t fingerprint;
+};
+std::map<const Globals *, Slot> &engines() {
+    static std::map<const Globals *, Slot> m;
     return m;
+}
+// content sample of the keys behind an `env` (engines are found by the env ADDRESS: a Globals rebuilt at the same address
+// must not be served from the stale GPU copy; see tfhe_amd_compat::key_fingerprint)
+uint64_t env_fingerprint(const Globals *env) {
+    uint64_t h = 0x5446484500000002ull;
+    const int n0 = env->n_lvl0, N2 = env->n_lvl2, rows2 = 2 * env->ell_lvl2;
+    const int is[3] = {0, n0 / 2, n0 - 1}, pos[4] = {0, 1, N2 / 2, N2 - 1};
+    for (int a = 0; a < 3; a++)
+        for (int r = 0; r < rows2; r += rows2 - 1)
+            for (int b = 0; b < 4; b++) {
+                uint64_t bits;
+                std::memcpy(&bits, &env->bkFFT[is[a]].allsamples[r].a[1].values[pos[b]], 8);
+                h = tfhe_amd_compat::fp_mix(h, bits);
+            }
+    h = tfhe_amd_compat::fp_mix(h, (uint32_t)env->preKS[0][0][1].a[0]);
+    h = tfhe_amd_compat::fp_mix(h, (uint32_t)env->preKS[env->n_lvl1 - 1][env->kslength_lvl10 - 1][1].a[n0]);
+    for (int u = 0; u < 2; u++) {
+        h = tfhe_amd_compat::fp_mix(h, (uint32_t)env->privKS[u][0][0][1].a[0].coefs[0]);
+        h = tfhe_amd_compat::fp_mix(h, (uint32_t)env->privKS[u][N2][env->kslength_lvl21 - 1][1].a[1].coefs[env->n_lvl1 - 1]);
+    }
+    return h;
 }
 Engine &engine_of(const Globals *env) {
     auto &m = engines();
+    const uint64_t fp = env_fingerprint(env);
     auto it = m.find(env);
-    if (it == m.end()) it = m.emplace(env, new Engine(env, tfhe_amd_compat::device_ordinal())).first;
-    return *it->second;
+    if (it != m.end() && it->second.fingerprint != fp) {  // rebuilt in place: upload again
+        delete it->second.eng;
+        m.erase(it);
+        it = m.end();
+    }
+    if (it == m.end()) it = m.emplace(env, Slot{new Engine(env, tfhe_amd_compat::device_ordinal()), fp}).first;
+    return *it->second.eng;
 }
 }  // namespace
 
@@ -53,6 +85,6 @@ void tfhe_amd_dropin_release(const Globals *env) {
     auto &m = engines();
     auto it = m.find(env);
     if (it == m.end()) return;
-    delete it->second;
+    delete it->second.eng;
     m.erase(it);
 }

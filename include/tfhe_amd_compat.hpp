@@ -78,6 +78,7 @@ struct Resident {
     // array forms: pinned host staging + device buffers, grown on demand
     void *h_in = nullptr, *h_out = nullptr, *da_in = nullptr, *da_out = nullptr;
     size_t arr_in_bytes = 0, arr_out_bytes = 0;
+    uint64_t fingerprint = 0;  // content sample of the host key the GPU copy was made from (see key_fingerprint)
 };
 struct ResidentKey {
     const void *obj, *ks;
@@ -111,16 +112,55 @@ inline void staging(Resident &R, size_t bytes) {
     check(tfhe_amd_malloc(R.ctx, &R.d_aux, bytes), R.ctx, "malloc");
 }
 
+// Resident copies are found by the ADDRESS of the caller's key object.  A key that is freed and rebuilt at the same address
+// without a release() in between must not be served from the stale GPU copy: every lookup re-reads a SAMPLE of the host
+// key (the bit patterns of a few values of its first, middle and last polynomials and key-switch rows: ~50 loads) and
+// compares it with the sample taken at upload time; a difference drops the resident copy and uploads the key again.
+inline uint64_t fp_mix(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    return h;
+}
+template <class GswT>
+inline uint64_t key_fingerprint(const GswT *bkFFT, int n, int N, int l, const LweKeySwitchKey *ks) {
+    uint64_t h = 0x5446484500000001ull;
+    const int rows[3] = {0, n / 2, n - 1}, pos[4] = {0, 1, N / 2, N - 1};
+    for (int a = 0; a < 3 && bkFFT && n > 0; a++)
+        for (int r = 0; r < 2 * l; r += (2 * l - 1 > 0 ? 2 * l - 1 : 1))
+            for (int q = 0; q < 2; q++)
+                for (int b = 0; b < 4; b++) {
+                    uint64_t bits;
+                    std::memcpy(&bits, &bkFFT[rows[a]].all_samples[r].a[q].values[pos[b]], 8);
+                    h = fp_mix(h, bits);
+                }
+    if (ks) {
+        const int is[3] = {0, ks->n / 2, ks->n - 1};
+        for (int a = 0; a < 3; a++)
+            for (int j = 0; j < ks->t; j += (ks->t - 1 > 0 ? ks->t - 1 : 1)) {
+                const LweSample &row = ks->ks[is[a]][j][ks->base - 1];
+                h = fp_mix(h, (uint32_t)row.a[0]);
+                h = fp_mix(h, (uint32_t)row.a[ks->out_params->n - 1]);
+                h = fp_mix(h, (uint32_t)row.b);
+            }
+    }
+    return h;
+}
+
+inline void release_entry(std::map<ResidentKey, Resident>::iterator it);
 // flatten n TGswSampleFFT (pointer-rich) into [n][2l][2][N] doubles and upload
 template <class GswT>
 inline Resident &attach_gsw(const GswT *bkFFT, int n, int N, int l, int Bgbit, const LweKeySwitchKey *ks = nullptr,
                             const void *owner = nullptr) {
     auto &reg = registry();
     const ResidentKey key{(const void *)bkFFT, (const void *)ks, n, N, l, Bgbit};
+    const uint64_t fp = key_fingerprint(bkFFT, n, N, l, ks);
     auto it = reg.find(key);
-    if (it != reg.end()) return it->second;
+    if (it != reg.end()) {
+        if (it->second.fingerprint == fp) return it->second;
+        release_entry(it);  // same address, other contents: the caller rebuilt the key in place
+    }
     Resident R;
     R.owner = owner;
+    R.fingerprint = fp;
     R.n = n;
     R.N = N;
     R.l = l;
@@ -197,8 +237,7 @@ inline void release_entry(std::map<ResidentKey, Resident>::iterator it) {
 }
 // every resident engine made from this key object, whatever shape it was attached with and whichever of its
 // addresses the caller passes: the LweBootstrappingKeyFFT, its bkFFT array or its key-switch key.  (The copies are
-// keyed by ADDRESS: a key that is freed and rebuilt at the same address without a release() in between would be
-// served from the stale GPU copy.)
+// keyed by ADDRESS and guarded by a content sample, see key_fingerprint: a key rebuilt in place is uploaded again.)
 inline void release(const void *key_object) {
     auto &reg = registry();
     for (auto it = reg.begin(); it != reg.end();) {
@@ -281,9 +320,15 @@ inline void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, 
 inline Resident &attach_ks(const LweKeySwitchKey *ks) {
     auto &reg = registry();
     const ResidentKey key{(const void *)ks, (const void *)ks, ks->out_params->n, ks->n, 0, 0};
+    const uint64_t fp = key_fingerprint((const TGswSampleFFT *)nullptr, 0, 0, 0, ks);
     auto it = reg.find(key);
+    if (it != reg.end() && it->second.fingerprint != fp) {
+        release_entry(it);  // rebuilt in place
+        it = reg.end();
+    }
     if (it == reg.end()) {
         Resident R;
+        R.fingerprint = fp;
         R.n = ks->out_params->n;
         R.N = ks->n;
         tfhe_amd_params p;

@@ -164,6 +164,19 @@ static int run_lib(const char *inp, const char *outp) {
         out.put(r.a, 4 * (size_t)n);
         out.put(&r.b, 4);
     }
+    // ... and the ORIGINAL key put back at the same addresses WITHOUT a release: the content sample taken at every lookup
+    // (tfhe_amd_compat::key_fingerprint) must notice, and the outputs must be those of the original key again
+    {
+        for (int i = 0; i < n; i++)
+            for (int r = 0; r < kpl; r++)
+                for (int q = 0; q < 2; q++)
+                    polys[((size_t)i * kpl + r) * 2 + q].values = (double *)bkflat + (((size_t)i * kpl + r) * 2 + q) * N;
+        LweSample x{(Torus32 *)xs, xs[n], 0};
+        LweSample r{rb.data(), 0, 0};
+        tfhe_bootstrap_FFT(&r, &bk, mu, &x);
+        out.put(r.a, 4 * (size_t)n);
+        out.put(&r.b, 4);
+    }
 #ifdef DROPIN
     tfhe_amd_dropin_release(nullptr);
     out.save(outp);

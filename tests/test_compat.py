@@ -73,6 +73,8 @@ def run_lib_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=
     bkr = np.ascontiguousarray(bk[::-1])
     assert np.array_equal(take(np.int32, N + 1), O.bootstrap_woks32(N, bkr, mu, x[0], l, Bgbit)), "release(bk) + rebuilt key, woKS"
     assert np.array_equal(take(np.int32, n + 1), O.bootstrap32(N, bkr, ks, mu, x[0], l, Bgbit, t, bb)), "release(bk) + rebuilt key"
+    # the original key put back in place WITHOUT a release: noticed through the content sample
+    assert np.array_equal(take(np.int32, n + 1), O.bootstrap32(N, bk, ks, mu, x[0], l, Bgbit, t, bb)), "key rebuilt in place, no release"
     if not plugin:  # the literal drop-in driver (tests/test_dropin.py) has no FFT-plugin section
         assert pos == len(raw)
         return
