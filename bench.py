@@ -28,6 +28,7 @@ After the timed region of a one-GPU run (never inside `value`; --headline-only s
 rocprofv3 scripts under tools/ pass so that the default command's kernel table holds the headline kernels only):
   config1_latency     BASELINE config 1: one gate bootstrap per call (and 8) through tfhe_amd_bootstrap, HIP events
   streamed_schedule   BASELINE config 2's literal schedule: one external-product launch per CMux step
+  config3_circuit_bootstrap, config4_transforms   BASELINE configs 3 and 4 as tools/bench_configs.py measures them (--other-configs)
 
 The JSON line also carries
   roofline      dominant kernel (k_blind_rotate).  bound = "fp64_issue": wave64 fp64 instructions
@@ -154,6 +155,37 @@ def oracle_rows(B):
     return list(range(n, min(n + 8, B)))
 
 
+def other_configs(T, a):
+    """config3_circuit_bootstrap / config4_transforms of the bench line: tools/bench_configs.py's own measurements (HIP events
+    through the C ABI, synthetic keys), run after the timed region; their per-line prints go to stderr"""
+    import contextlib
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    out = {}
+    try:
+        BC = importlib.import_module("bench_configs")
+        small = a.lwe_n is not None  # the test hook of the CPU emulator runs: tiny sizes
+        ns = argparse.Namespace(small=small, lib=a.lib, reps=min(3, max(1, a.extras_reps)), cb_batch=1024, batch=8192)
+        want = {w.strip() for w in a.other_configs.split(",") if w.strip()}
+        with contextlib.redirect_stdout(sys.stderr):
+            if "3" in want:
+                try:
+                    cb, lut = BC.bench_cb(T, ns)
+                    out["config3_circuit_bootstrap"] = dict(cb, baseline_config="BASELINE config 3 (circuit bootstrap TLWE -> TRGSW at "
+                                                            "the PoC parameters, batch 1024)", lut_evaluation=lut)
+                except Exception as e:  # noqa: BLE001 -- reported on the line, the headline stands
+                    out["config3_circuit_bootstrap"] = {"error": repr(e)}
+            if "4" in want:
+                try:
+                    lines = BC.bench_fft(T, ns)
+                    out["config4_transforms"] = {"baseline_config": "BASELINE config 4 (batched anticyclic transforms, N = 2048 batch 8192 and "
+                                                 "4 x that; N = 1024 beside it)", "lines": lines}
+                except Exception as e:  # noqa: BLE001
+                    out["config4_transforms"] = {"error": repr(e)}
+    except Exception as e:  # noqa: BLE001
+        out["other_configs_error"] = repr(e)
+    return out
+
+
 def launch_ranks(a, argv, shard, cfg):
     """--gpus N > 1 without a launcher: this process stays off the GPU (no torch, no engine library), measures the
     CPU baseline and the oracle's answers on an idle host, then runs the N ranks as a child torch.distributed.run and
@@ -237,6 +269,10 @@ def main():
                          "schedule): a rocprofv3 --stats run of the command then sees the headline kernels only")
     ap.add_argument("--streamed", action="store_true", help="(kept for older scripts: the streamed schedule is now on by default)")
     ap.add_argument("--latency-batches", default="1,8", help="batch sizes of the config 1 latency section")
+    ap.add_argument("--other-configs", default="3,4",
+                    help="which of BASELINE's other one-GPU configs a one-GPU run also measures after the timed region "
+                         "(tools/bench_configs.py: 3 = circuit bootstrap at the PoC parameters, 4 = batched N = 2048 transforms); "
+                         "'' = none.  Never part of `value`; --headline-only skips them too")
     ap.add_argument("--extras-reps", type=int, default=5, help="repetitions of each measurement after the timed region")
     ap.add_argument("--pipelined", action="store_true",
                     help="also time (after the timed region, one GPU) the same K steps issued alternately on two contexts / "
@@ -472,6 +508,12 @@ def main():
             streamed["hipgraph"] = {"error": str(e)}
         eng.set_option(T.OPT_STREAMED_GRAPH, 0)
 
+    # BASELINE configs 3 and 4 (the other workloads one GPU can run), through tools/bench_configs.py: the same functions, their
+    # lines collected instead of printed.  A failure here must not cost the main metric line.
+    other = None
+    if extras and a.other_configs.strip():
+        other = other_configs(T, a)
+
     pipelined = None
     if world == 1 and a.pipelined:
         job2 = shard.GateJob(cfg, SEED, device=device, lib_path=a.lib)  # second context: its own stream and key replicas
@@ -588,6 +630,8 @@ def main():
             line["config1_latency"] = latency
         if streamed is not None:
             line["streamed_schedule"] = streamed
+        if other is not None:
+            line.update(other)
         if pipelined is not None:
             line["pipelined_two_contexts"] = pipelined
         if cpu_line is not None:

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -46,6 +47,40 @@ struct Block {
     int current = -1;
 };
 thread_local Block *t_blk = nullptr;
+
+// Fiber stacks are reused across blocks and launches (a pool shared by the worker threads): mapping and unmapping 256-512
+// stacks per emulated workgroup, and faulting their pages in again, was ~40 % of the CPU suite's time.  The sanitizer build
+// maps fresh stacks every time instead, so that no redzone poisoning of an earlier fiber can outlive its stack.
+#if defined(__SANITIZE_ADDRESS__)
+constexpr bool kPoolStacks = false;
+#else
+constexpr bool kPoolStacks = true;
+#endif
+std::mutex g_stack_mu;
+std::vector<void *> g_stack_pool;
+void *stack_acquire() {
+    if (kPoolStacks) {
+        std::lock_guard<std::mutex> lk(g_stack_mu);
+        if (!g_stack_pool.empty()) {
+            void *p = g_stack_pool.back();
+            g_stack_pool.pop_back();
+            return p;
+        }
+    }
+    void *p = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) { perror("mmap"); abort(); }
+    return p;
+}
+void stack_release(void *p) {
+    if (kPoolStacks) {
+        std::lock_guard<std::mutex> lk(g_stack_mu);
+        if (g_stack_pool.size() < 4096) {  // 8 worker threads x 512 work-items: bounds the mapped (mostly untouched) memory
+            g_stack_pool.push_back(p);
+            return;
+        }
+    }
+    munmap(p, kStack);
+}
 
 void yield() { swapcontext(&t_blk->fibers[t_blk->current].ctx, &t_blk->sched); }
 
@@ -103,8 +138,7 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
     for (unsigned t = 0; t < nt; t++) {
         Fiber &f = b.fibers[t];
         f.tid = t;
-        f.stack = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-        if (f.stack == MAP_FAILED) { perror("mmap"); abort(); }
+        f.stack = stack_acquire();
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
         f.ctx.uc_stack.ss_size = kStack;
@@ -127,7 +161,7 @@ void run_block(const std::function<void()> &body, Dim3 grid, Dim3 block, unsigne
             if (!f.done) alive++;
         }
     }
-    for (auto &f : b.fibers) munmap(f.stack, kStack);
+    for (auto &f : b.fibers) stack_release(f.stack);
     free(smem_raw);
     t_blk = nullptr;
 }

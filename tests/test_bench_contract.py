@@ -124,7 +124,8 @@ def test_bench_post_region_sections_on_emulator(emu_lib):
     """what the default one-GPU command measures after the timed region: BASELINE config 1 (latency through
     tfhe_amd_bootstrap) and config 2's literal schedule (one launch per CMux), both bit-compared with the headline outputs"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", emu_lib, "--batch", "2", "--steps", "1",
-                          "--warmup", "0", "--no-cpu-baseline", "--extras-reps", "1", "--latency-batches", "1,2", "--lwe-n", "24"],
+                          "--warmup", "0", "--no-cpu-baseline", "--extras-reps", "1", "--latency-batches", "1,2", "--lwe-n", "24",
+                          "--other-configs", "4"],  # (config 3's 2049-coefficient private key switch is minutes on the emulator)
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
@@ -135,6 +136,9 @@ def test_bench_post_region_sections_on_emulator(emu_lib):
     assert st["launches"] == 24 + 3 and st["identical_to_persistent"] is True and st["roofline"]["bound"] == "hbm"
     assert st["roofline"]["algorithmic_bytes_per_launch"] == 2 * 16388 + 65536
     assert st["hipgraph"].get("identical_to_persistent") is True
+    c4 = d["config4_transforms"]["lines"]
+    assert any("execute_reverse_torus64 N=2048" in ln["workload"] for ln in c4) and all(ln["roofline"]["bound"] == "hbm" for ln in c4 if "roofline" in ln)
+    assert "config3_circuit_bootstrap" not in d
     assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # never inside `value`
 
 
