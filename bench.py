@@ -235,8 +235,10 @@ def launch_ranks(a, argv, shard, cfg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    # defaults: the chip's clock ramps over a process's first launches (1.9 -> 2.15 -> 2.2 GHz over three 16 ms launches,
+    # profiles/r04_wave_probe.txt), so a run without flags warms up three times before it times ten steps (0.2 s in all)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None,
                     help="bootstraps per GPU per step (weak scaling); default: 4096 on one GPU (BASELINE config 2)")
     ap.add_argument("--total", type=int, default=None,

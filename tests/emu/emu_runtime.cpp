@@ -6,6 +6,9 @@
 #include <sys/mman.h>
 #include <time.h>
 #include <ucontext.h>
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -18,7 +21,12 @@ namespace emu {
 thread_local Dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 
 namespace {
+// (ASan clears the shadow of a fiber's whole stack at every swapcontext: the sanitizer build keeps it as small as the kernels allow)
+#if defined(__SANITIZE_ADDRESS__)
+constexpr size_t kStack = 192 * 1024;
+#else
 constexpr size_t kStack = 512 * 1024;
+#endif
 
 struct Rendezvous {
     int expected = 0, count = 0;
@@ -49,13 +57,15 @@ struct Block {
 thread_local Block *t_blk = nullptr;
 
 // Fiber stacks are reused across blocks and launches (a pool shared by the worker threads): mapping and unmapping 256-512
-// stacks per emulated workgroup, and faulting their pages in again, was ~40 % of the CPU suite's time.  The sanitizer build
-// maps fresh stacks every time instead, so that no redzone poisoning of an earlier fiber can outlive its stack.
+// stacks per emulated workgroup, and faulting their pages in again, was ~40 % of the CPU suite's time (and nearly all of a
+// sanitizer run's).  Under AddressSanitizer a reused stack is unpoisoned first, so that no redzone poisoning left by an earlier
+// fiber (whose frames never unwound past the trampoline) can outlive it.
 #if defined(__SANITIZE_ADDRESS__)
-constexpr bool kPoolStacks = false;
+#define EMU_UNPOISON_STACK(p, n) ASAN_UNPOISON_MEMORY_REGION((p), (n))
 #else
-constexpr bool kPoolStacks = true;
+#define EMU_UNPOISON_STACK(p, n) ((void)0)
 #endif
+constexpr bool kPoolStacks = true;
 std::mutex g_stack_mu;
 std::vector<void *> g_stack_pool;
 void *stack_acquire() {
@@ -64,6 +74,7 @@ void *stack_acquire() {
         if (!g_stack_pool.empty()) {
             void *p = g_stack_pool.back();
             g_stack_pool.pop_back();
+            EMU_UNPOISON_STACK(p, kStack);
             return p;
         }
     }

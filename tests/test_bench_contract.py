@@ -78,7 +78,7 @@ def test_bench_dist_flag_single_rank_on_emulator(emu_lib):
     """--dist: the same branch with world size 1 (what a 1-GPU box can run of the driver's N > 1 launch)"""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + (os.getpid() % 90)))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", emu_lib, "--dist", "--backend", "gloo", "--total", "2",
-                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--lwe-n", "24"], capture_output=True, text=True, timeout=600,
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--lwe-n", "24", "--headline-only"], capture_output=True, text=True, timeout=600,
                          cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
