@@ -107,6 +107,22 @@ def test_bench_starts_its_own_ranks_on_emulator(emu_lib):
     assert abs(d["value"] - 5 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
+def test_bench_eight_self_launched_ranks_on_emulator(emu_lib):
+    """the shape of the driver's largest run -- `bench.py --gpus 8`, no launcher -- with gloo and the emulator build: eight ranks,
+    a ragged contiguous split (19 = 3 + 3 + 3 + 2 x 5), every rank counted"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "TFHE_BENCH_HANDOFF")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--lib", emu_lib, "--backend", "gloo",
+                          "--total", "19", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--lwe-n", "8"], capture_output=True,
+                         text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["scaling"] == "strong"
+    assert [(r["rank"], r["batch"]) for r in d["ranks"]] == [(0, 3), (1, 3), (2, 3), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2)]
+    assert d["config"]["total_per_step"] == 19 and d["decrypt_check"] is True
+    assert abs(d["value"] - 19 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["ms_per_step"] * 1e-3 >= max(r["seconds"] for r in d["ranks"]) - 1e-9  # the MAX over ranks is what is reported
+
+
 def test_bench_never_reports_ranks_that_did_not_run(emu_lib):
     """--gpus 2 with the self-launch disabled and no launcher, and --gpus 2 under a one-rank world: non-zero exit, no line"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TFHE_BENCH_HANDOFF")}
