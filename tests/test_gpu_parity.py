@@ -304,6 +304,25 @@ def test_gate_path_8wave_workgroups_other_gadgets(gpu_lib):
         P.check_gate_wide_batch(gpu_lib, l=l, Bgbit=Bgbit, B=1031, seed=seed)
 
 
+def test_kernel_choice_boundaries(gpu_lib):
+    """the library picks the blind-rotation form by batch size (split kernel up to 512, 4-wave workgroups up to 1024, 8-wave
+    above): a sample's output must not depend on the batch it travels in -- batches on both sides of each boundary, the
+    library's own choice, against one reference run (oracle-checked on a subset) of the same inputs"""
+    N, n, l, Bgbit, t, bb = 1024, 8, 2, 10, 8, 2
+    s = P.GateSetup(gpu_lib, N, n, l, Bgbit, t, bb)
+    try:
+        rs = np.random.RandomState(512)
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(1026, n + 1)).astype(np.int32)
+        ref = s.eng.bootstrap(1 << 29, x)
+        for i in (0, 511, 512, 1023, 1024, 1025):
+            assert np.array_equal(ref[i], O.bootstrap32(N, s.bk, s.ks, 1 << 29, x[i], l, Bgbit, t, bb)), i
+        for B in (1, 2, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025):
+            assert np.array_equal(s.eng.bootstrap(1 << 29, x[:B]), ref[:B]), B
+            assert np.array_equal(s.eng.bootstrap_woks(1 << 29, x[:B]), s.eng.bootstrap_woks(1 << 29, x)[:B]), B
+    finally:
+        s.close()
+
+
 def test_two_contexts_on_two_host_threads(gpu_lib):
     """SURVEY 8(b) threading contract: a context is bound to one stream and is not thread-safe, DISTINCT contexts are
     independent -- two host threads, one context each (own stream, own key replicas), bootstrapping different batches at the
