@@ -364,7 +364,14 @@ def main():
             if a.backend == "nccl":
                 torch.cuda.synchronize()
         finally:
+            # the banner is a C printf: it sits in libc's stdio buffer (stdout is a pipe: fully buffered) until that buffer is
+            # flushed -- at exit, i.e. AFTER the JSON line and to the restored descriptor -- unless it is flushed here
             sys.stdout.flush()
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 

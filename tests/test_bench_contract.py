@@ -62,6 +62,7 @@ def test_bench_multi_rank_path_on_emulator(emu_lib):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout  # rank 0 only
+    assert [ln for ln in out.stdout.splitlines() if ln.strip()] == lines, "stdout must hold the one JSON line and nothing else"
     d = json.loads(lines[0])
     for k in CONTRACT:
         assert k in d, k
