@@ -34,7 +34,8 @@ def main():
         jobs.append((lib, job, eng, x_d, u_d, o_d, [eng.event() for _ in range(3)], [], []))
     ref = None
     for r in range(a.rounds + 1):
-        for lib, job, eng, x_d, u_d, o_d, ev, br, ks in jobs:
+        # list order forwards and backwards in alternate rounds: a build is not always measured behind the same neighbour
+        for lib, job, eng, x_d, u_d, o_d, ev, br, ks in (jobs if r % 2 == 0 else jobs[::-1]):
             eng.record(ev[0])
             eng._chk(eng.lib.tfhe_amd_bootstrap_woks(eng.ctx, u_d.ptr, 1 << 29, x_d.ptr, a.batch))
             eng.record(ev[1])

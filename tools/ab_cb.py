@@ -36,7 +36,7 @@ def main():
         eng.set_bootstrap_key(eng.gsw_from_torus(bk))
         jobs.append((lib, eng, eng.to_device(abar), eng.alloc(a.batch * (N2 + 1) * 8), [eng.event(), eng.event()], []))
     for r in range(a.rounds + 1):
-        for lib, eng, d_abar, d_out, ev, ts in jobs:
+        for lib, eng, d_abar, d_out, ev, ts in (jobs if r % 2 == 0 else jobs[::-1]):  # alternate the list order
             eng.record(ev[0])
             eng._chk(eng.lib.tfhe_amd_cb_bootstrap_woks(eng.ctx, d_out.ptr, 1 << 55, d_abar.ptr, a.batch))
             eng.record(ev[1])

@@ -52,7 +52,7 @@ def main():
                          xv=cb._dev(x_priv), ov=cb._dev(np.zeros((Bp, 2, N1), np.int32)),
                          ev=BC.Events(cb.lib, cb.ctx), t=dict(gate=[], preks=[], privks=[])))
     for r in range(a.rounds + 1):
-        for j in jobs:
+        for j in (jobs if r % 2 == 0 else jobs[::-1]):  # alternate the list order
             eg, ep, cb, ev = j["eg"], j["ep"], j["cb"], j["ev"]
             e0, e1 = eg.event(), eg.event()
             eg.record(e0); eg._chk(eg.lib.tfhe_amd_keyswitch(eg.ctx, j["og"].ptr, j["xg"].ptr, 4096)); eg.record(e1)
