@@ -30,7 +30,9 @@ rocprofv3 scripts under tools/ pass so that the default command's kernel table h
   streamed_schedule   BASELINE config 2's literal schedule: one external-product launch per CMux step
   config3_circuit_bootstrap, config4_transforms   BASELINE configs 3 and 4 as tools/bench_configs.py measures them (--other-configs)
 
-The JSON line also carries
+The ONE JSON line on stdout is kept compact (~3 KB: a few numbers per section); the full record -- every note, stage and
+per-transform line described below -- is written to gpurun_out/bench_detail_<n>gpu.json (--detail PATH), named by the line's
+`detail` key.  The record carries
   roofline      dominant kernel (k_blind_rotate).  bound = "fp64_issue": wave64 fp64 instructions
                 per second (2,144 per CMux per sample, the floor of the bit-exact DAG) / HIP-event
                 kernel time, against 1024 SIMDs x 2.4 GHz / 4 cycles.  `hbm_contract` keeps the
@@ -186,6 +188,88 @@ def other_configs(T, a):
     return out
 
 
+def write_detail(line, a):
+    """the FULL record (every note, every stage, every config-4 line) as a file: gpurun_out/bench_detail_<n>gpu.json next to the
+    repository root (gpurun merges that directory back; the driver pulls it), or --detail PATH.  Returns the path or None."""
+    path = a.detail or os.path.join(ROOT, "gpurun_out", f"bench_detail_{line['n_gpus']}gpu.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(line, f, indent=1)
+        return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError:
+        return None
+
+
+def compact_line(full, detail_path):
+    """The ONE JSON line on stdout, kept to ~3 KB: whoever stores only a tail of a run's stdout must still hold the whole line.
+    Contract keys first, with `roofline` and `cpu_baseline` in the contract's shape; the other BASELINE configs measured after the
+    timed region as a few numbers each, at the END of the line; every note, stage and per-transform line is in the detail file."""
+    r = full["roofline"]
+    c = full["config"]
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data")}
+    out["config"] = {"workload": c["baseline_config"] + "; " + c["workload"].split(", ", 1)[-1].split(", persistent")[0],
+                     "batch_per_gpu": c["batch_per_gpu"], "total_per_step": c["total_per_step"],
+                     "parallelism": f"batch-sharded x{full['n_gpus']}, keys replicated, no data-path collective",
+                     "process_group": c["process_group"], "library": c["library"]}
+    if "launched_by" in c:
+        out["config"]["launched_by"] = "bench.py GPU-free parent -> torch.distributed.run child"
+    out["roofline"] = {"bound": r["bound"], "kernel": r["kernel"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+                       "frac": r["frac"], "traffic": r["traffic"], "persistent_algorithmic_bytes": r["persistent_algorithmic_bytes"],
+                       "kernel_ms": r["kernel_ms"], "fp64_issue_frac": r["fp64_issue"]["frac"],
+                       "hbm_contract_frac": r["hbm_contract"]["frac"], "hbm_contract_bytes": r["hbm_contract"]["algorithmic_bytes_per_launch"],
+                       "note": "frac = B*n*173,056 flop / kernel time / 78.6 TF (SURVEY 8d, persistent variant: compute-bound)"}
+    if "cpu_baseline" in full:
+        b = full["cpu_baseline"]
+        out["cpu_baseline"] = {"value": b["value"], "unit": b["unit"], "cores": b["cores"], "kind": b["kind"],
+                               "sample": b["sample"].split(" composed from")[0] + (" (reference FMA assembly + key switch)" if b["kind"] == "reference" else ""),
+                               "per_core_value": b.get("per_core_value"), "measured_by": (b.get("measured_by") or "").split(":")[0].split(" (")[0]}
+    out["ranks_seen"] = full["ranks_seen"]
+    if full["n_gpus"] > 1:
+        out["ranks"] = [[x["rank"], x["device"], x["batch"], round(x["seconds"], 4)] for x in full["ranks"]]  # rank, device, batch, s
+    out["kernels_ms"] = {k: round(v, 4) for k, v in full["kernels_ms"].items()}
+    out["checks"] = {"decrypt": full["decrypt_check"],
+                     "oracle_bit_identical": None if full["oracle_bit_check"] is None else full["oracle_bit_check"]["identical"],
+                     "tail_identical_to_front": None if full["tail_check"] is None else full["tail_check"]["identical_to_front"]}
+    lat = full.get("config1_latency")
+    if lat:
+        out["config1_latency"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in lat.items()
+                                  if k.startswith("latency_batch") and not k.endswith("_wall_ms")}
+        out["config1_latency"]["identical_to_headline"] = all(v for k, v in lat.items() if k.endswith("identical_to_headline_outputs"))
+    st = full.get("streamed_schedule")
+    if st:
+        out["config2_streamed"] = {"bootstraps_per_s": round(st["value"], 1), "launches": st["launches"],
+                                   "extprod_launch_us": round(st["extprod_launch_us"], 3), "hbm_frac": round(st["roofline"]["frac"], 4),
+                                   "identical_to_persistent": st["identical_to_persistent"],
+                                   "hipgraph_bootstraps_per_s": (round(st["hipgraph"]["value"], 1) if "value" in st.get("hipgraph", {}) else None)}
+    c3 = full.get("config3_circuit_bootstrap")
+    if c3:
+        if "error" in c3:
+            out["config3_circuit_bootstrap"] = {"error": c3["error"][:200]}
+        else:
+            br = c3.get("blind_rotation_roofline", {})
+            out["config3_circuit_bootstrap"] = {"circuit_bootstraps_per_s": round(c3["circuit_bootstraps_per_s"], 1), "ms_per_batch": round(c3["ms_min"], 3),
+                                                "blind_rotation_ms": round(c3["stages_ms"]["circuitBootstrapWoKS (one of l1)"], 3),
+                                                "blind_rotation_flops_frac": (round(br["fp64_valu_frac"], 4) if "fp64_valu_frac" in br else None),
+                                                "lut_evaluations_per_s": round(c3["lut_evaluation"]["lut_evaluations_per_s"], 1)}
+    c4 = full.get("config4_transforms")
+    if c4:
+        if "error" in c4:
+            out["config4_transforms"] = {"error": c4["error"][:200]}
+        else:  # HBM fraction (algorithmic bytes / time / 8 TB/s) per conversion, in the order rev_int, rev_t64, dir_t64, dir_t32
+            grp = {}
+            for ln in c4["lines"]:
+                if "roofline" in ln:
+                    w = ln["workload"].split()
+                    grp.setdefault(w[1] + " " + w[2], []).append(round(ln["roofline"]["frac"], 3))
+            out["config4_transforms"] = {"hbm_frac [reverse_int, reverse_torus64, direct_torus64, direct_torus32]": grp}
+    if "pipelined_two_contexts" in full:
+        out["pipelined_two_contexts"] = {"value": round(full["pipelined_two_contexts"]["value"], 1)}
+    out["detail"] = detail_path
+    return out
+
+
 def launch_ranks(a, argv, shard, cfg):
     """--gpus N > 1 without a launcher: this process stays off the GPU (no torch, no engine library), measures the
     CPU baseline and the oracle's answers on an idle host, then runs the N ranks as a child torch.distributed.run and
@@ -228,7 +312,7 @@ def launch_ranks(a, argv, shard, cfg):
     d = json.loads(lines[0])
     if d.get("n_gpus") != a.gpus or d.get("ranks_seen") != a.gpus:
         raise SystemExit(f"bench.py: asked for {a.gpus} ranks, the line reports n_gpus={d.get('n_gpus')} ranks_seen={d.get('ranks_seen')}")
-    d["config"]["launched_by"] = "bench.py parent process (GPU-free) -> python -m torch.distributed.run --nproc-per-node %d" % a.gpus
+    d["config"]["launched_by"] = "bench.py GPU-free parent -> python -m torch.distributed.run --nproc-per-node %d" % a.gpus
     print(json.dumps(d), flush=True)
 
 
@@ -276,6 +360,9 @@ def main():
                          "(tools/bench_configs.py: 3 = circuit bootstrap at the PoC parameters, 4 = batched N = 2048 transforms); "
                          "'' = none.  Never part of `value`; --headline-only skips them too")
     ap.add_argument("--extras-reps", type=int, default=5, help="repetitions of each measurement after the timed region")
+    ap.add_argument("--detail", default=None,
+                    help="where the FULL record (all notes, stages, per-transform lines) is written as a file; default: "
+                         "gpurun_out/bench_detail_<n>gpu.json under the repository.  stdout carries the compact line only")
     ap.add_argument("--pipelined", action="store_true",
                     help="also time (after the timed region, one GPU) the same K steps issued alternately on two contexts / "
                          "streams: consecutive batches are independent, the next blind rotation fills the CUs the current "
@@ -646,7 +733,8 @@ def main():
         if cpu_line is not None:
             cpu_line = dict(cpu_line, measured_by=baseline_by)
             line["cpu_baseline"] = cpu_line
-        print(json.dumps(line), flush=True)
+        detail_path = write_detail(line, a)
+        print(json.dumps(compact_line(line, detail_path)), flush=True)
     job.close()
     if dist is not None:
         dist.destroy_process_group()

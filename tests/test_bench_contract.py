@@ -13,13 +13,15 @@ CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
 
 
-def test_bench_line_on_emulator(emu_lib):
+def test_bench_line_on_emulator(emu_lib, tmp_path):
+    detail = str(tmp_path / "detail.json")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", emu_lib, "--batch", "2", "--steps", "1",
-                          "--warmup", "0", "--cpu-seconds", "1", "--headline-only"], capture_output=True, text=True, timeout=600,
-                         cwd=ROOT)
+                          "--warmup", "0", "--cpu-seconds", "1", "--headline-only", "--detail", detail], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
+    assert len(lines[0]) < 3500, "the stdout line must stay compact: a stored tail of the run's stdout has to hold all of it"
     d = json.loads(lines[0])
     for k in CONTRACT:
         assert k in d, k
@@ -27,26 +29,31 @@ def test_bench_line_on_emulator(emu_lib):
     assert d["unit"] == "bootstraps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    # SURVEY 8(d), persistent variant: compute-bound, flops against the fp64 vector peak; the north-star HBM accounting
-    # rides along as hbm_contract, the issue-slot diagnostic as fp64_issue
+    # SURVEY 8(d), persistent variant: compute-bound, flops against the fp64 vector peak; the north-star HBM accounting and the
+    # issue-slot diagnostic ride along as single fractions (their full objects are in the detail file)
     assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert abs(r["peak"] - 78.6) < 1e-9 and r["flop_per_cmux"] == 173056 and r["flops_frac"] == r["frac"]
+    assert abs(r["peak"] - 78.6) < 1e-9 and "traffic" in r
     assert abs(r["achieved"] * 1e12 - 2 * 630 * 173056 / (r["kernel_ms"] * 1e-3)) < 1e-6 * r["achieved"] * 1e12
     assert r["persistent_algorithmic_bytes"] == 2 * (2524 + 4100) + 630 * 65536
-    i = r["fp64_issue"]
-    assert i["bound"] == "fp64_issue" and abs(i["frac"] - i["achieved"] / i["peak"]) < 1e-12
-    assert abs(i["peak"] - 1024 * 2.4 / 4) < 1e-9 and i["fp64_wave_instr_per_cmux"] == 2144
-    assert d["ranks_seen"] == 1 and d["ranks"] == [{"rank": 0, "device": 0, "batch": 2, "seconds": d["ranks"][0]["seconds"]}]
-    assert "config1_latency" not in d and "streamed_schedule" not in d  # --headline-only
-    h = r["hbm_contract"]
-    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
     # 16,388 B per CMux per sample + 65,536 B key row per CMux per launch, n = 630 CMux
-    assert h["algorithmic_bytes_per_launch"] == 2 * 630 * 16388 + 630 * 65536
-    assert "traffic" in r
+    assert r["hbm_contract_bytes"] == 2 * 630 * 16388 + 630 * 65536
+    assert abs(r["hbm_contract_frac"] - r["hbm_contract_bytes"] / (r["kernel_ms"] * 1e-3) / 8.0e12) < 1e-9
+    assert abs(r["fp64_issue_frac"] - 2 * 630 * 2144 / (r["kernel_ms"] * 1e-3) / (1024 * 2.4e9 / 4)) < 1e-9
+    assert d["ranks_seen"] == 1 and "ranks" not in d
+    assert "config1_latency" not in d and "config2_streamed" not in d  # --headline-only
     c = d["cpu_baseline"]
-    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "bootstraps/s"
-    assert d["decrypt_check"] is True
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "bootstraps/s" and c["sample"]
+    assert d["checks"]["decrypt"] is True
     assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # the full record behind the line
+    assert d["detail"] == detail
+    f = json.load(open(detail))
+    assert f["value"] == d["value"] and f["roofline"]["frac"] == r["frac"] and f["roofline"]["flop_per_cmux"] == 173056
+    i, h = f["roofline"]["fp64_issue"], f["roofline"]["hbm_contract"]
+    assert i["bound"] == "fp64_issue" and abs(i["frac"] - i["achieved"] / i["peak"]) < 1e-12 and i["fp64_wave_instr_per_cmux"] == 2144
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
+    assert f["ranks"] == [{"rank": 0, "device": 0, "batch": 2, "seconds": f["ranks"][0]["seconds"]}]
+    assert f["decrypt_check"] is True and "scaling_note" in f["config"]
 
 
 def test_bench_multi_rank_path_on_emulator(emu_lib):
@@ -67,11 +74,11 @@ def test_bench_multi_rank_path_on_emulator(emu_lib):
     for k in CONTRACT:
         assert k in d, k
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
-    assert d["ranks_seen"] == 2 and [(r["rank"], r["batch"]) for r in d["ranks"]] == [(0, 3), (1, 2)]
+    assert d["ranks_seen"] == 2 and [(r[0], r[2]) for r in d["ranks"]] == [(0, 3), (1, 2)]  # [rank, device, batch, seconds]
     assert "rank 0, before torch" in d["cpu_baseline"]["measured_by"]
     assert d["config"]["total_per_step"] == 5 and d["config"]["batch_per_gpu"] == 3  # ragged: 3 + 2
     assert "gloo, world 2" in d["config"]["process_group"]
-    assert d["decrypt_check"] is True
+    assert d["checks"]["decrypt"] is True
     assert abs(d["value"] - 5 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
@@ -101,10 +108,10 @@ def test_bench_starts_its_own_ranks_on_emulator(emu_lib):
     for k in CONTRACT:
         assert k in d, k
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "strong"
-    assert [(r["rank"], r["batch"]) for r in d["ranks"]] == [(0, 3), (1, 2)]
+    assert [(r[0], r[2]) for r in d["ranks"]] == [(0, 3), (1, 2)]
     assert "parent" in d["cpu_baseline"]["measured_by"] and d["cpu_baseline"]["value"] > 0
-    assert "bench.py parent process" in d["config"]["launched_by"]
-    assert d["decrypt_check"] is True
+    assert "GPU-free parent" in d["config"]["launched_by"]
+    assert d["checks"]["decrypt"] is True
     assert abs(d["value"] - 5 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
@@ -118,10 +125,10 @@ def test_bench_eight_self_launched_ranks_on_emulator(emu_lib):
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["scaling"] == "strong"
-    assert [(r["rank"], r["batch"]) for r in d["ranks"]] == [(0, 3), (1, 3), (2, 3), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2)]
-    assert d["config"]["total_per_step"] == 19 and d["decrypt_check"] is True
+    assert [(r[0], r[2]) for r in d["ranks"]] == [(0, 3), (1, 3), (2, 3), (3, 2), (4, 2), (5, 2), (6, 2), (7, 2)]
+    assert d["config"]["total_per_step"] == 19 and d["checks"]["decrypt"] is True
     assert abs(d["value"] - 19 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert d["ms_per_step"] * 1e-3 >= max(r["seconds"] for r in d["ranks"]) - 1e-9  # the MAX over ranks is what is reported
+    assert d["ms_per_step"] * 1e-3 >= max(r[3] for r in d["ranks"]) - 1e-3  # the MAX over ranks is what is reported
 
 
 def test_bench_never_reports_ranks_that_did_not_run(emu_lib):
@@ -147,15 +154,17 @@ def test_bench_post_region_sections_on_emulator(emu_lib):
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     lat = d["config1_latency"]
-    assert lat["latency_batch1_ms"] > 0 and lat["latency_batch2_ms"] > 0
-    assert lat["batch1_identical_to_headline_outputs"] is True and lat["batch2_identical_to_headline_outputs"] is True
-    st = d["streamed_schedule"]
-    assert st["launches"] == 24 + 3 and st["identical_to_persistent"] is True and st["roofline"]["bound"] == "hbm"
-    assert st["roofline"]["algorithmic_bytes_per_launch"] == 2 * 16388 + 65536
-    assert st["hipgraph"].get("identical_to_persistent") is True
-    c4 = d["config4_transforms"]["lines"]
-    assert any("execute_reverse_torus64 N=2048" in ln["workload"] for ln in c4) and all(ln["roofline"]["bound"] == "hbm" for ln in c4 if "roofline" in ln)
+    assert lat["latency_batch1_ms"] > 0 and lat["latency_batch2_ms"] > 0 and lat["identical_to_headline"] is True
+    st = d["config2_streamed"]
+    assert st["launches"] == 24 + 3 and st["identical_to_persistent"] is True and st["hipgraph_bootstraps_per_s"] > 0
+    c4 = d["config4_transforms"]["hbm_frac [reverse_int, reverse_torus64, direct_torus64, direct_torus32]"]
+    assert any(k.startswith("N=2048") for k in c4) and any(k.startswith("N=1024") for k in c4)
     assert "config3_circuit_bootstrap" not in d
+    f = json.load(open(os.path.join(ROOT, d["detail"])))  # the full record: every stage and line
+    assert f["streamed_schedule"]["roofline"]["bound"] == "hbm" and f["streamed_schedule"]["roofline"]["algorithmic_bytes_per_launch"] == 2 * 16388 + 65536
+    assert f["streamed_schedule"]["hipgraph"].get("identical_to_persistent") is True
+    assert f["config1_latency"]["batch1_identical_to_headline_outputs"] is True
+    assert any("execute_reverse_torus64 N=2048" in ln["workload"] for ln in f["config4_transforms"]["lines"])
     assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # never inside `value`
 
 
