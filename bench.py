@@ -159,7 +159,7 @@ def oracle_rows(B):
 
 def other_configs(T, a):
     """config3_circuit_bootstrap / config4_transforms of the bench line: tools/bench_configs.py's own measurements (HIP events
-    through the C ABI, synthetic keys), run after the timed region; their per-line prints go to stderr"""
+    through the C ABI, synthetic keys), run after the timed region; their per-line prints are dropped (stderr stays quiet: the driver keeps a tail of it)"""
     import contextlib
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     out = {}
@@ -168,7 +168,8 @@ def other_configs(T, a):
         small = a.lwe_n is not None  # the test hook of the CPU emulator runs: tiny sizes
         ns = argparse.Namespace(small=small, lib=a.lib, reps=min(3, max(1, a.extras_reps)), cb_batch=1024, batch=8192)
         want = {w.strip() for w in a.other_configs.split(",") if w.strip()}
-        with contextlib.redirect_stdout(sys.stderr):
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):  # their per-line prints: dropped (the lines are returned, and kept in the detail file)
             if "3" in want:
                 try:
                     cb, lut = BC.bench_cb(T, ns)
