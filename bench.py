@@ -210,7 +210,7 @@ def compact_line(full, detail_path):
     c = full["config"]
     out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data")}
-    out["config"] = {"workload": c["baseline_config"] + "; " + c["workload"].split(", ", 1)[-1].split(", persistent")[0],
+    out["config"] = {"workload": c["workload"].split(", persistent")[0] + "; persistent kernel, inputs resident in HBM",
                      "batch_per_gpu": c["batch_per_gpu"], "total_per_step": c["total_per_step"],
                      "parallelism": f"batch-sharded x{full['n_gpus']}, keys replicated, no data-path collective",
                      "process_group": c["process_group"], "library": c["library"]}
