@@ -6,9 +6,13 @@
 //   new_*_table / *_get_buffer / fft / ifft / *_model   CB/spqlios/spqlios-fft-impl.cpp:158-203,400-447 and the
 //                                         assembly cores spqlios-{i,}fft-fma.s          -> tfhe_amd_{i,}fft_f64
 // One polynomial per call, synchronous (copy in, one kernel, copy out), like the functions replaced.
+// Calls from several host threads are serialised per ring degree (one staging area per engine): the reference's class has
+// the same restriction by construction (its objects transform in their own scratch buffers, fft_processor_spqlios.cpp:21-24),
+// its AddMul is re-entrant -- here both are safe to call concurrently, one at a time inside.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "tfhe_amd.h"
 #include "tfhe_amd_spqlios.h"
@@ -20,6 +24,7 @@ struct Engine {
     tfhe_amd_ctx *ctx;
     int N;
     void *in_d, *out_d, *aux_d;  // one-polynomial staging, N doubles each
+    std::mutex mu;               // one call at a time on the staging area
 };
 
 [[noreturn]] void die(const char *what, int rc, tfhe_amd_ctx *c) {
@@ -32,10 +37,12 @@ void chk(int rc, Engine *e, const char *what) {
 
 Engine *engine(int N) {
     static Engine *slots[2] = {nullptr, nullptr};
+    static std::mutex create_mu;
     if (N != 1024 && N != 2048) {
         std::fprintf(stderr, "tfhe_amd_spqlios: ring degree %d is not served (1024 and 2048 are)\n", N);
         std::abort();
     }
+    std::lock_guard<std::mutex> guard(create_mu);
     Engine *&e = slots[N == 2048];
     if (e) return e;
     const char *dev = std::getenv("TFHE_AMD_DEVICE");
@@ -61,6 +68,7 @@ Engine *engine(int N) {
 // copy `in_bytes` in, run one batch-1 call, copy `out_bytes` out
 template <class Call>
 void roundtrip(Engine *e, void *res, size_t out_bytes, const void *src, size_t in_bytes, Call call, const char *what) {
+    std::lock_guard<std::mutex> guard(e->mu);
     chk(tfhe_amd_memcpy_h2d(e->ctx, e->in_d, src, in_bytes), e, "h2d");
     chk(call(e), e, what);
     chk(tfhe_amd_memcpy_d2h(e->ctx, res, e->out_d, out_bytes), e, "d2h");
@@ -111,7 +119,7 @@ FFT_Processor_Spqlios::FFT_Processor_Spqlios(const int N_)
       imag_inout_rev(nullptr), tables_direct(nullptr), tables_reverse(nullptr) {}  // no GPU work here: see the header
 FFT_Processor_Spqlios::~FFT_Processor_Spqlios() {}  // the engines live as long as the process (the reference never frees its tables either)
 
-#define SEAM_ENGINE() (tables_direct ? (Engine *)tables_direct : (Engine *)(tables_direct = engine(N)))
+#define SEAM_ENGINE() engine(N)  // created at the first call (under a lock), then a table look-up
 
 void FFT_Processor_Spqlios::execute_reverse_int(double *res, const int *a) {
     roundtrip(SEAM_ENGINE(), res, 8 * (size_t)N, a, 4 * (size_t)N,
@@ -138,6 +146,7 @@ FFT_Processor_Spqlios fftp2048(2048);
 extern "C" void LagrangeHalfCPolynomialAddMulASM(double *res, double *a, double *b, long Ns2) {
     Engine *e = engine((int)(2 * Ns2));
     const size_t bytes = 8 * (size_t)e->N;
+    std::lock_guard<std::mutex> guard(e->mu);
     chk(tfhe_amd_memcpy_h2d(e->ctx, e->out_d, res, bytes), e, "h2d");
     chk(tfhe_amd_memcpy_h2d(e->ctx, e->in_d, a, bytes), e, "h2d");
     chk(tfhe_amd_memcpy_h2d(e->ctx, e->aux_d, b, bytes), e, "h2d");

@@ -36,8 +36,8 @@ class FFT_Processor_Spqlios {
     const int Ns2;
 
    private:
-    /* same storage as the reference's object (its scratch buffers and tables); here only `tables_direct` is used:
-     * the engine of this ring degree, created at the first execute_* call.  The rest stays null. */
+    /* same storage as the reference's object (its scratch buffers and tables); all of it stays null here: the engine
+     * of this ring degree lives in the library (created at the first execute_* call, calls serialised per ring degree). */
     double* real_inout_direct;
     double* imag_inout_direct;
     double* real_inout_rev;

@@ -141,13 +141,40 @@ def test_unmodified_reference_objects_on_the_seam_library_emu(emu_lib, tmp_path)
     compare(str(tmp_path), run_both(exe, str(tmp_path), small=True))
 
 
+def run_seam_threads(seam, workdir, threads, reps):
+    """tests/compat/seam_threads.cpp linked against the seam library `seam`: (returncode, output)"""
+    os.makedirs(workdir, exist_ok=True)
+    exe = os.path.join(workdir, "seam_threads")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(HERE, "compat", "seam_threads.cpp"),
+                           "-o", exe, "-L" + os.path.dirname(seam), "-l:" + os.path.basename(seam),
+                           "-Wl,-rpath," + os.path.dirname(seam), "-lpthread"])
+    out = subprocess.run([exe, str(threads), str(reps)], capture_output=True, text=True, timeout=600)
+    return out.returncode, out.stdout + out.stderr
+
+
+def test_seam_library_from_several_host_threads_emu(emu_lib, tmp_path):
+    """four host threads through fftp1024.execute_* and LagrangeHalfCPolynomialAddMulASM at once (tests/compat/seam_threads.cpp):
+    every result equals the single-threaded one (the library serialises its calls per ring degree)"""
+    import importlib
+    b = importlib.import_module("experimental-tfhe_amd.build")
+    seam = b.build_spqlios(emu_lib, os.path.join(os.path.dirname(emu_lib), "libtfhe_amd_spqlios_emu.so"))
+    rc, text = run_seam_threads(seam, str(tmp_path), 4, 2)
+    assert rc == 0 and "seam_threads ok" in text, text
+
+
 def prerun_gpu_drivers():
     """conftest.pytest_collection_finish, on a GPU box, before this process initialises the GPU"""
-    if not (O.have_ref() and os.path.exists(SEAM_HIP)):
-        return
+    import importlib
+    b = importlib.import_module("experimental-tfhe_amd.build")
     if os.path.isdir(RUN_DIR):
         for f in os.listdir(RUN_DIR):
             os.remove(os.path.join(RUN_DIR, f))
+    if os.path.exists(b.OUT_SPQLIOS):  # the threaded check needs no reference file: only the seam library
+        rc, text = run_seam_threads(b.OUT_SPQLIOS, RUN_DIR, 8, 50)
+        with open(os.path.join(RUN_DIR, "threads.txt"), "w") as f:
+            f.write(f"rc={rc}\n{text}")
+    if not (O.have_ref() and os.path.exists(SEAM_HIP)):
+        return
     names = run_both(SEAM_HIP, RUN_DIR, small=False)
     with open(os.path.join(RUN_DIR, "done"), "w") as f:
         f.write("\n".join(names) + "\n")
@@ -162,3 +189,13 @@ def test_unmodified_reference_objects_on_the_seam_library_gpu(gpu_lib):
     names = open(done).read().split()
     assert "cbwoks" in names and "boot32" in names and len(names) == 22
     compare(RUN_DIR, names)
+
+
+@pytest.mark.gpu
+def test_seam_library_from_several_host_threads_gpu(gpu_lib):
+    """eight host threads x 50 rounds through the HIP seam library (run before this process touched the GPU)"""
+    path = os.path.join(RUN_DIR, "threads.txt")
+    assert os.path.exists(path), "the threaded seam check did not run before the session's GPU tests"
+    text = open(path).read()
+    assert text.startswith("rc=0") and "seam_threads ok: 8 threads x 50 rounds" in text, text
+
