@@ -9,7 +9,8 @@
 // These have C++ linkage on the PoC's own types, so this file is compiled NEXT TO the PoC's poc_types.h
 // (add it to the PoC's build in place of the bodies above) and linked with
 // libtfhe_amd.so.  One engine per `env` pointer, created on first use: Globals::preKS, bkFFT and privKS
-// are flattened and uploaded once.
+// are flattened and uploaded once.  Every entry point takes the shims' one lock (tfhe_amd_compat::shim_mutex): callers on
+// several host threads are serialised.
 #include <cstring>
 #include <map>
 
@@ -64,24 +65,24 @@ Engine &engine_of(const Globals *env) {
 }
 }  // namespace
 
-void preKeySwitch(LweSample32 *result, const LweSample32 *x, const Globals *env) { engine_of(env).preKeySwitch(result, x); }
-void preModSwitch(int *result, const LweSample32 *x, const Globals *env) { engine_of(env).preModSwitch(result, x); }
-void circuitBootstrapWoKS(LweSample64 *result, const Torus64 mu, const int *abar, const Globals *env) {
+void preKeySwitch(LweSample32 *result, const LweSample32 *x, const Globals *env) { TFHE_AMD_SHIM_GUARD(); engine_of(env).preKeySwitch(result, x); }
+void preModSwitch(int *result, const LweSample32 *x, const Globals *env) { TFHE_AMD_SHIM_GUARD(); engine_of(env).preModSwitch(result, x); }
+void circuitBootstrapWoKS(LweSample64 *result, const Torus64 mu, const int *abar, const Globals *env) { TFHE_AMD_SHIM_GUARD();
     engine_of(env).circuitBootstrapWoKS(result, mu, abar);
 }
-void circuitPrivKS(TLweSample32 *result, const int u, const LweSample64 *x, const Globals *env) {
+void circuitPrivKS(TLweSample32 *result, const int u, const LweSample64 *x, const Globals *env) { TFHE_AMD_SHIM_GUARD();
     engine_of(env).circuitPrivKS(result, u, x);
 }
-void tfhe_CircuitBootstrapFFT(TGswSample32 *result, const LweSample32 *sample, const Globals *env) {
+void tfhe_CircuitBootstrapFFT(TGswSample32 *result, const LweSample32 *sample, const Globals *env) { TFHE_AMD_SHIM_GUARD();
     engine_of(env).tfhe_CircuitBootstrapFFT(result, sample);
 }
-void tfhe_CircuitBootstrapFFT_array(TGswSample32 *const *results, const LweSample32 *const *samples, const Globals *env, int count) {
+void tfhe_CircuitBootstrapFFT_array(TGswSample32 *const *results, const LweSample32 *const *samples, const Globals *env, int count) { TFHE_AMD_SHIM_GUARD();
     engine_of(env).tfhe_CircuitBootstrapFFT_array(results, samples, count);
 }
-void CMux(TLweSample32 *out, const TGswSample32 *c, const TLweSample32 *in0, const TLweSample32 *in1, const Globals *env) {
+void CMux(TLweSample32 *out, const TGswSample32 *c, const TLweSample32 *in0, const TLweSample32 *in1, const Globals *env) { TFHE_AMD_SHIM_GUARD();
     engine_of(env).CMux(out, c, in0, in1);
 }
-void tfhe_amd_dropin_release(const Globals *env) {
+void tfhe_amd_dropin_release(const Globals *env) { TFHE_AMD_SHIM_GUARD();
     auto &m = engines();
     auto it = m.find(env);
     if (it == m.end()) return;

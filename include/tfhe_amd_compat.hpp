@@ -39,6 +39,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "tfhe_amd.h"
@@ -99,11 +100,19 @@ inline std::map<ResidentKey, Resident> &registry() {
     static std::map<ResidentKey, Resident> r;
     return r;
 }
+// One lock around every public entry point of this header (the registry, its staging buffers and the PoC engines are
+// shared state): callers on several host threads are SERIALISED, never corrupted.  Concurrency that pays goes through the
+// array forms or the batch C ABI (one context per thread).
+inline std::recursive_mutex &shim_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+#define TFHE_AMD_SHIM_GUARD() std::lock_guard<std::recursive_mutex> tfhe_amd_shim_guard_(::tfhe_amd_compat::shim_mutex())
 inline int &device_ordinal() {
     static int d = 0;
     return d;
 }
-inline void set_device(int d) { device_ordinal() = d; }
+inline void set_device(int d) { TFHE_AMD_SHIM_GUARD(); device_ordinal() = d; }
 
 inline void staging(Resident &R, size_t bytes) {
     if (R.d_in) return;
@@ -239,6 +248,7 @@ inline void release_entry(std::map<ResidentKey, Resident>::iterator it) {
 // addresses the caller passes: the LweBootstrappingKeyFFT, its bkFFT array or its key-switch key.  (The copies are
 // keyed by ADDRESS and guarded by a content sample, see key_fingerprint: a key rebuilt in place is uploaded again.)
 inline void release(const void *key_object) {
+    TFHE_AMD_SHIM_GUARD();
     auto &reg = registry();
     for (auto it = reg.begin(); it != reg.end();) {
         auto cur = it++;
@@ -246,6 +256,7 @@ inline void release(const void *key_object) {
     }
 }
 inline void release_all() {
+    TFHE_AMD_SHIM_GUARD();
     while (!registry().empty()) release_entry(registry().begin());
 }
 
@@ -279,12 +290,14 @@ inline void get_tlwe(Resident &R, TLweSample *s, const void *src_d, int N) {
 }
 
 inline void tfhe_bootstrap_woKS_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x) {
+    TFHE_AMD_SHIM_GUARD();
     Resident &R = attach(bk);
     put_lwe(R, R.d_in, x, R.n);
     check(tfhe_amd_bootstrap_woks(R.ctx, (int32_t *)R.d_out, mu, (const int32_t *)R.d_in, 1), R.ctx, "bootstrap_woks");
     get_lwe(R, result, R.d_out, R.N);
 }
 inline void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x) {
+    TFHE_AMD_SHIM_GUARD();
     Resident &R = attach(bk);
     put_lwe(R, R.d_in, x, R.n);
     check(tfhe_amd_bootstrap(R.ctx, (int32_t *)R.d_out, mu, (const int32_t *)R.d_in, 1), R.ctx, "bootstrap");
@@ -292,6 +305,7 @@ inline void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *
 }
 inline void tfhe_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bkFFT, const int *bara, const int n,
                                  const TGswParams *bk_params) {
+    TFHE_AMD_SHIM_GUARD();
     Resident &R = attach_gsw(bkFFT, n, bk_params->tlwe_params->N, bk_params->l, bk_params->Bgbit);
     put_tlwe(R, R.d_in, accum, R.N);
     check(tfhe_amd_memcpy_h2d(R.ctx, R.d_aux, bara, sizeof(int) * (size_t)n), R.ctx, "h2d");
@@ -300,6 +314,7 @@ inline void tfhe_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bkFFT, 
 }
 inline void tfhe_blindRotateAndExtract_FFT(LweSample *result, const TorusPolynomial *v, const TGswSampleFFT *bk,
                                            const int barb, const int *bara, const int n, const TGswParams *bk_params) {
+    TFHE_AMD_SHIM_GUARD();
     Resident &R = attach_gsw(bk, n, bk_params->tlwe_params->N, bk_params->l, bk_params->Bgbit);
     std::vector<int32_t> rot((size_t)n + 1);
     std::memcpy(rot.data(), bara, sizeof(int) * (size_t)n);
@@ -310,6 +325,7 @@ inline void tfhe_blindRotateAndExtract_FFT(LweSample *result, const TorusPolynom
     get_lwe(R, result, R.d_out, R.N);
 }
 inline void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, const TGswParams *params) {
+    TFHE_AMD_SHIM_GUARD();
     Resident &R = attach_gsw(gsw, 1, params->tlwe_params->N, params->l, params->Bgbit);
     put_tlwe(R, R.d_in, accum, R.N);
     check(tfhe_amd_extern_mul(R.ctx, R.d_in, R.gsw, 0, 1), R.ctx, "extern_mul");
@@ -359,6 +375,7 @@ inline Resident &attach_ks(const LweKeySwitchKey *ks) {
     return it->second;
 }
 inline void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample) {
+    TFHE_AMD_SHIM_GUARD();
     Resident &R = attach_ks(ks);
     put_lwe(R, R.d_in, sample, R.N);
     check(tfhe_amd_keyswitch(R.ctx, (int32_t *)R.d_out, (const int32_t *)R.d_in, 1), R.ctx, "keyswitch");
@@ -397,17 +414,20 @@ inline void lwe_array_call(Resident &R, LweSample *const *results, int n_out, co
 }
 inline void tfhe_bootstrap_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
                                      const LweSample *const *xs, int count) {
+    TFHE_AMD_SHIM_GUARD();
     Resident &R = attach(bk);
     lwe_array_call(R, results, R.n, xs, R.n, count,
                    [&](int32_t *o, const int32_t *i) { return tfhe_amd_bootstrap(R.ctx, o, mu, i, count); }, "bootstrap (array)");
 }
 inline void tfhe_bootstrap_woKS_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
                                           const LweSample *const *xs, int count) {
+    TFHE_AMD_SHIM_GUARD();
     Resident &R = attach(bk);
     lwe_array_call(R, results, R.N, xs, R.n, count,
                    [&](int32_t *o, const int32_t *i) { return tfhe_amd_bootstrap_woks(R.ctx, o, mu, i, count); }, "bootstrap_woks (array)");
 }
 inline void lweKeySwitch_array(LweSample *const *results, const LweKeySwitchKey *ks, const LweSample *const *samples, int count) {
+    TFHE_AMD_SHIM_GUARD();
     Resident &R = attach_ks(ks);
     lwe_array_call(R, results, R.n, samples, R.N, count,
                    [&](int32_t *o, const int32_t *i) { return tfhe_amd_keyswitch(R.ctx, o, i, count); }, "keyswitch (array)");
@@ -438,28 +458,33 @@ class FFT_Processor_AMD {
         tfhe_amd_ctx_destroy(ctx_);
     }
     void execute_reverse_int(double *res, const int *a) {
+        TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(ctx_, a_, a, 4 * (size_t)N), ctx_, "h2d");
         check(tfhe_amd_ifft_int32(ctx_, (double *)b_, (const int32_t *)a_, 1), ctx_, "ifft");
         check(tfhe_amd_memcpy_d2h(ctx_, res, b_, 8 * (size_t)N), ctx_, "d2h");
     }
     void execute_reverse_torus32(double *res, const int32_t *a) { execute_reverse_int(res, (const int *)a); }
     void execute_direct_torus32(int32_t *res, const double *a) {
+        TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(ctx_, a_, a, 8 * (size_t)N), ctx_, "h2d");
         check(tfhe_amd_fft_torus32(ctx_, (int32_t *)b_, (const double *)a_, 1), ctx_, "fft");
         check(tfhe_amd_memcpy_d2h(ctx_, res, b_, 4 * (size_t)N), ctx_, "d2h");
     }
     void execute_reverse_torus64(double *res, const int64_t *a) {
+        TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(ctx_, a_, a, 8 * (size_t)N), ctx_, "h2d");
         check(tfhe_amd_ifft_torus64(ctx_, (double *)b_, (const int64_t *)a_, 1), ctx_, "ifft");
         check(tfhe_amd_memcpy_d2h(ctx_, res, b_, 8 * (size_t)N), ctx_, "d2h");
     }
     void execute_direct_torus64(int64_t *res, const double *a) {
+        TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(ctx_, a_, a, 8 * (size_t)N), ctx_, "h2d");
         check(tfhe_amd_fft_torus64(ctx_, (int64_t *)b_, (const double *)a_, 1), ctx_, "fft");
         check(tfhe_amd_memcpy_d2h(ctx_, res, b_, 8 * (size_t)N), ctx_, "d2h");
     }
     // LagrangeHalfCPolynomialAddMulASM(res, a, b, Ns2)
     void AddMul(double *res, const double *a, const double *b) {
+        TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(ctx_, c_, res, 8 * (size_t)N), ctx_, "h2d");
         check(tfhe_amd_memcpy_h2d(ctx_, a_, a, 8 * (size_t)N), ctx_, "h2d");
         check(tfhe_amd_memcpy_h2d(ctx_, b_, b, 8 * (size_t)N), ctx_, "h2d");
@@ -546,6 +571,7 @@ class PocEngine {
     // tfhe_CircuitBootstrapFFT(TGswSample32* result, const LweSample32* sample, env)   poc:823-873
     template <class TGswSample32T, class LweSample32T>
     void tfhe_CircuitBootstrapFFT(TGswSample32T *result, const LweSample32T *sample) {
+        TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(c2_, d_a_, sample->a, sizeof(int32_t) * (size_t)(p_.N1 + 1)), c2_, "h2d");
         die(tfhe_amd_circuit_bootstrap(cb_, (int32_t *)d_b_, (const int32_t *)d_a_, 1), "circuit_bootstrap");
         std::vector<int32_t> f((size_t)2 * p_.l1 * 2 * p_.N1);
@@ -560,6 +586,7 @@ class PocEngine {
     // tfhe_amd_circuit_bootstrap on the batch, one copy out, scatter into the caller's TGswSample32 objects.
     template <class TGswSample32T, class LweSample32T>
     void tfhe_CircuitBootstrapFFT_array(TGswSample32T *const *results, const LweSample32T *const *samples, int count) {
+        TFHE_AMD_SHIM_GUARD();
         if (count <= 0) return;
         const size_t rin = (size_t)p_.N1 + 1, rout = (size_t)2 * p_.l1 * 2 * p_.N1;
         array_staging(c2_, h_in_, da_in_, arr_in_bytes_, sizeof(int32_t) * rin * count, h_out_, da_out_, arr_out_bytes_,
@@ -580,6 +607,7 @@ class PocEngine {
     // circuitBootstrapWoKS(LweSample64* result, Torus64 mu, const int* abar, env)   poc:530-659
     template <class LweSample64T>
     void circuitBootstrapWoKS(LweSample64T *result, const Torus64 mu, const int *abar) {
+        TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(c2_, d_a_, abar, sizeof(int) * (size_t)(p_.n0 + 1)), c2_, "h2d");
         check(tfhe_amd_cb_bootstrap_woks(c2_, (int64_t *)d_b_, mu, (const int32_t *)d_a_, 1), c2_, "cb_bootstrap_woks");
         check(tfhe_amd_memcpy_d2h(c2_, result->a, d_b_, sizeof(int64_t) * (size_t)(p_.N2 + 1)), c2_, "d2h");
@@ -587,6 +615,7 @@ class PocEngine {
     // circuitPrivKS(TLweSample32* result, int u, const LweSample64* x, env)   poc:667-698
     template <class TLweSample32T, class LweSample64T>
     void circuitPrivKS(TLweSample32T *result, const int u, const LweSample64T *x) {
+        TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(c2_, d_a_, x->a, sizeof(int64_t) * (size_t)(p_.N2 + 1)), c2_, "h2d");
         die(tfhe_amd_privks(cb_, (int32_t *)d_b_, u, (const int64_t *)d_a_, 1), "privks");
         std::vector<int32_t> f((size_t)2 * p_.N1);
@@ -596,6 +625,7 @@ class PocEngine {
     // preKeySwitch(LweSample32* result, const LweSample32* x, env)   poc:437-465
     template <class LweSample32T>
     void preKeySwitch(LweSample32T *result, const LweSample32T *x) {
+        TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(c10_, d_a_, x->a, sizeof(int32_t) * (size_t)(p_.N1 + 1)), c10_, "h2d");
         check(tfhe_amd_keyswitch(c10_, (int32_t *)d_b_, (const int32_t *)d_a_, 1), c10_, "keyswitch");
         check(tfhe_amd_memcpy_d2h(c10_, result->a, d_b_, sizeof(int32_t) * (size_t)(p_.n0 + 1)), c10_, "d2h");
@@ -603,6 +633,7 @@ class PocEngine {
     // preModSwitch(int* result, const LweSample32* x, env)   poc:472-484
     template <class LweSample32T>
     void preModSwitch(int *result, const LweSample32T *x) {
+        TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(c2_, d_a_, x->a, sizeof(int32_t) * (size_t)(p_.n0 + 1)), c2_, "h2d");
         check(tfhe_amd_modswitch(c2_, (int32_t *)d_b_, (const int32_t *)d_a_, 1), c2_, "modswitch");
         check(tfhe_amd_memcpy_d2h(c2_, result, d_b_, sizeof(int) * (size_t)(p_.n0 + 1)), c2_, "d2h");
@@ -612,6 +643,7 @@ class PocEngine {
     // c (x) (in1 - in0) + in0 with c converted to Lagrange form on the device (tGswToFFTConvert).
     template <class TLweSample32T, class TGswSample32T>
     void CMux(TLweSample32T *out, const TGswSample32T *c, const TLweSample32T *in0, const TLweSample32T *in1) {
+        TFHE_AMD_SHIM_GUARD();
         const size_t N1 = (size_t)p_.N1, rows = (size_t)2 * p_.l1;
         std::vector<int32_t> g(rows * 2 * N1), d(4 * N1);
         for (int u = 0; u < 2; u++)

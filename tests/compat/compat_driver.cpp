@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 // -DDROPIN: the LITERAL drop-in form -- only the global-scope declarations of include/tfhe_amd_dropin.h
@@ -292,7 +293,22 @@ static int run_arr(const char *inp, const char *outp) {
     const double t1 = now_s();
     for (int c = 0; c < count; c++) tfhe_bootstrap_FFT(&rl[c], &bk, mu, &x[c]);
     const double t_loop = now_s() - t1;
+    // the one-sample shim from several host threads at once (the shims take one lock: serialised, never corrupted)
+    const int tcount = count < 8 ? count : 8;
+    std::vector<Torus32> a_thr((size_t)tcount * n);
+    std::vector<LweSample> rt((size_t)tcount);
+    for (int c = 0; c < tcount; c++) rt[c] = LweSample{a_thr.data() + (size_t)c * n, 0, 0};
+    {
+        std::vector<std::thread> pool;
+        for (int w = 0; w < 4; w++)
+            pool.emplace_back([&, w]() {
+                for (int c = w; c < tcount; c += 4) tfhe_bootstrap_FFT(&rt[c], &bk, mu, &x[c]);
+            });
+        for (auto &th : pool) th.join();
+    }
     bool same = a_arr == a_loop && a_ks == a_loop;
+    for (int c = 0; c < tcount; c++)
+        same = same && rt[c].b == rl[c].b && memcmp(rt[c].a, rl[c].a, 4 * (size_t)n) == 0;
     for (int c = 0; c < count; c++) same = same && ra[c].b == rl[c].b && rk[c].b == rl[c].b;
     Out out;
     for (int c = 0; c < count; c++) {

@@ -36,7 +36,7 @@ def build_lib_driver(engine_lib, tag):
     if not _newer(out, [src, dropin, os.path.join(INC, "tfhe_amd_dropin.h")]):
         d = os.path.dirname(dropin)
         subprocess.check_call(["g++", "-std=c++11", "-O1", "-DDROPIN", "-I" + INC, src, "-o", out, "-L" + d,
-                               "-l:" + os.path.basename(dropin), "-Wl,-rpath," + d])
+                               "-l:" + os.path.basename(dropin), "-Wl,-rpath," + d, "-lpthread"])
     return out
 
 
