@@ -41,6 +41,15 @@ ABI_SYMBOLS = [
     "tfhe_amd_privks", "tfhe_amd_circuit_bootstrap",
     "tfhe_amd_keygen_binary", "tfhe_amd_lwe_encrypt32", "tfhe_amd_lwe_phase32",
     "tfhe_amd_keygen_bk_torus32", "tfhe_amd_keygen_bk_torus64", "tfhe_amd_keygen_ks32",
+    "tfhe_amd_device_count", "tfhe_amd_device_pci_bus_id", "tfhe_amd_clock_probe",
+    "tfhe_amd_load_keyswitch_key_d", "tfhe_amd_keyswitch_key_bytes", "tfhe_amd_keyswitch_key_export",
+    "tfhe_amd_gsw_packed_bytes", "tfhe_amd_gsw_export_packed", "tfhe_amd_gsw_from_packed",
+    "tfhe_amd_pool_create", "tfhe_amd_pool_destroy", "tfhe_amd_pool_last_error", "tfhe_amd_pool_size", "tfhe_amd_pool_device",
+    "tfhe_amd_pool_ctx", "tfhe_amd_pool_load_keys", "tfhe_amd_pool_load_keys_torus", "tfhe_amd_pool_bootstrap_host",
+    "tfhe_amd_pool_bootstrap_woks_host", "tfhe_amd_pool_keyswitch_host", "tfhe_amd_pool_last_split",
+    "tfhe_amd_cb_pool_create", "tfhe_amd_cb_pool_destroy", "tfhe_amd_cb_pool_last_error", "tfhe_amd_cb_pool_size",
+    "tfhe_amd_cb_pool_member", "tfhe_amd_cb_pool_load_preks", "tfhe_amd_cb_pool_load_bk_fft", "tfhe_amd_cb_pool_load_bk_torus",
+    "tfhe_amd_cb_pool_load_privks_plane", "tfhe_amd_cb_pool_circuit_bootstrap_host",
 ]
 
 
@@ -153,6 +162,45 @@ def load_library(path=None):
     lib.tfhe_amd_keygen_bk_torus64.argtypes = list(lib.tfhe_amd_keygen_bk_torus32.argtypes)
     lib.tfhe_amd_keygen_ks32.argtypes = [i32p, i32p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_double,
                                          C.c_uint64, C.c_uint64]
+    lib.tfhe_amd_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    lib.tfhe_amd_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.tfhe_amd_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    lib.tfhe_amd_clock_probe.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.tfhe_amd_load_keyswitch_key_d.argtypes = [vp, vp]
+    lib.tfhe_amd_keyswitch_key_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
+    lib.tfhe_amd_keyswitch_key_export.argtypes = [vp, vp]
+    lib.tfhe_amd_gsw_packed_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
+    lib.tfhe_amd_gsw_export_packed.argtypes = [vp, vp, vp]
+    lib.tfhe_amd_gsw_from_packed.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    ip = C.POINTER(C.c_int)
+    lib.tfhe_amd_pool_create.argtypes = [C.POINTER(Params), ip, C.c_int, C.POINTER(vp)]
+    lib.tfhe_amd_pool_destroy.argtypes = [vp]
+    lib.tfhe_amd_pool_destroy.restype = None
+    lib.tfhe_amd_pool_last_error.argtypes = [vp]
+    lib.tfhe_amd_pool_last_error.restype = C.c_char_p
+    lib.tfhe_amd_pool_size.argtypes = [vp]
+    lib.tfhe_amd_pool_device.argtypes = [vp, C.c_int]
+    lib.tfhe_amd_pool_ctx.argtypes = [vp, C.c_int]
+    lib.tfhe_amd_pool_ctx.restype = vp
+    lib.tfhe_amd_pool_load_keys.argtypes = [vp, f64p, i32p]
+    lib.tfhe_amd_pool_load_keys_torus.argtypes = [vp, vp, i32p]
+    lib.tfhe_amd_pool_bootstrap_host.argtypes = [vp, i32p, C.c_int32, i32p, C.c_int]
+    lib.tfhe_amd_pool_bootstrap_woks_host.argtypes = [vp, i32p, C.c_int32, i32p, C.c_int]
+    lib.tfhe_amd_pool_keyswitch_host.argtypes = [vp, i32p, i32p, C.c_int]
+    lib.tfhe_amd_pool_last_split.argtypes = [vp, ip, C.POINTER(C.c_double)]
+    lib.tfhe_amd_cb_pool_create.argtypes = [C.POINTER(CbParams), ip, C.c_int, C.POINTER(vp)]
+    lib.tfhe_amd_cb_pool_destroy.argtypes = [vp]
+    lib.tfhe_amd_cb_pool_destroy.restype = None
+    lib.tfhe_amd_cb_pool_last_error.argtypes = [vp]
+    lib.tfhe_amd_cb_pool_last_error.restype = C.c_char_p
+    lib.tfhe_amd_cb_pool_size.argtypes = [vp]
+    lib.tfhe_amd_cb_pool_member.argtypes = [vp, C.c_int]
+    lib.tfhe_amd_cb_pool_member.restype = vp
+    lib.tfhe_amd_cb_pool_load_preks.argtypes = [vp, i32p]
+    lib.tfhe_amd_cb_pool_load_bk_fft.argtypes = [vp, f64p]
+    lib.tfhe_amd_cb_pool_load_bk_torus.argtypes = [vp, i64p]
+    lib.tfhe_amd_cb_pool_load_privks_plane.argtypes = [vp, C.c_int, i32p]
+    lib.tfhe_amd_cb_pool_circuit_bootstrap_host.argtypes = [vp, i32p, i32p, C.c_int]
     _libs[path] = lib
     return lib
 
@@ -298,6 +346,40 @@ class Engine:
     def load_keyswitch_key(self, ks):
         ks = np.ascontiguousarray(ks, dtype=np.int32)
         self._chk(self.lib.tfhe_amd_load_keyswitch_key(self.ctx, _np_ptr(ks)))
+
+    # -- keys as the bytes of their device layout (replication: one copy per device, or one broadcast)
+    def gsw_packed_bytes(self, count):
+        n = C.c_size_t()
+        self._chk(self.lib.tfhe_amd_gsw_packed_bytes(self.ctx, count, C.byref(n)))
+        return int(n.value)
+
+    def gsw_export_packed(self, g, dst_ptr):
+        """writes the TGSW samples' kernel layout to `dst_ptr` (device memory of this context's device, or host)"""
+        self._chk(self.lib.tfhe_amd_gsw_export_packed(self.ctx, g, dst_ptr))
+
+    def gsw_from_packed(self, src_ptr, count):
+        g = C.c_void_p()
+        self._chk(self.lib.tfhe_amd_gsw_from_packed(self.ctx, src_ptr, count, C.byref(g)))
+        self._gsw.append(g)
+        return g
+
+    def keyswitch_key_bytes(self):
+        n = C.c_size_t()
+        self._chk(self.lib.tfhe_amd_keyswitch_key_bytes(self.ctx, C.byref(n)))
+        return int(n.value)
+
+    def keyswitch_key_export(self, dst_ptr):
+        self._chk(self.lib.tfhe_amd_keyswitch_key_export(self.ctx, dst_ptr))
+
+    def load_keyswitch_key_d(self, src_ptr):
+        self._chk(self.lib.tfhe_amd_load_keyswitch_key_d(self.ctx, src_ptr))
+
+    def clock_probe(self, duration_us):
+        """(median, min, max) shader clock in GHz over `duration_us`, measured BESIDE the work already queued on this
+        context's stream (tfhe_amd_clock_probe)"""
+        med, lo, hi = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self.lib.tfhe_amd_clock_probe(self.ctx, int(duration_us), C.byref(med), C.byref(lo), C.byref(hi)))
+        return float(med.value), float(lo.value), float(hi.value)
 
     # -- host-array convenience wrappers around the device-pointer ABI (tests, smoke)
     def _roundtrip(self, fn, inp, out_dtype, out_shape, *extra):
@@ -569,6 +651,129 @@ class CircuitBootstrap:
         return tgsw, out
 
 
+class Pool:
+    """tfhe_amd_pool: one context, one host thread and one pinned staging buffer per member device; the caller's keys
+    uploaded once to every member; host batches cut into contiguous slices (include/tfhe_amd.h)."""
+
+    def __init__(self, devices, torus_bits=32, n=630, N=1024, l=2, Bgbit=10, ks_t=8, ks_basebit=2, ks_n_out=None, lib_path=None):
+        self.lib = load_library(lib_path)
+        self.params = Params(torus_bits, n, N, 1, l, Bgbit, ks_t, ks_basebit, (n if ks_n_out is None else ks_n_out) if ks_t else 0)
+        devs = (C.c_int * len(devices))(*devices)
+        self.pool = C.c_void_p()
+        rc = self.lib.tfhe_amd_pool_create(C.byref(self.params), devs, len(devices), C.byref(self.pool))
+        if rc != OK:
+            raise TfheAmdError(f"tfhe_amd_pool_create({list(devices)}) failed with status {rc} (2 = a device is missing; there is no CPU path)")
+        self.devices = list(devices)
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise TfheAmdError(f"status {rc}: {self.lib.tfhe_amd_pool_last_error(self.pool).decode()}")
+
+    def close(self):
+        if self.pool:
+            self.lib.tfhe_amd_pool_destroy(self.pool)
+            self.pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_keys(self, bkfft=None, ks=None):
+        a = None if bkfft is None else np.ascontiguousarray(bkfft, np.float64)
+        k = None if ks is None else np.ascontiguousarray(ks, np.int32)
+        self._chk(self.lib.tfhe_amd_pool_load_keys(self.pool, None if a is None else _np_ptr(a), None if k is None else _np_ptr(k)))
+
+    def load_keys_torus(self, bk_torus=None, ks=None):
+        a = None if bk_torus is None else np.ascontiguousarray(bk_torus, np.int32 if self.params.torus_bits == 32 else np.int64)
+        k = None if ks is None else np.ascontiguousarray(ks, np.int32)
+        self._chk(self.lib.tfhe_amd_pool_load_keys_torus(self.pool, None if a is None else _np_ptr(a), None if k is None else _np_ptr(k)))
+
+    def _rows(self, fn, x, in_cols, out_cols, *lead):
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, in_cols)
+        out = np.empty((x.shape[0], out_cols), np.int32)
+        self._chk(fn(self.pool, _np_ptr(out), *lead, _np_ptr(x), x.shape[0]))
+        return out
+
+    def bootstrap(self, mu, x):
+        n = self.params.n
+        return self._rows(self.lib.tfhe_amd_pool_bootstrap_host, x, n + 1, n + 1, int(mu))
+
+    def bootstrap_woks(self, mu, x):
+        return self._rows(self.lib.tfhe_amd_pool_bootstrap_woks_host, x, self.params.n + 1, self.params.N + 1, int(mu))
+
+    def keyswitch(self, x):
+        return self._rows(self.lib.tfhe_amd_pool_keyswitch_host, x, self.params.N + 1, self.params.ks_n_out + 1)
+
+    def last_split(self):
+        m = len(self.devices)
+        cnt, sec = (C.c_int * m)(), (C.c_double * m)()
+        self._chk(self.lib.tfhe_amd_pool_last_split(self.pool, cnt, sec))
+        return list(cnt), list(sec)
+
+
+class CircuitBootstrapPool:
+    """tfhe_amd_cb_pool: the circuit bootstrap sharded over several devices the same way"""
+
+    def __init__(self, devices, n0=500, N1=1024, N2=2048, l1=2, Bgbit1=8, l2=4, Bgbit2=9, t10=6, bb10=2, t21=10, bb21=3, lib_path=None):
+        self.lib = load_library(lib_path)
+        self.p = CbParams(n0, N1, N2, l1, Bgbit1, l2, Bgbit2, t10, bb10, t21, bb21)
+        devs = (C.c_int * len(devices))(*devices)
+        self.pool = C.c_void_p()
+        rc = self.lib.tfhe_amd_cb_pool_create(C.byref(self.p), devs, len(devices), C.byref(self.pool))
+        if rc != OK:
+            raise TfheAmdError(f"tfhe_amd_cb_pool_create({list(devices)}) failed with status {rc}")
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise TfheAmdError(f"status {rc}: {self.lib.tfhe_amd_cb_pool_last_error(self.pool).decode()}")
+
+    def close(self):
+        if self.pool:
+            self.lib.tfhe_amd_cb_pool_destroy(self.pool)
+            self.pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_preks(self, preks):
+        self._chk(self.lib.tfhe_amd_cb_pool_load_preks(self.pool, _np_ptr(np.ascontiguousarray(preks, np.int32))))
+
+    def load_bk_fft(self, bk):
+        self._chk(self.lib.tfhe_amd_cb_pool_load_bk_fft(self.pool, _np_ptr(np.ascontiguousarray(bk, np.float64))))
+
+    def load_privks(self, privks):
+        a = np.ascontiguousarray(privks, np.int32).reshape(2, -1)
+        for u in range(2):
+            self._chk(self.lib.tfhe_amd_cb_pool_load_privks_plane(self.pool, u, _np_ptr(a[u])))
+
+    def circuit_bootstrap(self, x):
+        x = np.ascontiguousarray(x, np.int32).reshape(-1, self.p.N1 + 1)
+        out = np.empty((x.shape[0], 2, self.p.l1, 2, self.p.N1), np.int32)
+        self._chk(self.lib.tfhe_amd_cb_pool_circuit_bootstrap_host(self.pool, _np_ptr(out), _np_ptr(x), x.shape[0]))
+        return out
+
+
+def device_count(lib_path=None):
+    """HIP devices the engine library sees in this process (tfhe_amd_device_count)"""
+    lib = load_library(lib_path)
+    n = C.c_int()
+    if lib.tfhe_amd_device_count(C.byref(n)) != OK:
+        return 0
+    return int(n.value)
+
+
+def device_pci_bus_id(device=0, lib_path=None):
+    """'domain:bus:device.function' of the GPU behind an ordinal, or None"""
+    lib = load_library(lib_path)
+    buf = C.create_string_buffer(32)
+    return buf.value.decode() if lib.tfhe_amd_device_pci_bus_id(device, buf, 32) == OK else None
+
+
 # ---- harness wrappers (host side of the ABI; usable without a GPU) --------------------
 def build_tables(N, lib_path=None):
     """the reference-layout twiddle tables (fft, ifft) from the host-only builder: no context, no device"""
@@ -631,5 +836,4 @@ def device_info(device=0, lib_path=None):
     """one-line description of the GPU (tfhe_amd_device_info), or None when there is none"""
     lib = load_library(lib_path)
     buf = C.create_string_buffer(512)
-    lib.tfhe_amd_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     return buf.value.decode() if lib.tfhe_amd_device_info(device, buf, 512) == OK else None

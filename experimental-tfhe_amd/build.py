@@ -16,7 +16,7 @@ OUT = os.path.join(HERE, "libtfhe_amd.so")
 OUT_DROPIN = os.path.join(HERE, "libtfhe_amd_dropin.so")  # global-scope reference entry points (csrc/dropin_library.cpp)
 OUT_SPQLIOS = os.path.join(HERE, "libtfhe_amd_spqlios.so")  # the reference's FFT plugin symbols (csrc/spqlios_seam.cpp)
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-SOURCES = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp"), os.path.join(CSRC, "hp_twiddles.cpp")]
+SOURCES = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp"), os.path.join(CSRC, "hp_twiddles.cpp"), os.path.join(CSRC, "pool.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "devport.h"),
                   os.path.join(os.path.dirname(HERE), "include", "tfhe_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",

@@ -126,6 +126,10 @@ __device__ __forceinline__ V tfhe_nontemporal_load(const V *p) { return __builti
 template <typename V>
 __device__ __forceinline__ void tfhe_nontemporal_store(V v, V *p) { __builtin_nontemporal_store(v, p); }
 #define TFHE_TRAP() __builtin_trap()
+// counters of the clock probe: shader cycles (s_memtime), the constant 100 MHz reference (s_memrealtime); a short sleep
+#define TFHE_SHADER_CYCLES() __builtin_amdgcn_s_memtime()
+#define TFHE_REF_TICKS() __builtin_amdgcn_s_memrealtime()
+#define TFHE_SLEEP() __builtin_amdgcn_s_sleep(64)
 // the workgroup's dynamic LDS block
 #define TFHE_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 // D = A(32x32 int8) * B(32x32 int8) + C(32x32 int32) on the matrix cores, one wave.  Lane l holds

@@ -1,0 +1,420 @@
+// pool.cpp -- several GPUs in one process: tfhe_amd_pool / tfhe_amd_cb_pool of include/tfhe_amd.h.
+//
+// Host C++ written entirely on the C ABI of this library (contexts, pinned host buffers, copies, the batch entry
+// points): no HIP call of its own.  The mapping is the reference's independent-item loop
+// (parallel/src/test_parallel_multiplications.cpp:62, `#pragma omp parallel for` over samples that never interact):
+// one member per device, each with its own context (= its own stream), its own HOST THREAD -- HIP's current device is
+// per thread, and a thread that only ever serves one device never switches -- and its own pinned staging buffers;
+// the caller's keys are uploaded once to every member (key ownership as CB/lwe_functions.cpp:287-316: the caller keeps
+// the host key); a call cuts its batch into contiguous slices (experimental-tfhe_amd/shard.py's rule), every member runs
+// copy in -> launch -> copy out on its slice, and nothing is exchanged between devices.
+#include <stdint.h>
+#include <string.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tfhe_amd.h"
+
+namespace {
+
+// rows a member stages per round trip: bounds the pinned buffers whatever the call's size (config 5 hands over 2.6 GB)
+constexpr size_t STAGE_BYTES = (size_t)64 << 20;
+
+// one persistent host thread; run() hands it a job and returns at once, wait() collects the status
+class Worker {
+   public:
+    Worker() : th_([this] { loop(); }) {}
+    ~Worker() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void run(std::function<int()> job) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = std::move(job);
+            busy_ = true;
+        }
+        cv_.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !busy_; });
+        return rc_;
+    }
+
+   private:
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [this] { return busy_ || quit_; });
+            if (quit_) return;
+            std::function<int()> job = std::move(job_);
+            lk.unlock();
+            const int rc = job();
+            lk.lock();
+            rc_ = rc;
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<int()> job_;
+    bool busy_ = false, quit_ = false;
+    int rc_ = 0;
+    std::thread th_;  // last: started when everything above exists
+};
+
+// pinned host + device staging of one member, grown on demand through the member's own context
+struct Staging {
+    void *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+    size_t in_bytes = 0, out_bytes = 0;
+    int ensure(tfhe_amd_ctx *c, size_t in_need, size_t out_need) {
+        if (in_bytes < in_need) {
+            if (h_in) tfhe_amd_host_free(c, h_in);
+            if (d_in) tfhe_amd_free(c, d_in);
+            h_in = d_in = nullptr;
+            in_bytes = 0;
+            if (int rc = tfhe_amd_host_alloc(c, &h_in, in_need)) return rc;
+            if (int rc = tfhe_amd_malloc(c, &d_in, in_need)) return rc;
+            in_bytes = in_need;
+        }
+        if (out_bytes < out_need) {
+            if (h_out) tfhe_amd_host_free(c, h_out);
+            if (d_out) tfhe_amd_free(c, d_out);
+            h_out = d_out = nullptr;
+            out_bytes = 0;
+            if (int rc = tfhe_amd_host_alloc(c, &h_out, out_need)) return rc;
+            if (int rc = tfhe_amd_malloc(c, &d_out, out_need)) return rc;
+            out_bytes = out_need;
+        }
+        return TFHE_AMD_OK;
+    }
+    void release(tfhe_amd_ctx *c) {
+        if (h_in) tfhe_amd_host_free(c, h_in);
+        if (h_out) tfhe_amd_host_free(c, h_out);
+        if (d_in) tfhe_amd_free(c, d_in);
+        if (d_out) tfhe_amd_free(c, d_out);
+        h_in = h_out = d_in = d_out = nullptr;
+        in_bytes = out_bytes = 0;
+    }
+};
+
+// [lo, hi) of `total` rows owned by member r of m: contiguous, sizes differ by at most one
+void slice_of(int total, int r, int m, int *lo, int *hi) {
+    const int base = total / m, rem = total % m;
+    *lo = r * base + (r < rem ? r : rem);
+    *hi = *lo + base + (r < rem ? 1 : 0);
+}
+
+// copy in -> launch -> copy out of rows [lo, hi), in rounds of at most STAGE_BYTES per direction
+template <class Launch>
+int staged_rows(tfhe_amd_ctx *c, Staging &st, char *out, size_t out_row, const char *in, size_t in_row, int lo, int hi, Launch launch) {
+    const size_t big = in_row > out_row ? in_row : out_row;
+    int per_round = (int)(STAGE_BYTES / big);
+    if (per_round < 1) per_round = 1;
+    if (per_round > hi - lo) per_round = hi - lo;
+    if (int rc = st.ensure(c, (size_t)per_round * in_row, (size_t)per_round * out_row)) return rc;
+    for (int at = lo; at < hi; at += per_round) {
+        const int rows = hi - at < per_round ? hi - at : per_round;
+        memcpy(st.h_in, in + (size_t)at * in_row, (size_t)rows * in_row);  // pageable -> pinned: the copy below then runs at the link's rate
+        if (int rc = tfhe_amd_memcpy_h2d(c, st.d_in, st.h_in, (size_t)rows * in_row)) return rc;
+        if (int rc = launch(st.d_out, st.d_in, rows)) return rc;
+        if (int rc = tfhe_amd_memcpy_d2h(c, st.h_out, st.d_out, (size_t)rows * out_row)) return rc;  // waits for the launch
+        memcpy(out + (size_t)at * out_row, st.h_out, (size_t)rows * out_row);
+    }
+    return TFHE_AMD_OK;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+// ------------------------------------------------------------------ gate-bootstrap pool
+struct tfhe_amd_pool {
+    tfhe_amd_params p;
+    struct Member {
+        int device = 0;
+        tfhe_amd_ctx *ctx = nullptr;
+        tfhe_amd_gsw *bk = nullptr;
+        Staging st;
+        Worker *worker = nullptr;
+        int last_count = 0;
+        double last_seconds = 0;
+        std::string err;
+    };
+    std::vector<Member> m;
+    std::mutex call_mu;  // one sharded call at a time
+    std::string err;
+};
+
+namespace {
+// every member runs job(member index) on its own thread; the first failure is the call's status
+template <class Pool, class Job>
+int on_every_member(Pool *pool, Job job) {
+    for (size_t i = 0; i < pool->m.size(); i++) pool->m[i].worker->run([pool, i, job] { return job((int)i); });
+    int rc = TFHE_AMD_OK;
+    for (size_t i = 0; i < pool->m.size(); i++) {
+        const int r = pool->m[i].worker->wait();
+        if (r && !rc) {
+            rc = r;
+            pool->err = "member " + std::to_string(i) + " (device " + std::to_string(pool->m[i].device) + "): " + pool->m[i].err;
+        }
+    }
+    return rc;
+}
+int member_status(tfhe_amd_pool::Member &mb, int rc) {
+    if (rc) mb.err = mb.ctx ? tfhe_amd_last_error(mb.ctx) : "no context";
+    return rc;
+}
+
+template <class Launch>
+int pool_rows(tfhe_amd_pool *pool, int32_t *out, size_t out_ints, const int32_t *x, size_t in_ints, int count, Launch launch) {
+    if (!pool || !out || !x || count < 0) return TFHE_AMD_ERR_PARAM;
+    std::lock_guard<std::mutex> lk(pool->call_mu);
+    const int members = (int)pool->m.size();
+    return on_every_member(pool, [=](int i) {
+        tfhe_amd_pool::Member &mb = pool->m[i];
+        int lo, hi;
+        slice_of(count, i, members, &lo, &hi);
+        mb.last_count = hi - lo;
+        mb.last_seconds = 0;
+        if (hi == lo) return (int)TFHE_AMD_OK;
+        const double t0 = now_s();
+        const int rc = staged_rows(mb.ctx, mb.st, (char *)out, out_ints * 4, (const char *)x, in_ints * 4, lo, hi,
+                                   [&](void *o, const void *in, int rows) { return launch(mb.ctx, (int32_t *)o, (const int32_t *)in, rows); });
+        mb.last_seconds = now_s() - t0;
+        return member_status(mb, rc);
+    });
+}
+}  // namespace
+
+extern "C" {
+
+int tfhe_amd_pool_create(const tfhe_amd_params *params, const int *devices, int n_devices, tfhe_amd_pool **out) {
+    if (!params || !devices || !out || n_devices < 1 || n_devices > 64) return TFHE_AMD_ERR_PARAM;
+    *out = nullptr;
+    tfhe_amd_pool *pool = new tfhe_amd_pool();
+    pool->p = *params;
+    pool->m.resize((size_t)n_devices);
+    for (int i = 0; i < n_devices; i++) {
+        pool->m[i].device = devices[i];
+        pool->m[i].worker = new Worker();
+    }
+    // every member creates its context on its own thread: that thread's current device is the member's from then on
+    const int rc = on_every_member(pool, [pool](int i) {
+        tfhe_amd_pool::Member &mb = pool->m[i];
+        const int r = tfhe_amd_ctx_create(&pool->p, mb.device, &mb.ctx);
+        if (r) mb.err = "tfhe_amd_ctx_create failed";
+        return r;
+    });
+    if (rc) {
+        tfhe_amd_pool_destroy(pool);
+        return rc;
+    }
+    *out = pool;
+    return TFHE_AMD_OK;
+}
+
+void tfhe_amd_pool_destroy(tfhe_amd_pool *pool) {
+    if (!pool) return;
+    (void)on_every_member(pool, [pool](int i) {  // device objects are released on the thread (= device) that made them
+        tfhe_amd_pool::Member &mb = pool->m[i];
+        if (mb.ctx) {
+            mb.st.release(mb.ctx);
+            if (mb.bk) tfhe_amd_gsw_free(mb.bk);
+            tfhe_amd_ctx_destroy(mb.ctx);
+        }
+        mb.ctx = nullptr;
+        mb.bk = nullptr;
+        return (int)TFHE_AMD_OK;
+    });
+    for (auto &mb : pool->m) delete mb.worker;
+    delete pool;
+}
+
+const char *tfhe_amd_pool_last_error(const tfhe_amd_pool *pool) { return pool ? pool->err.c_str() : "null pool"; }
+int tfhe_amd_pool_size(const tfhe_amd_pool *pool) { return pool ? (int)pool->m.size() : 0; }
+int tfhe_amd_pool_device(const tfhe_amd_pool *pool, int member) {
+    return pool && member >= 0 && member < (int)pool->m.size() ? pool->m[member].device : -1;
+}
+tfhe_amd_ctx *tfhe_amd_pool_ctx(tfhe_amd_pool *pool, int member) {
+    return pool && member >= 0 && member < (int)pool->m.size() ? pool->m[member].ctx : nullptr;
+}
+
+static int pool_load(tfhe_amd_pool *pool, const void *bk, bool bk_is_fft, const int32_t *ks) {
+    if (!pool || (!bk && !ks)) return TFHE_AMD_ERR_PARAM;
+    std::lock_guard<std::mutex> lk(pool->call_mu);
+    return on_every_member(pool, [=](int i) {
+        tfhe_amd_pool::Member &mb = pool->m[i];
+        if (bk) {
+            tfhe_amd_gsw *g = nullptr;
+            int rc = bk_is_fft ? tfhe_amd_gsw_from_fft(mb.ctx, (const double *)bk, pool->p.n, &g)
+                               : tfhe_amd_gsw_from_torus(mb.ctx, bk, pool->p.n, &g);
+            if (!rc) rc = tfhe_amd_set_bootstrap_key(mb.ctx, g);
+            if (rc) {
+                if (g) tfhe_amd_gsw_free(g);
+                return member_status(mb, rc);
+            }
+            if (mb.bk) tfhe_amd_gsw_free(mb.bk);  // the previous key, after the new one is in place
+            mb.bk = g;
+        }
+        if (ks)
+            if (int rc = tfhe_amd_load_keyswitch_key(mb.ctx, ks)) return member_status(mb, rc);
+        return (int)TFHE_AMD_OK;
+    });
+}
+int tfhe_amd_pool_load_keys(tfhe_amd_pool *pool, const double *bkfft, const int32_t *ks) { return pool_load(pool, bkfft, true, ks); }
+int tfhe_amd_pool_load_keys_torus(tfhe_amd_pool *pool, const void *bk_torus, const int32_t *ks) {
+    return pool_load(pool, bk_torus, false, ks);
+}
+
+int tfhe_amd_pool_bootstrap_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count) {
+    if (!pool) return TFHE_AMD_ERR_PARAM;
+    const size_t row = (size_t)pool->p.n + 1;
+    return pool_rows(pool, out, row, x, row, count,
+                     [mu](tfhe_amd_ctx *c, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_bootstrap(c, o, mu, in, rows); });
+}
+int tfhe_amd_pool_bootstrap_woks_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count) {
+    if (!pool) return TFHE_AMD_ERR_PARAM;
+    return pool_rows(pool, out, (size_t)pool->p.N + 1, x, (size_t)pool->p.n + 1, count,
+                     [mu](tfhe_amd_ctx *c, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_bootstrap_woks(c, o, mu, in, rows); });
+}
+int tfhe_amd_pool_keyswitch_host(tfhe_amd_pool *pool, int32_t *out, const int32_t *x, int count) {
+    if (!pool) return TFHE_AMD_ERR_PARAM;
+    return pool_rows(pool, out, (size_t)pool->p.ks_n_out + 1, x, (size_t)pool->p.N + 1, count,
+                     [](tfhe_amd_ctx *c, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_keyswitch(c, o, in, rows); });
+}
+int tfhe_amd_pool_last_split(const tfhe_amd_pool *pool, int *counts, double *seconds) {
+    if (!pool) return TFHE_AMD_ERR_PARAM;
+    for (size_t i = 0; i < pool->m.size(); i++) {
+        if (counts) counts[i] = pool->m[i].last_count;
+        if (seconds) seconds[i] = pool->m[i].last_seconds;
+    }
+    return TFHE_AMD_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ circuit-bootstrap pool
+struct tfhe_amd_cb_pool {
+    tfhe_amd_cb_params p;
+    struct Member {
+        int device = 0;
+        tfhe_amd_cb *cb = nullptr;
+        tfhe_amd_ctx *ctx = nullptr;  // the member's level-2 context (memory helpers)
+        Staging st;
+        Worker *worker = nullptr;
+        std::string err;
+    };
+    std::vector<Member> m;
+    std::mutex call_mu;
+    std::string err;
+};
+
+namespace {
+int cb_member_status(tfhe_amd_cb_pool::Member &mb, int rc) {
+    if (rc) mb.err = mb.cb ? tfhe_amd_cb_last_error(mb.cb) : "no handle";
+    return rc;
+}
+template <class Load>
+int cb_pool_load(tfhe_amd_cb_pool *pool, const void *key, Load load) {
+    if (!pool || !key) return TFHE_AMD_ERR_PARAM;
+    std::lock_guard<std::mutex> lk(pool->call_mu);
+    return on_every_member(pool, [=](int i) { return cb_member_status(pool->m[i], load(pool->m[i].cb)); });
+}
+}  // namespace
+
+extern "C" {
+
+int tfhe_amd_cb_pool_create(const tfhe_amd_cb_params *params, const int *devices, int n_devices, tfhe_amd_cb_pool **out) {
+    if (!params || !devices || !out || n_devices < 1 || n_devices > 64) return TFHE_AMD_ERR_PARAM;
+    *out = nullptr;
+    tfhe_amd_cb_pool *pool = new tfhe_amd_cb_pool();
+    pool->p = *params;
+    pool->m.resize((size_t)n_devices);
+    for (int i = 0; i < n_devices; i++) {
+        pool->m[i].device = devices[i];
+        pool->m[i].worker = new Worker();
+    }
+    const int rc = on_every_member(pool, [pool](int i) {
+        tfhe_amd_cb_pool::Member &mb = pool->m[i];
+        const int r = tfhe_amd_cb_create(&pool->p, mb.device, &mb.cb);
+        if (r) mb.err = "tfhe_amd_cb_create failed";
+        else mb.ctx = tfhe_amd_cb_ctx_lvl2(mb.cb);
+        return r;
+    });
+    if (rc) {
+        tfhe_amd_cb_pool_destroy(pool);
+        return rc;
+    }
+    *out = pool;
+    return TFHE_AMD_OK;
+}
+
+void tfhe_amd_cb_pool_destroy(tfhe_amd_cb_pool *pool) {
+    if (!pool) return;
+    (void)on_every_member(pool, [pool](int i) {
+        tfhe_amd_cb_pool::Member &mb = pool->m[i];
+        if (mb.cb) {
+            mb.st.release(mb.ctx);
+            tfhe_amd_cb_destroy(mb.cb);
+        }
+        mb.cb = nullptr;
+        mb.ctx = nullptr;
+        return (int)TFHE_AMD_OK;
+    });
+    for (auto &mb : pool->m) delete mb.worker;
+    delete pool;
+}
+
+const char *tfhe_amd_cb_pool_last_error(const tfhe_amd_cb_pool *pool) { return pool ? pool->err.c_str() : "null pool"; }
+int tfhe_amd_cb_pool_size(const tfhe_amd_cb_pool *pool) { return pool ? (int)pool->m.size() : 0; }
+tfhe_amd_cb *tfhe_amd_cb_pool_member(tfhe_amd_cb_pool *pool, int member) {
+    return pool && member >= 0 && member < (int)pool->m.size() ? pool->m[member].cb : nullptr;
+}
+int tfhe_amd_cb_pool_load_preks(tfhe_amd_cb_pool *pool, const int32_t *preks) {
+    return cb_pool_load(pool, preks, [preks](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_preks(cb, preks); });
+}
+int tfhe_amd_cb_pool_load_bk_fft(tfhe_amd_cb_pool *pool, const double *bkfft) {
+    return cb_pool_load(pool, bkfft, [bkfft](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_bk_fft(cb, bkfft); });
+}
+int tfhe_amd_cb_pool_load_bk_torus(tfhe_amd_cb_pool *pool, const int64_t *bk) {
+    return cb_pool_load(pool, bk, [bk](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_bk_torus(cb, bk); });
+}
+int tfhe_amd_cb_pool_load_privks_plane(tfhe_amd_cb_pool *pool, int u_plane, const int32_t *plane) {
+    return cb_pool_load(pool, plane, [u_plane, plane](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_privks_plane(cb, u_plane, plane); });
+}
+
+int tfhe_amd_cb_pool_circuit_bootstrap_host(tfhe_amd_cb_pool *pool, int32_t *out, const int32_t *x, int count) {
+    if (!pool || !out || !x || count < 0) return TFHE_AMD_ERR_PARAM;
+    std::lock_guard<std::mutex> lk(pool->call_mu);
+    const int members = (int)pool->m.size();
+    const size_t in_row = ((size_t)pool->p.N1 + 1) * 4, out_row = (size_t)2 * pool->p.l1 * 2 * pool->p.N1 * 4;
+    return on_every_member(pool, [=](int i) {
+        tfhe_amd_cb_pool::Member &mb = pool->m[i];
+        int lo, hi;
+        slice_of(count, i, members, &lo, &hi);
+        if (hi == lo) return (int)TFHE_AMD_OK;
+        const int rc = staged_rows(mb.ctx, mb.st, (char *)out, out_row, (const char *)x, in_row, lo, hi, [&](void *o, const void *in, int rows) {
+            return tfhe_amd_circuit_bootstrap(mb.cb, (int32_t *)o, (const int32_t *)in, rows);
+        });
+        if (rc) {  // the pipeline's message, or the level-2 context's when a copy failed
+            const char *e = tfhe_amd_cb_last_error(mb.cb);
+            mb.err = (e && *e) ? e : tfhe_amd_last_error(mb.ctx);
+        }
+        return rc;
+    });
+}
+
+}  // extern "C"

@@ -44,12 +44,14 @@ struct tfhe_amd_ctx {
     size_t ws_acc_bytes;
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
+    hipStream_t probe_stream;  // tfhe_amd_clock_probe: a second stream, so that the probe runs BESIDE the work queued on `stream`
+    void *probe_d;             // its stamps
     int br_split_max;      // TFHE_AMD_OPT_BR_SPLIT: largest batch served by k_blind_rotate_split (< 0: BR_SPLIT_AUTO_MAX, 0: never)
     int ks_force_gather;   // TFHE_AMD_OPT_KS_GATHER: != 0 per-sample gather kernel even where the matrix-core kernel applies
     // TFHE_AMD_OPT_STREAMED_GRAPH: the n+3 launches of tfhe_amd_bootstrap_streamed captured once into a
     // hipGraph and replayed while the call's arguments stay the same
     bool streamed_graph;
-    unsigned streamed_warm;  // bit 3 * ks_gather + blind-rotation kernel class: that schedule variant has run uncaptured once
+    unsigned streamed_warm;  // bit 9 * ks_gather + 3 * class of the 0-step launches + class of the 1-step launches: that schedule variant has run uncaptured once
     struct {
         void *exec;  // hipGraphExec_t
         const void *x, *out;
@@ -517,11 +519,26 @@ int tfhe_amd_device_info(int device, char *buf, size_t len) {
     int rt = 0, drv = 0;
     (void)hipRuntimeGetVersion(&rt);
     (void)hipDriverGetVersion(&drv);
-    snprintf(buf, len, "%s (%s), %d CUs, %d MHz, %.1f GiB, LDS/workgroup %zu KiB (opt-in %zu KiB), L2 %d MiB, wave %d, "
+    char pci[32] = "?";
+    (void)hipDeviceGetPCIBusId(pci, (int)sizeof(pci), device);
+    snprintf(buf, len, "%s (%s), PCI %s, %d CUs, %d MHz, %.1f GiB, LDS/workgroup %zu KiB (opt-in %zu KiB), L2 %d MiB, wave %d, "
                        "HIP runtime %d driver %d",
-             p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000, (double)p.totalGlobalMem / (1 << 30),
+             p.name, p.gcnArchName, pci, p.multiProcessorCount, p.clockRate / 1000, (double)p.totalGlobalMem / (1 << 30),
              p.sharedMemPerBlock >> 10, (size_t)p.sharedMemPerBlockOptin >> 10, p.l2CacheSize >> 20, p.warpSize, rt, drv);
     return TFHE_AMD_OK;
+}
+
+int tfhe_amd_device_count(int *count) {
+    if (!count) return TFHE_AMD_ERR_PARAM;
+    *count = 0;
+    return hipGetDeviceCount(count) == hipSuccess ? TFHE_AMD_OK : TFHE_AMD_ERR_DEVICE;
+}
+
+// "domain:bus:device.function" of the physical GPU behind an ordinal: the ordinal is per process (a launcher may show
+// every rank one device, all of them "device 0"), the bus id is what tells two GPUs apart
+int tfhe_amd_device_pci_bus_id(int device, char *buf, size_t len) {
+    if (!buf || len < 13) return TFHE_AMD_ERR_PARAM;
+    return hipDeviceGetPCIBusId(buf, (int)len, device) == hipSuccess ? TFHE_AMD_OK : TFHE_AMD_ERR_DEVICE;
 }
 
 const char *tfhe_amd_version(void) { return "experimental-tfhe_amd 0.1 (gfx950)"; }
@@ -557,6 +574,8 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->ws_lwe = c->ws_acc = nullptr;
     c->vp_rot_d = nullptr;
     c->hp_tw_d = nullptr;
+    c->probe_stream = nullptr;
+    c->probe_d = nullptr;
     c->ws_lwe_bytes = c->ws_acc_bytes = 0;
     if (hipSetDevice(device) != hipSuccess) {
         delete c;
@@ -609,6 +628,8 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     if (c->ws_acc) (void)hipFree(c->ws_acc);
     if (c->vp_rot_d) (void)hipFree(c->vp_rot_d);
     if (c->hp_tw_d) (void)hipFree(c->hp_tw_d);
+    if (c->probe_d) (void)hipFree(c->probe_d);
+    if (c->probe_stream) (void)hipStreamDestroy(c->probe_stream);
     drop_streamed_graph(c);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -618,6 +639,8 @@ const char *tfhe_amd_last_error(const tfhe_amd_ctx *c) { return c ? c->err.c_str
 
 int tfhe_amd_set_stream(tfhe_amd_ctx *c, void *s) {
     if (!c) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    drop_streamed_graph(c);  // a captured schedule replays on the stream it was captured on
     if (s) {
         if (c->own_stream) {
             HIPCHECK(c, hipStreamSynchronize(c->stream));
@@ -673,12 +696,14 @@ int tfhe_amd_event_record(tfhe_amd_ctx *c, void *event) {
 }
 int tfhe_amd_event_elapsed_ms(tfhe_amd_ctx *c, void *start, void *stop, float *ms) {
     if (!c || !start || !stop || !ms) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     HIPCHECK(c, hipEventSynchronize((hipEvent_t)stop));
     HIPCHECK(c, hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return TFHE_AMD_OK;
 }
 int tfhe_amd_event_destroy(tfhe_amd_ctx *c, void *event) {
     if (!c) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
     if (event) HIPCHECK(c, hipEventDestroy((hipEvent_t)event));
     return TFHE_AMD_OK;
 }
@@ -882,6 +907,99 @@ int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *c, const int32_t *ks) {
     return TFHE_AMD_OK;
 }
 
+// the key-switch key from DEVICE memory (or any pointer hipMemcpyDefault resolves): what a rank does with the bytes a
+// broadcast delivered.  Same layout as tfhe_amd_load_keyswitch_key; the matrix-core layout is rebuilt locally.
+int tfhe_amd_load_keyswitch_key_d(tfhe_amd_ctx *c, const int32_t *ks_any) {
+    if (!c || !ks_any) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    REQUIRE(c, c->p.ks_t > 0, "context has no key-switch parameters");
+    drop_streamed_graph(c);
+    const size_t bytes = (size_t)c->p.N * c->p.ks_t * ((size_t)1 << c->p.ks_basebit) * (c->p.ks_n_out + 1) * 4;
+    if (!c->ks_d) HIPCHECK(c, hipMalloc((void **)&c->ks_d, bytes));
+    HIPCHECK(c, hipMemcpyAsync(c->ks_d, ks_any, bytes, hipMemcpyDefault, c->stream));
+    if (ks_mfma_supported(c->p.ks_t, c->p.ks_basebit)) {
+        if (!c->ksm_d) HIPCHECK(c, hipMalloc((void **)&c->ksm_d, ks_mfma_bytes(c->p.N, c->p.ks_t, c->p.ks_basebit, c->p.ks_n_out + 1)));
+        if (int rc = ks_mfma_pack(c->stream, c->ksm_d, c->ks_d, c->p.N, c->p.ks_t, c->p.ks_basebit, c->p.ks_n_out + 1))
+            return fail(c, rc, "k_ks_mfma_pack launch");
+    }
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_keyswitch_key_bytes(const tfhe_amd_ctx *c, size_t *bytes) {
+    if (!c || !bytes) return TFHE_AMD_ERR_PARAM;
+    *bytes = c->p.ks_t > 0 ? (size_t)c->p.N * c->p.ks_t * ((size_t)1 << c->p.ks_basebit) * (c->p.ks_n_out + 1) * 4 : 0;
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_keyswitch_key_export(tfhe_amd_ctx *c, void *dst_any) {
+    if (!c || !dst_any) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    if (!c->ks_d) return fail(c, TFHE_AMD_ERR_STATE, "no key-switch key");
+    size_t bytes = 0;
+    (void)tfhe_amd_keyswitch_key_bytes(c, &bytes);
+    HIPCHECK(c, hipMemcpyAsync(dst_any, c->ks_d, bytes, hipMemcpyDefault, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return TFHE_AMD_OK;
+}
+
+// TGSW samples in the KERNEL layout, as bytes: what one device hands to another (or to a broadcast) so that the
+// receiver neither regenerates nor re-converts the key.  [count][2l][2][N/128][64] double2, scaled by 2/N.
+int tfhe_amd_gsw_packed_bytes(const tfhe_amd_ctx *c, int count, size_t *bytes) {
+    if (!c || !bytes || count < 0) return TFHE_AMD_ERR_PARAM;
+    *bytes = (size_t)count * 2 * c->p.l * 2 * (c->p.N / 2) * sizeof(double2);
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_gsw_export_packed(tfhe_amd_ctx *c, const tfhe_amd_gsw *g, void *dst_any) {
+    if (!c || !g || !dst_any) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    REQUIRE(c, g->ctx == c, "TGSW handle belongs to another context");
+    HIPCHECK(c, hipMemcpyAsync(dst_any, g->data_d, g->sample_complex * g->count * sizeof(double2), hipMemcpyDefault, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_gsw_from_packed(tfhe_amd_ctx *c, const void *src_any, int count, tfhe_amd_gsw **out) {
+    if (!c || !src_any || !out || count < 1) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    tfhe_amd_gsw *g = nullptr;
+    if (int rc = gsw_alloc(c, count, &g)) return rc;
+    if (hipMemcpyAsync(g->data_d, src_any, g->sample_complex * count * sizeof(double2), hipMemcpyDefault, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        tfhe_amd_gsw_free(g);
+        return fail(c, TFHE_AMD_ERR_DEVICE, "copy of the packed TGSW samples");
+    }
+    *out = g;
+    return TFHE_AMD_OK;
+}
+
+// ---- diagnostics: the shader clock the chip holds WHILE the context's queued work runs
+// A few one-wave workgroups on a second stream stamp s_memtime (shader cycles) and s_memrealtime (100 MHz) around a
+// sleep loop of `duration_us` (MI355X_MICROARCH.md, DVFS give-back item 6: clock = d memtime / d memrealtime x 100 MHz).
+// They need a wave slot and no LDS, so they run beside kernels that fill the CUs' LDS.  Call right after queueing work
+// on the context's stream; blocks for about duration_us.
+int tfhe_amd_clock_probe(tfhe_amd_ctx *c, int duration_us, double *ghz_median, double *ghz_min, double *ghz_max) {
+    if (!c || duration_us < 1 || !ghz_median) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    constexpr int PROBES = 32;
+    if (!c->probe_stream) HIPCHECK(c, hipStreamCreateWithFlags(&c->probe_stream, hipStreamNonBlocking));
+    if (!c->probe_d) HIPCHECK(c, hipMalloc(&c->probe_d, PROBES * sizeof(ClockStamp)));
+    TFHE_LAUNCH_FLAT(k_clock_probe, dim3(PROBES), dim3(64), c->probe_stream, (ClockStamp *)c->probe_d,
+                     (unsigned long long)duration_us * 100ull);
+    HIPCHECK(c, hipGetLastError());
+    ClockStamp h[PROBES];
+    HIPCHECK(c, hipMemcpyAsync(h, c->probe_d, sizeof(h), hipMemcpyDeviceToHost, c->probe_stream));
+    HIPCHECK(c, hipStreamSynchronize(c->probe_stream));
+    double g[PROBES];
+    int m = 0;
+    for (int i = 0; i < PROBES; i++)
+        if (h[i].r1 > h[i].r0) g[m++] = (double)(h[i].c1 - h[i].c0) / (double)(h[i].r1 - h[i].r0) * 0.1;
+    if (m == 0) return fail(c, TFHE_AMD_ERR_DEVICE, "clock probe: no stamps");
+    for (int i = 1; i < m; i++)  // insertion sort: 32 values
+        for (int j = i; j > 0 && g[j] < g[j - 1]; j--) std::swap(g[j], g[j - 1]);
+    *ghz_median = g[m / 2];
+    if (ghz_min) *ghz_min = g[0];
+    if (ghz_max) *ghz_max = g[m - 1];
+    return TFHE_AMD_OK;
+}
+
 // ---- L1
 int tfhe_amd_ifft_int32(tfhe_amd_ctx *c, double *out_d, const int32_t *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
@@ -911,11 +1029,18 @@ int tfhe_amd_fft_torus64(tfhe_amd_ctx *c, int64_t *out_d, const double *in_d, in
     if (batch == 0) return TFHE_AMD_OK;
     return c->logn == 10 ? launch_fft_t<int64_t, 10>(c, out_d, in_d, batch) : launch_fft_t<int64_t, 11>(c, out_d, in_d, batch);
 }
-// the bare core transforms of spqlios-fft.h:52-53 (`ifft`, `fft`): N doubles -> N doubles, no conversion, no scale
+// the bare core transforms of spqlios-fft.h:52-53 (`ifft`, `fft`): N doubles -> N doubles, no conversion, no scale.
+// Same element type on both sides makes aliasing easy: the persistent kernels prefetch the next polynomial while they
+// store the current one, so ANY overlap of the two ranges (out = in, or out = in + N inside a batch) is refused.
+static bool ranges_overlap(const void *a, const void *b, size_t bytes) {
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    if (bytes == 0) return x == y;
+    return x < y + bytes && y < x + bytes;
+}
 int tfhe_amd_ifft_f64(tfhe_amd_ctx *c, double *out_d, const double *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
     ENTER(c);
-    REQUIRE(c, out_d != in_d, "the transforms are out of place on the device");
+    REQUIRE(c, !ranges_overlap(out_d, in_d, (size_t)batch * c->p.N * sizeof(double)), "the transforms are out of place on the device: the two ranges overlap");
     if (batch == 0) return TFHE_AMD_OK;
     return c->logn == 10 ? launch_ifft_t<double, 10>(c, out_d, in_d, batch) : launch_ifft_t<double, 11>(c, out_d, in_d, batch);
 }
@@ -923,7 +1048,7 @@ int tfhe_amd_fft_f64(tfhe_amd_ctx *c, double *out_d, const double *in_d, int bat
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
     ENTER(c);
     REQUIRE_ALIGNED16(c, in_d);
-    REQUIRE(c, out_d != in_d, "the transforms are out of place on the device");
+    REQUIRE(c, !ranges_overlap(out_d, in_d, (size_t)batch * c->p.N * sizeof(double)), "the transforms are out of place on the device: the two ranges overlap");
     if (batch == 0) return TFHE_AMD_OK;
     return c->logn == 10 ? launch_fft_t<double, 10>(c, out_d, in_d, batch) : launch_fft_t<double, 11>(c, out_d, in_d, batch);
 }
@@ -1146,9 +1271,12 @@ int tfhe_amd_bootstrap_streamed(tfhe_amd_ctx *c, int32_t *out_d, int32_t mu, con
         if (int rc = grow(c, &c->ws_acc, &c->ws_acc_bytes, (size_t)batch * 2 * c->p.N * 4)) return rc;
         // one warm-up per (key-switch variant, blind-rotation kernel class): the class follows the batch size, and the
         // first launch of a kernel sets its LDS attribute (hipFuncSetAttribute), which must not happen inside a capture
-        BlindRotateArgs<int32_t> probe;
+        // (the schedule's two 0-step launches -- initialisation and extraction -- never take the split kernel: their class
+        // follows the batch alone, so it is part of the key too)
+        BlindRotateArgs<int32_t> probe, probe0;
         fill_common(c, probe, c->bk, 0, 1, batch);
-        const unsigned vbit = 1u << ((c->ks_force_gather ? 3 : 0) + br32_class(c, probe));
+        fill_common(c, probe0, c->bk, 0, 0, batch);
+        const unsigned vbit = 1u << ((c->ks_force_gather ? 9 : 0) + 3 * br32_class(c, probe0) + br32_class(c, probe));
         if (!(c->streamed_warm & vbit)) {
             c->streamed_warm |= vbit;
             return streamed_plain(c, out_d, mu, x_d, batch);
@@ -1391,6 +1519,7 @@ int tfhe_amd_cb_create(const tfhe_amd_cb_params *p, int device, tfhe_amd_cb **ou
 
 void tfhe_amd_cb_destroy(tfhe_amd_cb *cb) {
     if (!cb) return;
+    if (cb->c2) (void)hipSetDevice(cb->c2->device);  // the frees below belong to that device
     if (cb->c2) (void)hipStreamSynchronize(cb->c2->stream);
     if (cb->bk) tfhe_amd_gsw_free(cb->bk);
     for (int u = 0; u < 2; u++) {

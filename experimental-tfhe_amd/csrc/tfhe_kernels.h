@@ -1695,6 +1695,26 @@ TFHE_GLOBAL void k_modswitch(int32_t *__restrict__ out, const int32_t *__restric
     if (gid < total) out[gid] = modswitch_2N<LOGN>(in[gid]);
 }
 
+// ------------------------------------------- diagnostics: shader clock under load (tfhe_amd_clock_probe)
+// One lane per workgroup stamps the shader-cycle counter and the 100 MHz reference counter, sleeps (s_sleep: no issue
+// slots taken from the waves it runs beside) until `ticks` reference ticks have passed, and stamps again.
+struct ClockStamp {
+    unsigned long long c0, r0, c1, r1;
+};
+TFHE_GLOBAL void k_clock_probe(ClockStamp *out, unsigned long long ticks) {
+    if (threadIdx.x != 0) return;
+    ClockStamp s;
+    s.c0 = TFHE_SHADER_CYCLES();
+    s.r0 = TFHE_REF_TICKS();
+    do {
+        TFHE_SLEEP();
+        s.r1 = TFHE_REF_TICKS();
+    } while (s.r1 - s.r0 < ticks);
+    s.c1 = TFHE_SHADER_CYCLES();
+    s.r1 = TFHE_REF_TICKS();
+    out[blockIdx.x] = s;
+}
+
 // ------------------------------------------- exact (FFT-free) external product
 // The reference's `#ifndef USE_FFT` backend (poc:285-316): the same external product with every
 // polynomial product computed exactly in Z_{2^W}[X]/(X^N+1) (torus{32,64}PolynomialMultAddKaratsuba,

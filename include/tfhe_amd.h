@@ -71,8 +71,17 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *params, int device, tfhe_amd_ctx 
 void tfhe_amd_ctx_destroy(tfhe_amd_ctx *ctx);
 const char *tfhe_amd_last_error(const tfhe_amd_ctx *ctx);
 const char *tfhe_amd_version(void);
-/* one-line description of a device (name, gfx target, CUs, clock, memory, LDS limits, runtime version) for logs */
+/* one-line description of a device (name, gfx target, PCI bus id, CUs, clock, memory, LDS limits, runtime version) for logs */
 int tfhe_amd_device_info(int device, char *buf, size_t len);
+/* number of HIP devices this process sees */
+int tfhe_amd_device_count(int *count);
+/* "domain:bus:device.function" of the GPU behind an ordinal (hipDeviceGetPCIBusId): ordinals are per process -- a launcher
+ * may show every rank ONE device, all of them "device 0" -- the bus id is what tells two GPUs apart; len >= 13 */
+int tfhe_amd_device_pci_bus_id(int device, char *buf, size_t len);
+/* the shader clock (GHz) the chip holds WHILE the work already queued on the context's stream runs: 32 one-wave
+ * probes on a second stream stamp s_memtime / s_memrealtime around a sleep of duration_us; median, and optionally
+ * min / max over the probes.  Blocks for about duration_us.  Diagnostic only. */
+int tfhe_amd_clock_probe(tfhe_amd_ctx *ctx, int duration_us, double *ghz_median, double *ghz_min, double *ghz_max);
 /* use an existing hipStream_t (passed as void*); NULL = the context's own stream */
 int tfhe_amd_set_stream(tfhe_amd_ctx *ctx, void *hip_stream);
 int tfhe_amd_sync(tfhe_amd_ctx *ctx);
@@ -135,6 +144,18 @@ int tfhe_amd_set_bootstrap_key(tfhe_amd_ctx *ctx, const tfhe_amd_gsw *bk);
 /* key-switch key, host layout [N][ks_t][1<<ks_basebit][ks_n_out+1] int32
  * (LweKeySwitchKey::ks, CB/lwe_functions.cpp:96-110; PoC preKS poc:375) */
 int tfhe_amd_load_keyswitch_key(tfhe_amd_ctx *ctx, const int32_t *ks);
+/* the same key from DEVICE memory of the context's device (or any pointer hipMemcpyDefault resolves), e.g. the bytes a
+ * broadcast delivered; tfhe_amd_keyswitch_key_export writes the resident key in that same layout */
+int tfhe_amd_load_keyswitch_key_d(tfhe_amd_ctx *ctx, const int32_t *ks_any);
+int tfhe_amd_keyswitch_key_bytes(const tfhe_amd_ctx *ctx, size_t *bytes);
+int tfhe_amd_keyswitch_key_export(tfhe_amd_ctx *ctx, void *dst_any);
+/* TGSW samples as the bytes of the KERNEL layout ([count][(k+1)l][k+1][N/128][64] complex doubles, scaled by 2/N): what
+ * one device hands to another -- SURVEY 8(e): "replicate bkFFT + KS key on every GPU at setup (one hipMemcpy per device or
+ * one RCCL broadcast)" -- so that the receiver neither regenerates nor re-converts the key.  src / dst: device memory of
+ * the context's device, or host memory. */
+int tfhe_amd_gsw_packed_bytes(const tfhe_amd_ctx *ctx, int count, size_t *bytes);
+int tfhe_amd_gsw_export_packed(tfhe_amd_ctx *ctx, const tfhe_amd_gsw *gsw, void *dst_any);
+int tfhe_amd_gsw_from_packed(tfhe_amd_ctx *ctx, const void *src_any, int count, tfhe_amd_gsw **out);
 
 /* ---- L1: the FFT plugin (class FFT_Processor_Spqlios, CB/spqlios/lagrangehalfc_impl.h:8-36) */
 /* execute_reverse_int / execute_reverse_torus32: [batch][N] int32 -> [batch][N] doubles */
@@ -278,6 +299,51 @@ int tfhe_amd_privks(tfhe_amd_cb *cb, int32_t *out_d, int u, const int64_t *x_d, 
 /* tfhe_CircuitBootstrapFFT: x_d [batch][N1+1] LWE32 -> out_d [batch][2][l1][2][N1] int32
  * (TGswSample32::samples[u][w], each a TLWE32 (a, b)) */
 int tfhe_amd_circuit_bootstrap(tfhe_amd_cb *cb, int32_t *out_d, const int32_t *x_d, int batch);
+
+/* ---- several GPUs in one process: a pool of contexts, one per device ----------------------------------------------
+ * The reference's only parallel construct is an independent-item loop (parallel/src/test_parallel_multiplications.cpp:62,
+ * `#pragma omp parallel for`): samples never interact.  A pool maps that loop onto the GPUs of a node: one context, ONE
+ * HOST THREAD and one pinned staging buffer per member, the CALLER'S keys uploaded once to every member
+ * (LweBootstrappingKeyFFT ownership: CB/lwe_functions.cpp:287-316 -- the caller keeps the host key, the pool keeps device
+ * copies), a batch cut into contiguous slices (member r of m gets floor(count/m) samples, the first count%m members one
+ * more), no collective, outputs written straight into the caller's array.  `devices` may name a device more than
+ * once (two members then share that GPU, each with its own stream and key copy).  A pool is not re-entrant: one call at
+ * a time (calls from several host threads are serialised). */
+typedef struct tfhe_amd_pool tfhe_amd_pool;
+int tfhe_amd_pool_create(const tfhe_amd_params *params, const int *devices, int n_devices, tfhe_amd_pool **out);
+void tfhe_amd_pool_destroy(tfhe_amd_pool *pool);
+const char *tfhe_amd_pool_last_error(const tfhe_amd_pool *pool);
+int tfhe_amd_pool_size(const tfhe_amd_pool *pool);
+int tfhe_amd_pool_device(const tfhe_amd_pool *pool, int member);
+/* member's context (borrowed; for options, events, the device-pointer entry points) */
+tfhe_amd_ctx *tfhe_amd_pool_ctx(tfhe_amd_pool *pool, int member);
+/* one upload per member, in parallel: bkfft = LweBootstrappingKeyFFT::bkFFT flattened, [n][(k+1)l][k+1][N] doubles (as
+ * tfhe_amd_gsw_from_fft); ks = LweKeySwitchKey::ks flattened (as tfhe_amd_load_keyswitch_key); either may be NULL */
+int tfhe_amd_pool_load_keys(tfhe_amd_pool *pool, const double *bkfft, const int32_t *ks);
+/* the same with the bootstrapping key in coefficient form (converted on every device, tGswToFFTConvert) */
+int tfhe_amd_pool_load_keys_torus(tfhe_amd_pool *pool, const void *bk_torus, const int32_t *ks);
+/* tfhe_bootstrap_FFT / tfhe_bootstrap_woKS_FFT / lweKeySwitch over `count` samples in HOST memory, sharded over the members:
+ * x [count][n+1] -> out [count][n+1];  x [count][n+1] -> out [count][N+1];  x [count][N+1] -> out [count][ks_n_out+1] */
+int tfhe_amd_pool_bootstrap_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count);
+int tfhe_amd_pool_bootstrap_woks_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count);
+int tfhe_amd_pool_keyswitch_host(tfhe_amd_pool *pool, int32_t *out, const int32_t *x, int count);
+/* what the last sharded call did: per member the number of samples and the host seconds its thread spent; arrays of
+ * tfhe_amd_pool_size entries, either may be NULL */
+int tfhe_amd_pool_last_split(const tfhe_amd_pool *pool, int *counts, double *seconds);
+
+/* the circuit bootstrap the same way (tfhe_CircuitBootstrapFFT over the driver loop poc:1009-1013) */
+typedef struct tfhe_amd_cb_pool tfhe_amd_cb_pool;
+int tfhe_amd_cb_pool_create(const tfhe_amd_cb_params *params, const int *devices, int n_devices, tfhe_amd_cb_pool **out);
+void tfhe_amd_cb_pool_destroy(tfhe_amd_cb_pool *pool);
+const char *tfhe_amd_cb_pool_last_error(const tfhe_amd_cb_pool *pool);
+int tfhe_amd_cb_pool_size(const tfhe_amd_cb_pool *pool);
+tfhe_amd_cb *tfhe_amd_cb_pool_member(tfhe_amd_cb_pool *pool, int member);
+int tfhe_amd_cb_pool_load_preks(tfhe_amd_cb_pool *pool, const int32_t *preks);
+int tfhe_amd_cb_pool_load_bk_fft(tfhe_amd_cb_pool *pool, const double *bkfft);
+int tfhe_amd_cb_pool_load_bk_torus(tfhe_amd_cb_pool *pool, const int64_t *bk);
+int tfhe_amd_cb_pool_load_privks_plane(tfhe_amd_cb_pool *pool, int u_plane, const int32_t *plane);
+/* x [count][N1+1] LWE32 (host) -> out [count][2][l1][2][N1] int32 (host) */
+int tfhe_amd_cb_pool_circuit_bootstrap_host(tfhe_amd_cb_pool *pool, int32_t *out, const int32_t *x, int count);
 
 /* ---- harness: synthetic keys and samples (the reference's keygen/encrypt/phase,
  *      poc:88-134,191-227,342-423; PRNG spec in DESIGN.md) -- host side ------------------ */

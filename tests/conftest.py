@@ -22,6 +22,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 _GPU_LIVE = {"on": False}
+# the CPU emulator of the kernels (tests/emu) presents 8 devices to every test and to every child process: contexts default
+# to device 0 as before, the multi-device tests place them elsewhere, and the emulator aborts on any operand used from
+# another device than the calling thread's current one (tests/emu/emu_runtime.h, "devices")
+os.environ.setdefault("TFHE_EMU_DEVICES", "8")
 
 
 def pytest_configure(config):

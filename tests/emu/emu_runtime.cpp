@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -231,6 +232,7 @@ v16i_t mfma_i32_32x32x32_i8(const v4i_t &a, const v4i_t &b, const v16i_t &c_in) 
 }  // namespace emu
 struct EmuGraph {
     std::vector<std::function<void()>> nodes;
+    int device = 0;  // the device of the stream the capture was opened on
 };
 namespace emu {
 static thread_local EmuGraph *t_capture = nullptr;  // hipStreamCaptureModeThreadLocal
@@ -303,7 +305,139 @@ static void launch_flat_now(const std::function<void()> &body, Dim3 grid, Dim3 b
 
 }  // namespace emu
 
-hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) {
+// ---- devices: registry of allocations / streams / attributes, and the cross-device checks ----------------------
+namespace emu {
+namespace {
+struct Alloc {
+    size_t bytes;
+    int device;
+    bool host;  // hipHostMalloc: visible from every device
+};
+std::mutex g_dev_mu;
+std::map<uintptr_t, Alloc> g_allocs;                    // base address -> allocation
+std::map<std::pair<const void *, int>, int> g_lds_attr;  // (kernel, device) -> allowed dynamic LDS bytes
+thread_local int t_device = 0;
+
+[[noreturn]] void die(const char *what, const char *detail, int other_device) {
+    fprintf(stderr, "emu: %s: %s belongs to device %d, the calling thread's current device is %d (missing hipSetDevice?)\n",
+            what, detail, other_device, t_device);
+    abort();
+}
+// the allocation p points into (base <= p < base + bytes), or nullptr: host memory the emulator does not know
+const Alloc *find_alloc(const void *p) {
+    const uintptr_t a = (uintptr_t)p;
+    auto it = g_allocs.upper_bound(a);
+    if (it == g_allocs.begin()) return nullptr;
+    --it;
+    return a < it->first + it->second.bytes ? &it->second : nullptr;
+}
+// a pointer that must be device memory of the current device (must_be_device) or, if it is device memory at all, of the current device
+void check_ptr(const void *p, bool must_be_device, const char *what, const char *role) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    const Alloc *a = find_alloc(p);
+    if (!a || a->host) {
+        if (must_be_device && !a) {
+            fprintf(stderr, "emu: %s: %s %p is not device memory\n", what, role, p);
+            abort();
+        }
+        return;
+    }
+    if (a->device != t_device) die(what, role, a->device);
+}
+int stream_device(hipStream_t s) { return s ? static_cast<Stream *>(s)->device : t_device; }
+void check_stream(hipStream_t s, const char *what) {
+    if (stream_device(s) != t_device) die(what, "the stream", stream_device(s));
+}
+void register_alloc(void *p, size_t bytes, bool host) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    g_allocs[(uintptr_t)p] = Alloc{bytes ? bytes : 1, t_device, host};
+}
+void unregister_alloc(void *p, bool host, const char *what) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = g_allocs.find((uintptr_t)p);
+    if (it == g_allocs.end() || it->second.host != host) {
+        fprintf(stderr, "emu: %s(%p): not a live allocation of this kind (double free?)\n", what, p);
+        abort();
+    }
+    if (!host && it->second.device != t_device) die(what, "the allocation", it->second.device);
+    g_allocs.erase(it);
+}
+}  // namespace
+
+int device_count() {
+    static const int n = [] {
+        const char *e = getenv("TFHE_EMU_DEVICES");
+        const int v = e ? atoi(e) : 1;
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    return n;
+}
+int current_device() { return t_device; }
+
+void check_launch(const void *fn, size_t smem_bytes, hipStream_t stream, const char *kernel) {
+    check_stream(stream, kernel);
+    if (fn && smem_bytes > 64 * 1024) {  // above 64 KiB the limit is raised per kernel AND per device
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        auto it = g_lds_attr.find(std::make_pair(fn, t_device));
+        if (it == g_lds_attr.end() || (size_t)it->second < smem_bytes) {
+            fprintf(stderr, "emu: %s: %zu bytes of dynamic LDS without hipFuncSetAttribute(MaxDynamicSharedMemorySize) on device %d\n",
+                    kernel, smem_bytes, t_device);
+            abort();
+        }
+    }
+}
+// kernel arguments are plain structs and pointers: any aligned 8-byte word of their object representation that points
+// into a live allocation of another device is a device pointer used on the wrong device (heap addresses cannot be
+// mistaken for the small integers, strides and gadget masks that share these structs)
+void check_words(const char *kernel, const void *obj, size_t bytes) {
+    if (bytes < 8 || device_count() == 1) return;
+    const unsigned char *b = static_cast<const unsigned char *>(obj);
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    for (size_t off = 0; off + 8 <= bytes; off += 8) {
+        uintptr_t w;
+        memcpy(&w, b + off, 8);
+        const Alloc *a = find_alloc((const void *)w);
+        if (a && !a->host && a->device != t_device) die(kernel, "a pointer among the kernel arguments", a->device);
+    }
+}
+}  // namespace emu
+
+hipError_t hipSetDevice(int d) {
+    if (d < 0 || d >= emu::device_count()) return hipErrorInvalidDevice;
+    emu::t_device = d;
+    return hipSuccess;
+}
+hipError_t hipGetDevice(int *d) {
+    *d = emu::t_device;
+    return hipSuccess;
+}
+hipError_t hipGetDeviceCount(int *d) {
+    *d = emu::device_count();
+    return hipSuccess;
+}
+hipError_t hipDeviceGetPCIBusId(char *buf, int len, int device) {
+    if (device < 0 || device >= emu::device_count() || !buf || len < 13) return hipErrorInvalidDevice;
+    snprintf(buf, (size_t)len, "0000:%02x:00.0", 0xe0 + device);
+    return hipSuccess;
+}
+hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int device) {
+    if (device < 0 || device >= emu::device_count()) return hipErrorInvalidDevice;
+    *v = 3;
+    return hipSuccess;
+}
+
+static void emu_copy_checks(void *d, const void *s, hipMemcpyKind kind, const char *what) {
+    emu::check_ptr(d, kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToDevice, what, "the destination");
+    emu::check_ptr(s, kind == hipMemcpyDeviceToHost || kind == hipMemcpyDeviceToDevice, what, "the source");
+}
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind kind) {
+    emu_copy_checks(d, s, kind, "hipMemcpy");
+    memcpy(d, s, n);
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind kind, hipStream_t stream) {
+    emu::check_stream(stream, "hipMemcpyAsync");
+    emu_copy_checks(d, s, kind, "hipMemcpyAsync");
     if (emu::t_capture) {
         emu::t_capture->nodes.push_back([d, s, n]() { memcpy(d, s, n); });
         return hipSuccess;
@@ -311,7 +445,14 @@ hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipSt
     memcpy(d, s, n);
     return hipSuccess;
 }
-hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
+hipError_t hipMemset(void *d, int v, size_t n) {
+    emu::check_ptr(d, true, "hipMemset", "the destination");
+    memset(d, v, n);
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t stream) {
+    emu::check_stream(stream, "hipMemsetAsync");
+    emu::check_ptr(d, true, "hipMemsetAsync", "the destination");
     if (emu::t_capture) {
         emu::t_capture->nodes.push_back([d, v, n]() { memset(d, v, n); });
         return hipSuccess;
@@ -319,9 +460,45 @@ hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
     memset(d, v, n);
     return hipSuccess;
 }
-hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) {
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
+    *s = new emu::Stream{emu::t_device};
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+    emu::check_stream(s, "hipStreamDestroy");
+    delete static_cast<emu::Stream *>(s);
+    return hipSuccess;
+}
+hipError_t hipEventCreate(hipEvent_t *e) {
+    *e = new EmuEvent{0, emu::t_device};
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t stream) {
+    emu::check_stream(stream, "hipEventRecord");
+    if (e->device != emu::t_device) emu::die("hipEventRecord", "the event", e->device);
+    e->t = emu_now_ms();
+    return hipSuccess;
+}
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    if (a->device != b->device) emu::die("hipEventElapsedTime", "one of the two events", a->device);
+    *ms = (float)(b->t - a->t);
+    return hipSuccess;
+}
+hipError_t hipEventDestroy(hipEvent_t e) {
+    if (e->device != emu::t_device) emu::die("hipEventDestroy", "the event", e->device);
+    delete e;
+    return hipSuccess;
+}
+hipError_t emu_func_set_attribute(const void *fn, int bytes) {
+    std::lock_guard<std::mutex> lk(emu::g_dev_mu);
+    emu::g_lds_attr[std::make_pair(fn, emu::t_device)] = bytes;
+    return hipSuccess;
+}
+hipError_t hipStreamBeginCapture(hipStream_t stream, hipStreamCaptureMode) {
+    emu::check_stream(stream, "hipStreamBeginCapture");
     if (emu::t_capture) return hipErrorInvalidValue;
     emu::t_capture = new EmuGraph();
+    emu::t_capture->device = emu::t_device;
     return hipSuccess;
 }
 hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *graph) {
@@ -341,20 +518,30 @@ hipError_t hipGraphExecDestroy(hipGraphExec_t exec) {
     delete exec;
     return hipSuccess;
 }
-hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t) {
+hipError_t hipGraphLaunch(hipGraphExec_t exec, hipStream_t stream) {
+    emu::check_stream(stream, "hipGraphLaunch");
+    if (exec->device != emu::t_device) emu::die("hipGraphLaunch", "the captured graph", exec->device);
     for (auto &node : exec->nodes) node();
     return hipSuccess;
 }
-hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int device) {
+    if (device < 0 || device >= emu::device_count()) return hipErrorInvalidDevice;
     memset(p, 0, sizeof(*p));
-    snprintf(p->name, sizeof(p->name), "CPU emulation of the kernels (tests/emu), not a device");
+    snprintf(p->name, sizeof(p->name), "CPU emulation of the kernels (tests/emu), not a device; emulated ordinal %d of %d", device,
+             emu::device_count());
     snprintf(p->gcnArchName, sizeof(p->gcnArchName), "emu");
     p->multiProcessorCount = 3;
     p->warpSize = 64;
     p->sharedMemPerBlock = p->sharedMemPerBlockOptin = 160 * 1024;
+    p->pciBusID = 0xe0 + device;
     return hipSuccess;
 }
 
+unsigned long long emu_ref_ticks() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (unsigned long long)ts.tv_sec * 100000000ull + (unsigned long long)ts.tv_nsec / 10ull;
+}
 double emu_now_ms() {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -364,9 +551,25 @@ double emu_now_ms() {
 hipError_t hipMalloc(void **p, size_t bytes) {
     // exact size: ASan then flags any out-of-bounds device-pointer access made by a kernel
     *p = malloc(bytes ? bytes : 1);
-    return *p ? hipSuccess : hipErrorInvalidValue;
+    if (!*p) return hipErrorInvalidValue;
+    emu::register_alloc(*p, bytes, false);
+    return hipSuccess;
 }
 hipError_t hipFree(void *p) {
+    if (!p) return hipSuccess;
+    emu::unregister_alloc(p, false, "hipFree");
+    free(p);
+    return hipSuccess;
+}
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) {
+    *p = malloc(bytes ? bytes : 1);
+    if (!*p) return hipErrorInvalidValue;
+    emu::register_alloc(*p, bytes, true);
+    return hipSuccess;
+}
+hipError_t hipHostFree(void *p) {
+    if (!p) return hipSuccess;
+    emu::unregister_alloc(p, true, "hipHostFree");
     free(p);
     return hipSuccess;
 }

@@ -82,16 +82,26 @@ static inline V tfhe_nontemporal_load(const V *p) { return *p; }
 template <typename V>
 static inline void tfhe_nontemporal_store(V v, V *p) { *p = v; }
 #define TFHE_TRAP() abort()
+// clock probe: the reference counter is the wall clock at 100 MHz, the "shader" counter 24 cycles per tick (a nominal 2.4 GHz)
+unsigned long long emu_ref_ticks();
+#define TFHE_REF_TICKS() emu_ref_ticks()
+#define TFHE_SHADER_CYCLES() (24ull * emu_ref_ticks())
+#define TFHE_SLEEP() ((void)0)
 namespace emu {
 typedef int v4i_t __attribute__((vector_size(16)));
 typedef int v16i_t __attribute__((vector_size(64)));
 v16i_t mfma_i32_32x32x32_i8(const v4i_t &a, const v4i_t &b, const v16i_t &c);  // wave-collective, same operand maps as the hardware's
 }
 #define TFHE_MFMA_I8(a, b, c) emu::mfma_i32_32x32x32_i8((a), (b), (c))
-#define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...) \
-    emu::launch([=]() { kernel(__VA_ARGS__); }, grid, block, smem)
-#define TFHE_LAUNCH_FLAT(kernel, grid, block, stream, ...) \
-    emu::launch_flat([=]() { kernel(__VA_ARGS__); }, grid, block)
+// Several emulated devices (TFHE_EMU_DEVICES=N): every launch is checked before it runs -- the stream, the kernel's
+// dynamic-LDS attribute and every device pointer among the arguments must belong to the calling thread's CURRENT
+// device, or the process aborts with a message naming the operand (see "devices" below).
+#define TFHE_LAUNCH(kernel, grid, block, smem, stream, ...)                                                    \
+    (emu::check_launch(emu::fn_key(kernel), (size_t)(smem), (stream), #kernel), emu::check_args(#kernel, __VA_ARGS__), \
+     emu::launch([=]() { kernel(__VA_ARGS__); }, grid, block, smem))
+#define TFHE_LAUNCH_FLAT(kernel, grid, block, stream, ...)                                           \
+    (emu::check_launch(nullptr, 0, (stream), #kernel), emu::check_args(#kernel, __VA_ARGS__), \
+     emu::launch_flat([=]() { kernel(__VA_ARGS__); }, grid, block))
 
 // workgroups of one launch run on several OS threads: global-memory atomics must be real ones
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
@@ -110,52 +120,77 @@ static inline double2 tfhe_buffer_load_d2(TFHE_BUFFER_RSRC rsrc, uint32_t lane_o
 typedef int hipError_t;
 typedef void *hipStream_t;
 #define TFHE_DYN_LDS(name) unsigned char *name = emu::dyn_smem()
-enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorInvalidDevice = 101 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *d) { *d = 1; return hipSuccess; }
+
+// ---- devices ---------------------------------------------------------------------------------------------------
+// TFHE_EMU_DEVICES=N (default 1) emulated devices.  The current device is per host thread, as in HIP.  Every allocation,
+// stream, event, captured graph and per-kernel LDS attribute is tagged with the device that was current when it was made;
+// a launch, copy, memset, free, event record or graph launch whose operands belong to ANOTHER device than the calling
+// thread's current one ABORTS the process (message on stderr).  Stricter than HIP in one place on purpose: hipFree and
+// hipStreamDestroy / hipEventDestroy of another device's object abort too (HIP accepts them), so that every path of the
+// host library is seen to select its device first.
+namespace emu {
+int device_count();
+int current_device();
+struct Stream { int device; };
+void check_launch(const void *fn, size_t smem_bytes, hipStream_t stream, const char *kernel);  // aborts on a foreign stream / missing LDS attribute
+void check_words(const char *kernel, const void *obj, size_t bytes);  // aborts if any 8-byte word of obj points into another device's memory
+template <class F>
+static inline const void *fn_key(F f) { return reinterpret_cast<const void *>(f); }
+static inline void check_args(const char *) {}
+template <class A, class... Rest>
+static inline void check_args(const char *kernel, const A &a, const Rest &...rest) {
+    check_words(kernel, &a, sizeof(A));
+    check_args(kernel, rest...);
+}
+}  // namespace emu
+hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int *d);
+hipError_t hipGetDeviceCount(int *d);
+hipError_t hipDeviceGetPCIBusId(char *buf, int len, int device);  // "0000:<e0 + device>:00.0"
 hipError_t hipMalloc(void **p, size_t bytes);
 hipError_t hipFree(void *p);
 enum { hipHostMallocDefault = 0 };
-static inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { return hipMalloc(p, bytes); }  // "pinned" = plain host memory here
-static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
-static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t bytes, unsigned);  // "pinned" = plain host memory here, usable from every device
+hipError_t hipHostFree(void *p);
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind);
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t);  // recorded while a capture is open
-static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+hipError_t hipMemset(void *d, int v, size_t n);
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t);  // recorded while a capture is open
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 // events: wall-clock stamps (the emulator runs launches synchronously)
-struct EmuEvent { double t; };
+struct EmuEvent { double t; int device; };
 typedef EmuEvent *hipEvent_t;
 double emu_now_ms();
-static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new EmuEvent{0}; return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now_ms(); return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t *e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t);
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
-static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t emu_func_set_attribute(const void *fn, int bytes);
 template <class F>
-static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
-// streams: launches run synchronously, a stream is only a token
+static inline hipError_t hipFuncSetAttribute(F f, hipFuncAttribute, int bytes) { return emu_func_set_attribute(emu::fn_key(f), bytes); }
+// streams: launches run synchronously, a stream is a token that remembers its device
 enum { hipStreamNonBlocking = 1 };
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)(new char); return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t s) { delete (char *)s; return hipSuccess; }
-// device queries: one emulated "device" whose persistent-wave kernels get a small fixed grid (3 workgroups), so
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned);
+hipError_t hipStreamDestroy(hipStream_t s);
+// device queries: every emulated device gives persistent-wave kernels a small fixed grid (3 workgroups), so
 // that the batch loop of every wave is exercised at test sizes
 struct hipDeviceProp_t {
     char name[256], gcnArchName[256];
-    int multiProcessorCount, clockRate, l2CacheSize, warpSize;
+    int multiProcessorCount, clockRate, l2CacheSize, warpSize, pciDomainID, pciBusID, pciDeviceID;
     size_t totalGlobalMem, sharedMemPerBlock, sharedMemPerBlockOptin;
 };
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int device);
 static inline hipError_t hipRuntimeGetVersion(int *v) { *v = 0; return hipSuccess; }
 static inline hipError_t hipDriverGetVersion(int *v) { *v = 0; return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
-static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int device);
 static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 1; return hipSuccess; }
 // stream capture / graphs: a graph is the list of launches recorded between Begin and EndCapture
 struct EmuGraph;

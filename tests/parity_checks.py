@@ -30,7 +30,7 @@ class GateSetup:
     """keys + engine for one Torus32 parameter set; keys come from the ORACLE's generator and
     are cross-checked against the library's own generator (same PRNG specification)."""
 
-    def __init__(self, lib_path, N, n, l, Bgbit, ks_t, ks_bb, bk_stdev=2.0 ** -25, ks_stdev=2.0 ** -15, seed=SEED):
+    def __init__(self, lib_path, N, n, l, Bgbit, ks_t, ks_bb, bk_stdev=2.0 ** -25, ks_stdev=2.0 ** -15, seed=SEED, device=0):
         self.N, self.n, self.l, self.Bgbit, self.ks_t, self.ks_bb = N, n, l, Bgbit, ks_t, ks_bb
         self.lib_path, self.seed = lib_path, seed
         self.lwe_key = O.keygen_binary(n, seed, 1)
@@ -38,7 +38,7 @@ class GateSetup:
         self.bk = O.bk_create32(N, self.lwe_key, self.tkey, l, Bgbit, bk_stdev, seed, 1000)
         self.ks = O.ks_create32(self.tkey, self.lwe_key, ks_t, ks_bb, ks_stdev, seed, 100000)
         self.bk_stdev, self.ks_stdev = bk_stdev, ks_stdev
-        self.eng = T.Engine(torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=ks_t, ks_basebit=ks_bb, lib_path=lib_path)
+        self.eng = T.Engine(torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=ks_t, ks_basebit=ks_bb, device=device, lib_path=lib_path)
         self.gsw = self.eng.gsw_from_fft(self.bk)
         self.eng.set_bootstrap_key(self.gsw)
         self.eng.load_keyswitch_key(self.ks)
