@@ -47,4 +47,5 @@ void tfhe_amd_dropin_release(const void *key_object) {
         tfhe_amd_compat::release_all();
 }
 void tfhe_amd_dropin_set_device(int device) { tfhe_amd_compat::set_device(device); }
+void tfhe_amd_dropin_set_devices(const int *devices, int n) { tfhe_amd_compat::set_devices(devices, n); }
 }

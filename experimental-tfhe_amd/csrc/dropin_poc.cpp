@@ -82,6 +82,7 @@ void tfhe_CircuitBootstrapFFT_array(TGswSample32 *const *results, const LweSampl
 void CMux(TLweSample32 *out, const TGswSample32 *c, const TLweSample32 *in0, const TLweSample32 *in1, const Globals *env) { TFHE_AMD_SHIM_GUARD();
     engine_of(env).CMux(out, c, in0, in1);
 }
+void tfhe_amd_dropin_poc_set_devices(const int *devices, int n) { tfhe_amd_compat::set_devices(devices, n); }
 void tfhe_amd_dropin_release(const Globals *env) { TFHE_AMD_SHIM_GUARD();
     auto &m = engines();
     auto it = m.find(env);

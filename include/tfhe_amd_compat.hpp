@@ -113,6 +113,20 @@ inline int &device_ordinal() {
     return d;
 }
 inline void set_device(int d) { TFHE_AMD_SHIM_GUARD(); device_ordinal() = d; }
+// Several GPUs behind the ARRAY forms: with more than one device named here, tfhe_bootstrap_FFT_array,
+// tfhe_bootstrap_woKS_FFT_array, lweKeySwitch_array and PocEngine::tfhe_CircuitBootstrapFFT_array cut the caller's loop into
+// contiguous slices over a pool (tfhe_amd_pool / tfhe_amd_cb_pool: one context, host thread and pinned staging buffer per
+// device, the caller's key uploaded once to each) -- the reference's `#pragma omp parallel for` over independent items
+// (parallel/src/test_parallel_multiplications.cpp:62) with GPUs as the workers.  The one-sample entry points stay on devices[0].
+inline std::vector<int> &device_list() {
+    static std::vector<int> d;
+    return d;
+}
+inline void set_devices(const int *devices, int n) {
+    TFHE_AMD_SHIM_GUARD();
+    device_list().assign(devices, devices + (n > 0 ? n : 0));
+    if (n > 0) device_ordinal() = devices[0];
+}
 
 inline void staging(Resident &R, size_t bytes) {
     if (R.d_in) return;
@@ -155,6 +169,88 @@ inline uint64_t key_fingerprint(const GswT *bkFFT, int n, int N, int l, const Lw
 }
 
 inline void release_entry(std::map<ResidentKey, Resident>::iterator it);
+// the pointer-rich host keys as the flat arrays of the C ABI: [n][2l][2][N] doubles, [ks->n][t][base][n_out+1] int32
+template <class GswT>
+inline std::vector<double> flatten_bk(const GswT *bkFFT, int n, int N, int l) {
+    std::vector<double> flat((size_t)n * 2 * l * 2 * N);
+    for (int i = 0; i < n; i++)
+        for (int r = 0; r < 2 * l; r++)
+            for (int q = 0; q < 2; q++)
+                std::memcpy(&flat[(((size_t)i * 2 * l + r) * 2 + q) * N], bkFFT[i].all_samples[r].a[q].values, sizeof(double) * (size_t)N);
+    return flat;
+}
+inline std::vector<int32_t> flatten_ks(const LweKeySwitchKey *ks) {
+    const int rows = ks->base, row = ks->out_params->n + 1;
+    std::vector<int32_t> kflat((size_t)ks->n * ks->t * rows * row);
+    for (int i = 0; i < ks->n; i++)
+        for (int j = 0; j < ks->t; j++)
+            for (int h = 0; h < rows; h++) {
+                int32_t *dst = &kflat[(((size_t)i * ks->t + j) * rows + h) * row];
+                std::memcpy(dst, ks->ks[i][j][h].a, sizeof(int32_t) * (size_t)(row - 1));
+                dst[row - 1] = ks->ks[i][j][h].b;
+            }
+    return kflat;
+}
+// the pools of the array forms (set_devices with more than one device): same keying and content sample as the one-device
+// registry, plus the device list the pool was built for
+struct PoolResident {
+    const void *owner = nullptr;
+    tfhe_amd_pool *pool = nullptr;
+    std::vector<int> devices;
+    uint64_t fingerprint = 0;
+    int n = 0, N = 0;
+    std::vector<int32_t> in, out;  // gathered rows (the pool stages them through its own pinned buffers)
+};
+inline std::map<ResidentKey, PoolResident> &pool_registry() {
+    static std::map<ResidentKey, PoolResident> r;
+    return r;
+}
+inline void pool_check(int rc, tfhe_amd_pool *p, const char *what) {
+    if (rc != TFHE_AMD_OK) {
+        std::fprintf(stderr, "tfhe_amd: %s failed (%d): %s\n", what, rc, p ? tfhe_amd_pool_last_error(p) : "");
+        std::abort();
+    }
+}
+template <class GswT>
+inline PoolResident &attach_pool(const GswT *bkFFT, int n, int N, int l, int Bgbit, const LweKeySwitchKey *ks, const void *owner) {
+    auto &reg = pool_registry();
+    const ResidentKey key{bkFFT ? (const void *)bkFFT : (const void *)ks, (const void *)ks, n, N, l, Bgbit};
+    const uint64_t fp = key_fingerprint(bkFFT, bkFFT ? n : 0, N, l, ks);
+    auto it = reg.find(key);
+    if (it != reg.end()) {
+        if (it->second.fingerprint == fp && it->second.devices == device_list()) return it->second;
+        tfhe_amd_pool_destroy(it->second.pool);  // the key was rebuilt in place, or the device list changed
+        reg.erase(it);
+    }
+    PoolResident R;
+    R.owner = owner;
+    R.fingerprint = fp;
+    R.devices = device_list();
+    R.n = n;
+    R.N = N;
+    tfhe_amd_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.torus_bits = 32;
+    p.n = n;
+    p.N = N;
+    p.k = 1;
+    p.l = l;
+    p.Bgbit = Bgbit;
+    if (ks) {
+        p.ks_t = ks->t;
+        p.ks_basebit = ks->basebit;
+        p.ks_n_out = ks->out_params->n;
+    }
+    pool_check(tfhe_amd_pool_create(&p, R.devices.data(), (int)R.devices.size(), &R.pool), nullptr, "tfhe_amd_pool_create");
+    {
+        std::vector<double> flat;
+        if (bkFFT) flat = flatten_bk(bkFFT, n, N, l);
+        std::vector<int32_t> kflat;
+        if (ks) kflat = flatten_ks(ks);
+        pool_check(tfhe_amd_pool_load_keys(R.pool, bkFFT ? flat.data() : nullptr, ks ? kflat.data() : nullptr), R.pool, "tfhe_amd_pool_load_keys");
+    }
+    return reg.emplace(key, std::move(R)).first->second;
+}
 // flatten n TGswSampleFFT (pointer-rich) into [n][2l][2][N] doubles and upload
 template <class GswT>
 inline Resident &attach_gsw(const GswT *bkFFT, int n, int N, int l, int Bgbit, const LweKeySwitchKey *ks = nullptr,
@@ -187,24 +283,13 @@ inline Resident &attach_gsw(const GswT *bkFFT, int n, int N, int l, int Bgbit, c
         p.ks_n_out = ks->out_params->n;
     }
     check(tfhe_amd_ctx_create(&p, device_ordinal(), &R.ctx), nullptr, "tfhe_amd_ctx_create");
-    std::vector<double> flat((size_t)n * 2 * l * 2 * N);
-    for (int i = 0; i < n; i++)
-        for (int r = 0; r < 2 * l; r++)
-            for (int q = 0; q < 2; q++)
-                std::memcpy(&flat[(((size_t)i * 2 * l + r) * 2 + q) * N], bkFFT[i].all_samples[r].a[q].values,
-                            sizeof(double) * (size_t)N);
-    check(tfhe_amd_gsw_from_fft(R.ctx, flat.data(), n, &R.gsw), R.ctx, "tfhe_amd_gsw_from_fft");
+    {
+        const std::vector<double> flat = flatten_bk(bkFFT, n, N, l);
+        check(tfhe_amd_gsw_from_fft(R.ctx, flat.data(), n, &R.gsw), R.ctx, "tfhe_amd_gsw_from_fft");
+    }
     check(tfhe_amd_set_bootstrap_key(R.ctx, R.gsw), R.ctx, "tfhe_amd_set_bootstrap_key");
     if (ks) {
-        const int rows = ks->base, row = ks->out_params->n + 1;
-        std::vector<int32_t> kflat((size_t)ks->n * ks->t * rows * row);
-        for (int i = 0; i < ks->n; i++)
-            for (int j = 0; j < ks->t; j++)
-                for (int h = 0; h < rows; h++) {
-                    int32_t *dst = &kflat[(((size_t)i * ks->t + j) * rows + h) * row];
-                    std::memcpy(dst, ks->ks[i][j][h].a, sizeof(int32_t) * (size_t)(row - 1));
-                    dst[row - 1] = ks->ks[i][j][h].b;
-                }
+        const std::vector<int32_t> kflat = flatten_ks(ks);
         check(tfhe_amd_load_keyswitch_key(R.ctx, kflat.data()), R.ctx, "tfhe_amd_load_keyswitch_key");
     }
     staging(R, sizeof(int32_t) * (size_t)(2 * N + n + 2));
@@ -254,10 +339,20 @@ inline void release(const void *key_object) {
         auto cur = it++;
         if (cur->first.obj == key_object || cur->first.ks == key_object || cur->second.owner == key_object) release_entry(cur);
     }
+    auto &pools = pool_registry();
+    for (auto it = pools.begin(); it != pools.end();) {
+        auto cur = it++;
+        if (cur->first.obj == key_object || cur->first.ks == key_object || cur->second.owner == key_object) {
+            tfhe_amd_pool_destroy(cur->second.pool);
+            pools.erase(cur);
+        }
+    }
 }
 inline void release_all() {
     TFHE_AMD_SHIM_GUARD();
     while (!registry().empty()) release_entry(registry().begin());
+    for (auto &e : pool_registry()) tfhe_amd_pool_destroy(e.second.pool);
+    pool_registry().clear();
 }
 
 inline Resident &attach(const LweBootstrappingKeyFFT *bk) {
@@ -359,15 +454,7 @@ inline Resident &attach_ks(const LweKeySwitchKey *ks) {
         p.ks_basebit = ks->basebit;
         p.ks_n_out = R.n;
         check(tfhe_amd_ctx_create(&p, device_ordinal(), &R.ctx), nullptr, "tfhe_amd_ctx_create");
-        const int row = R.n + 1;
-        std::vector<int32_t> kflat((size_t)ks->n * ks->t * ks->base * row);
-        for (int i = 0; i < ks->n; i++)
-            for (int j = 0; j < ks->t; j++)
-                for (int h = 0; h < ks->base; h++) {
-                    int32_t *dst = &kflat[(((size_t)i * ks->t + j) * ks->base + h) * row];
-                    std::memcpy(dst, ks->ks[i][j][h].a, sizeof(int32_t) * (size_t)R.n);
-                    dst[R.n] = ks->ks[i][j][h].b;
-                }
+        const std::vector<int32_t> kflat = flatten_ks(ks);
         check(tfhe_amd_load_keyswitch_key(R.ctx, kflat.data()), R.ctx, "tfhe_amd_load_keyswitch_key");
         staging(R, sizeof(int32_t) * (size_t)(2 * R.N + R.n + 2));
         it = reg.emplace(key, R).first;
@@ -412,9 +499,30 @@ inline void lwe_array_call(Resident &R, LweSample *const *results, int n_out, co
     check(tfhe_amd_memcpy_d2h(R.ctx, R.h_out, R.da_out, out_bytes), R.ctx, "d2h");
     scatter_lwe(results, (const int32_t *)R.h_out, count, n_out);
 }
+// the same call through a pool (more than one device named by set_devices): gather, ONE sharded call, scatter
+template <class Call>
+inline void lwe_array_pool_call(PoolResident &R, LweSample *const *results, int n_out, const LweSample *const *xs, int n_in, int count,
+                                Call call, const char *what) {
+    R.in.resize((size_t)count * (n_in + 1));
+    R.out.resize((size_t)count * (n_out + 1));
+    gather_lwe(R.in.data(), xs, count, n_in);
+    pool_check(call(R.out.data(), R.in.data()), R.pool, what);
+    scatter_lwe(results, R.out.data(), count, n_out);
+}
+inline PoolResident &attach_pool(const LweBootstrappingKeyFFT *bk) {
+    return attach_pool(bk->bkFFT, bk->in_out_params->n, bk->accum_params->N, bk->bk_params->l, bk->bk_params->Bgbit, bk->ks, bk);
+}
+inline bool use_pool() { return device_list().size() > 1; }
 inline void tfhe_bootstrap_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
                                      const LweSample *const *xs, int count) {
     TFHE_AMD_SHIM_GUARD();
+    if (count <= 0) return;
+    if (use_pool()) {
+        PoolResident &P = attach_pool(bk);
+        lwe_array_pool_call(P, results, P.n, xs, P.n, count,
+                            [&](int32_t *o, const int32_t *i) { return tfhe_amd_pool_bootstrap_host(P.pool, o, mu, i, count); }, "bootstrap (array, pool)");
+        return;
+    }
     Resident &R = attach(bk);
     lwe_array_call(R, results, R.n, xs, R.n, count,
                    [&](int32_t *o, const int32_t *i) { return tfhe_amd_bootstrap(R.ctx, o, mu, i, count); }, "bootstrap (array)");
@@ -422,12 +530,26 @@ inline void tfhe_bootstrap_FFT_array(LweSample *const *results, const LweBootstr
 inline void tfhe_bootstrap_woKS_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
                                           const LweSample *const *xs, int count) {
     TFHE_AMD_SHIM_GUARD();
+    if (count <= 0) return;
+    if (use_pool()) {
+        PoolResident &P = attach_pool(bk);
+        lwe_array_pool_call(P, results, P.N, xs, P.n, count,
+                            [&](int32_t *o, const int32_t *i) { return tfhe_amd_pool_bootstrap_woks_host(P.pool, o, mu, i, count); }, "bootstrap_woks (array, pool)");
+        return;
+    }
     Resident &R = attach(bk);
     lwe_array_call(R, results, R.N, xs, R.n, count,
                    [&](int32_t *o, const int32_t *i) { return tfhe_amd_bootstrap_woks(R.ctx, o, mu, i, count); }, "bootstrap_woks (array)");
 }
 inline void lweKeySwitch_array(LweSample *const *results, const LweKeySwitchKey *ks, const LweSample *const *samples, int count) {
     TFHE_AMD_SHIM_GUARD();
+    if (count <= 0) return;
+    if (use_pool()) {  // a key-switch key on its own: a pool of contexts that hold nothing else (gadget unused: l = Bgbit = 1)
+        PoolResident &P = attach_pool((const TGswSampleFFT *)nullptr, ks->out_params->n, ks->n, 1, 1, ks, ks);
+        lwe_array_pool_call(P, results, P.n, samples, P.N, count,
+                            [&](int32_t *o, const int32_t *i) { return tfhe_amd_pool_keyswitch_host(P.pool, o, i, count); }, "keyswitch (array, pool)");
+        return;
+    }
     Resident &R = attach_ks(ks);
     lwe_array_call(R, results, R.n, samples, R.N, count,
                    [&](int32_t *o, const int32_t *i) { return tfhe_amd_keyswitch(R.ctx, o, i, count); }, "keyswitch (array)");
@@ -507,7 +629,7 @@ template <class GlobalsT>
 class PocEngine {
    public:
     explicit PocEngine(const GlobalsT *env, int device = 0)
-        : cb_(nullptr), h_in_(nullptr), h_out_(nullptr), da_in_(nullptr), da_out_(nullptr), arr_in_bytes_(0), arr_out_bytes_(0) {
+        : env_(env), cb_(nullptr), pool_(nullptr), h_in_(nullptr), h_out_(nullptr), da_in_(nullptr), da_out_(nullptr), arr_in_bytes_(0), arr_out_bytes_(0) {
         tfhe_amd_cb_params p;
         p.n0 = env->n_lvl0;
         p.N1 = env->n_lvl1;
@@ -522,33 +644,16 @@ class PocEngine {
         p.bb21 = env->ksbasebit_lvl21;
         p_ = p;
         die(tfhe_amd_cb_create(&p, device, &cb_), "tfhe_amd_cb_create");
-        const int base10 = 1 << p.bb10, base21 = 1 << p.bb21;
-        {  // Globals::preKS -> [N1][t10][base10][n0+1]
-            std::vector<int32_t> f((size_t)p.N1 * p.t10 * base10 * (p.n0 + 1));
-            size_t o = 0;
-            for (int i = 0; i < p.N1; i++)
-                for (int j = 0; j < p.t10; j++)
-                    for (int u = 0; u < base10; u++, o += (size_t)p.n0 + 1)
-                        std::memcpy(&f[o], env->preKS[i][j][u].a, sizeof(int32_t) * (size_t)(p.n0 + 1));
+        {
+            const std::vector<int32_t> f = flat_preks();
             die(tfhe_amd_cb_load_preks(cb_, f.data()), "load preKS");
         }
-        {  // Globals::bkFFT -> [n0][2 l2][2][N2]
-            std::vector<double> f((size_t)p.n0 * 2 * p.l2 * 2 * p.N2);
-            size_t o = 0;
-            for (int i = 0; i < p.n0; i++)
-                for (int r = 0; r < 2 * p.l2; r++)
-                    for (int q = 0; q < 2; q++, o += (size_t)p.N2)
-                        std::memcpy(&f[o], env->bkFFT[i].allsamples[r].a[q].values, sizeof(double) * (size_t)p.N2);
+        {
+            const std::vector<double> f = flat_bkfft();
             die(tfhe_amd_cb_load_bk_fft(cb_, f.data()), "load bkFFT");
         }
-        for (int u = 0; u < 2; u++) {  // Globals::privKS plane u -> [N2+1][t21][base21][2][N1]
-            std::vector<int32_t> f((size_t)(p.N2 + 1) * p.t21 * base21 * 2 * p.N1);
-            size_t o = 0;
-            for (int i = 0; i <= p.N2; i++)
-                for (int j = 0; j < p.t21; j++)
-                    for (int d = 0; d < base21; d++)
-                        for (int q = 0; q < 2; q++, o += (size_t)p.N1)
-                            std::memcpy(&f[o], env->privKS[u][i][j][d].a[q].coefs, sizeof(int32_t) * (size_t)p.N1);
+        for (int u = 0; u < 2; u++) {
+            const std::vector<int32_t> f = flat_privks(u);
             die(tfhe_amd_cb_load_privks_plane(cb_, u, f.data()), "load privKS");
         }
         c2_ = tfhe_amd_cb_ctx_lvl2(cb_);
@@ -558,6 +663,7 @@ class PocEngine {
         check(tfhe_amd_malloc(c2_, &d_b_, big), c2_, "malloc");
     }
     ~PocEngine() {
+        if (pool_) tfhe_amd_cb_pool_destroy(pool_);
         if (cb_) {
             if (h_in_) tfhe_amd_host_free(c2_, h_in_);
             if (h_out_) tfhe_amd_host_free(c2_, h_out_);
@@ -589,6 +695,19 @@ class PocEngine {
         TFHE_AMD_SHIM_GUARD();
         if (count <= 0) return;
         const size_t rin = (size_t)p_.N1 + 1, rout = (size_t)2 * p_.l1 * 2 * p_.N1;
+        if (use_pool()) {  // several devices (set_devices): contiguous slices of the loop over a tfhe_amd_cb_pool
+            ensure_pool();
+            pool_in_.resize(rin * count);
+            pool_out_.resize(rout * count);
+            for (int c = 0; c < count; c++) std::memcpy(&pool_in_[(size_t)c * rin], samples[c]->a, sizeof(int32_t) * rin);
+            const int rc = tfhe_amd_cb_pool_circuit_bootstrap_host(pool_, pool_out_.data(), pool_in_.data(), count);
+            if (rc != TFHE_AMD_OK) {
+                std::fprintf(stderr, "tfhe_amd: circuit_bootstrap (array, pool) failed (%d): %s\n", rc, tfhe_amd_cb_pool_last_error(pool_));
+                std::abort();
+            }
+            scatter_tgsw(results, pool_out_.data(), count);
+            return;
+        }
         array_staging(c2_, h_in_, da_in_, arr_in_bytes_, sizeof(int32_t) * rin * count, h_out_, da_out_, arr_out_bytes_,
                       sizeof(int32_t) * rout * count);
         int32_t *hi = (int32_t *)h_in_;
@@ -596,13 +715,7 @@ class PocEngine {
         check(tfhe_amd_memcpy_h2d(c2_, da_in_, h_in_, sizeof(int32_t) * rin * count), c2_, "h2d");
         die(tfhe_amd_circuit_bootstrap(cb_, (int32_t *)da_out_, (const int32_t *)da_in_, count), "circuit_bootstrap (array)");
         check(tfhe_amd_memcpy_d2h(c2_, h_out_, da_out_, sizeof(int32_t) * rout * count), c2_, "d2h");
-        const int32_t *ho = (const int32_t *)h_out_;
-        for (int c = 0; c < count; c++)
-            for (int u = 0; u < 2; u++)
-                for (int w = 0; w < p_.l1; w++)
-                    for (int q = 0; q < 2; q++)
-                        std::memcpy(results[c]->samples[u][w].a[q].coefs,
-                                    ho + (size_t)c * rout + (((size_t)u * p_.l1 + w) * 2 + q) * p_.N1, sizeof(int32_t) * (size_t)p_.N1);
+        scatter_tgsw(results, (const int32_t *)h_out_, count);
     }
     // circuitBootstrapWoKS(LweSample64* result, Torus64 mu, const int* abar, env)   poc:530-659
     template <class LweSample64T>
@@ -672,9 +785,85 @@ class PocEngine {
             std::abort();
         }
     }
+    template <class TGswSample32T>
+    void scatter_tgsw(TGswSample32T *const *results, const int32_t *ho, int count) {
+        const size_t rout = (size_t)2 * p_.l1 * 2 * p_.N1;
+        for (int c = 0; c < count; c++)
+            for (int u = 0; u < 2; u++)
+                for (int w = 0; w < p_.l1; w++)
+                    for (int q = 0; q < 2; q++)
+                        std::memcpy(results[c]->samples[u][w].a[q].coefs,
+                                    ho + (size_t)c * rout + (((size_t)u * p_.l1 + w) * 2 + q) * p_.N1, sizeof(int32_t) * (size_t)p_.N1);
+    }
+    // Globals::preKS -> [N1][t10][base10][n0+1]
+    std::vector<int32_t> flat_preks() const {
+        const tfhe_amd_cb_params &p = p_;
+        const int base10 = 1 << p.bb10;
+        std::vector<int32_t> f((size_t)p.N1 * p.t10 * base10 * (p.n0 + 1));
+        size_t o = 0;
+        for (int i = 0; i < p.N1; i++)
+            for (int j = 0; j < p.t10; j++)
+                for (int u = 0; u < base10; u++, o += (size_t)p.n0 + 1)
+                    std::memcpy(&f[o], env_->preKS[i][j][u].a, sizeof(int32_t) * (size_t)(p.n0 + 1));
+        return f;
+    }
+    // Globals::bkFFT -> [n0][2 l2][2][N2]
+    std::vector<double> flat_bkfft() const {
+        const tfhe_amd_cb_params &p = p_;
+        std::vector<double> f((size_t)p.n0 * 2 * p.l2 * 2 * p.N2);
+        size_t o = 0;
+        for (int i = 0; i < p.n0; i++)
+            for (int r = 0; r < 2 * p.l2; r++)
+                for (int q = 0; q < 2; q++, o += (size_t)p.N2)
+                    std::memcpy(&f[o], env_->bkFFT[i].allsamples[r].a[q].values, sizeof(double) * (size_t)p.N2);
+        return f;
+    }
+    // Globals::privKS plane u -> [N2+1][t21][base21][2][N1]
+    std::vector<int32_t> flat_privks(int u) const {
+        const tfhe_amd_cb_params &p = p_;
+        const int base21 = 1 << p.bb21;
+        std::vector<int32_t> f((size_t)(p.N2 + 1) * p.t21 * base21 * 2 * p.N1);
+        size_t o = 0;
+        for (int i = 0; i <= p.N2; i++)
+            for (int j = 0; j < p.t21; j++)
+                for (int d = 0; d < base21; d++)
+                    for (int q = 0; q < 2; q++, o += (size_t)p.N1)
+                        std::memcpy(&f[o], env_->privKS[u][i][j][d].a[q].coefs, sizeof(int32_t) * (size_t)p.N1);
+        return f;
+    }
+    // the pool behind the array form: built for the current device list, rebuilt when that list changes
+    void ensure_pool() {
+        if (pool_ && pool_devices_ == device_list()) return;
+        if (pool_) tfhe_amd_cb_pool_destroy(pool_);
+        pool_ = nullptr;
+        pool_devices_ = device_list();
+        auto pdie = [&](int rc, const char *what) {
+            if (rc != TFHE_AMD_OK) {
+                std::fprintf(stderr, "tfhe_amd: %s failed (%d): %s\n", what, rc, pool_ ? tfhe_amd_cb_pool_last_error(pool_) : "");
+                std::abort();
+            }
+        };
+        pdie(tfhe_amd_cb_pool_create(&p_, pool_devices_.data(), (int)pool_devices_.size(), &pool_), "tfhe_amd_cb_pool_create");
+        {
+            const std::vector<int32_t> f = flat_preks();
+            pdie(tfhe_amd_cb_pool_load_preks(pool_, f.data()), "pool: load preKS");
+        }
+        {
+            const std::vector<double> f = flat_bkfft();
+            pdie(tfhe_amd_cb_pool_load_bk_fft(pool_, f.data()), "pool: load bkFFT");
+        }
+        for (int u = 0; u < 2; u++) {
+            const std::vector<int32_t> f = flat_privks(u);
+            pdie(tfhe_amd_cb_pool_load_privks_plane(pool_, u, f.data()), "pool: load privKS");
+        }
+    }
     PocEngine(const PocEngine &);
     PocEngine &operator=(const PocEngine &);
+    const GlobalsT *env_;
     tfhe_amd_cb *cb_;
+    tfhe_amd_cb_pool *pool_;
+    std::vector<int> pool_devices_;
+    std::vector<int32_t> pool_in_, pool_out_;
     tfhe_amd_cb_params p_;
     tfhe_amd_ctx *c2_, *c10_;
     void *d_a_, *d_b_;

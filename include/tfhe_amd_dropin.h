@@ -51,6 +51,11 @@ void lweKeySwitch_array(LweSample *const *results, const LweKeySwitchKey *ks, co
 void tfhe_amd_dropin_release(const void *key_object);
 /* GPU ordinal used by engines created from now on (default 0) */
 void tfhe_amd_dropin_set_device(int device);
+/* several GPUs: with n > 1 the ARRAY forms cut the caller's loop into contiguous slices over the named devices (one
+ * context, host thread and pinned staging buffer per device, the caller's key uploaded once to each: tfhe_amd_pool in
+ * tfhe_amd.h) -- the reference's `#pragma omp parallel for` over independent items
+ * (parallel/src/test_parallel_multiplications.cpp:62) with GPUs as the workers; one-sample calls stay on devices[0] */
+void tfhe_amd_dropin_set_devices(const int *devices, int n);
 }
 #else  /* TFHE_AMD_DROPIN_POC: poc_types.h has been included */
 void preKeySwitch(LweSample32 *result, const LweSample32 *x, const Globals *env);
@@ -63,5 +68,8 @@ void tfhe_CircuitBootstrapFFT_array(TGswSample32 *const *results, const LweSampl
 /* the reference declares CMux and leaves its body empty (poc:877-879): out = c ? in1 : in0 */
 void CMux(TLweSample32 *out, const TGswSample32 *c, const TLweSample32 *in0, const TLweSample32 *in1, const Globals *env);
 void tfhe_amd_dropin_release(const Globals *env);
+/* several GPUs behind tfhe_CircuitBootstrapFFT_array (see the library form above); defined by dropin_poc.cpp too, so that a
+ * PoC build needs no other object */
+void tfhe_amd_dropin_poc_set_devices(const int *devices, int n);
 #endif
 #endif

@@ -28,6 +28,18 @@
 using namespace tfhe_amd_compat;
 #endif
 
+// TFHE_COMPAT_DEVICES="1,4,6": the array forms are ALSO run over a pool of these devices (set_devices / tfhe_amd_dropin_set_devices)
+static std::vector<int> env_devices() {
+    std::vector<int> d;
+    const char *e = getenv("TFHE_COMPAT_DEVICES");
+    if (!e) return d;
+    for (const char *p = e; *p;) {
+        d.push_back(atoi(p));
+        while (*p && *p != ',') p++;
+        if (*p == ',') p++;
+    }
+    return d;
+}
 static std::vector<uint8_t> slurp(const char *path) {
     FILE *f = fopen(path, "rb");
     if (!f) { perror(path); exit(2); }
@@ -307,6 +319,50 @@ static int run_arr(const char *inp, const char *outp) {
         for (auto &th : pool) th.join();
     }
     bool same = a_arr == a_loop && a_ks == a_loop;
+    // the array forms over SEVERAL devices: the same loop cut into contiguous slices, one pool member per device
+    const std::vector<int> devs = env_devices();
+    bool pool_same = true;
+    double t_pool = 0;
+    if (devs.size() > 1) {
+        std::vector<Torus32> p_arr((size_t)count * n), p_woks((size_t)count * N), p_ks((size_t)count * n);
+        std::vector<LweSample> pa((size_t)count), pu((size_t)count), pk((size_t)count);
+        std::vector<LweSample *> pap((size_t)count), pup((size_t)count), pkp((size_t)count);
+        std::vector<const LweSample *> puc((size_t)count);
+        for (int c = 0; c < count; c++) {
+            pa[c] = LweSample{p_arr.data() + (size_t)c * n, 0, 0};
+            pu[c] = LweSample{p_woks.data() + (size_t)c * N, 0, 0};
+            pk[c] = LweSample{p_ks.data() + (size_t)c * n, 0, 0};
+            pap[c] = &pa[c];
+            pup[c] = &pu[c];
+            puc[c] = &pu[c];
+            pkp[c] = &pk[c];
+        }
+#ifdef DROPIN
+        tfhe_amd_dropin_set_devices(devs.data(), (int)devs.size());
+#else
+        set_devices(devs.data(), (int)devs.size());
+#endif
+        tfhe_bootstrap_FFT_array(nullptr, &bk, mu, nullptr, 0);
+        tfhe_bootstrap_FFT_array(pap.data(), &bk, mu, xp.data(), count);  // builds the pool: one key upload per device
+        const double tp = now_s();
+        tfhe_bootstrap_FFT_array(pap.data(), &bk, mu, xp.data(), count);
+        t_pool = now_s() - tp;
+        tfhe_bootstrap_woKS_FFT_array(pup.data(), &bk, mu, xp.data(), count);
+        lweKeySwitch_array(pkp.data(), &ksk, puc.data(), count);
+        pool_same = p_arr == a_loop && p_ks == a_loop && p_woks == a_woks;
+        for (int c = 0; c < count; c++) pool_same = pool_same && pa[c].b == rl[c].b && pk[c].b == rl[c].b && pu[c].b == ru[c].b;
+        // a one-sample call still works (on devices[0]) while several devices are named
+        LweSample one{a_thr.data(), 0, 0};
+        tfhe_bootstrap_FFT(&one, &bk, mu, &x[0]);
+        pool_same = pool_same && one.b == rl[0].b && memcmp(one.a, rl[0].a, 4 * (size_t)n) == 0;
+        const int zero = 0;
+#ifdef DROPIN
+        tfhe_amd_dropin_set_devices(&zero, 1);
+#else
+        set_devices(&zero, 1);
+#endif
+        same = same && pool_same;
+    }
     for (int c = 0; c < tcount; c++)
         same = same && rt[c].b == rl[c].b && memcmp(rt[c].a, rl[c].a, 4 * (size_t)n) == 0;
     for (int c = 0; c < count; c++) same = same && ra[c].b == rl[c].b && rk[c].b == rl[c].b;
@@ -317,8 +373,10 @@ static int run_arr(const char *inp, const char *outp) {
     }
     out.save(outp);
     printf("{\"count\": %d, \"array_seconds\": %.6f, \"array_bootstraps_per_s\": %.1f, \"loop_seconds\": %.6f, "
-           "\"loop_bootstraps_per_s\": %.1f, \"array_identical_to_loop\": %s}\n",
-           count, t_arr, count / t_arr, t_loop, count / t_loop, same ? "true" : "false");
+           "\"loop_bootstraps_per_s\": %.1f, \"array_identical_to_loop\": %s, \"pool_devices\": %d, \"pool_seconds\": %.6f, "
+           "\"pool_identical_to_loop\": %s}\n",
+           count, t_arr, count / t_arr, t_loop, count / t_loop, same ? "true" : "false", (int)devs.size(), t_pool,
+           devs.size() > 1 ? (pool_same ? "true" : "false") : "null");
 #ifdef DROPIN
     tfhe_amd_dropin_release(nullptr);
 #else
@@ -391,6 +449,7 @@ static int run_poc(const char *inp, const char *outp) {
 
     PocEngine<PGlobals> eng(&g);
     Out out;
+    std::vector<int32_t> all_res;  // the one-sample tfhe_CircuitBootstrapFFT results, for the array form below
     for (int c = 0; c < count; c++) {
         PLwe32 x{(int32_t *)xs + (size_t)c * (N1 + 1), nullptr};
         // preKeySwitch + preModSwitch
@@ -423,6 +482,7 @@ static int run_poc(const char *inp, const char *outp) {
         PTGsw32 tg{rs.data(), rr.data()};
         eng.tfhe_CircuitBootstrapFFT(&tg, &x);
         out.put(res.data(), 4 * res.size());
+        all_res.insert(all_res.end(), res.begin(), res.end());
         // CMux (stub at poc:877-879) with the circuit bootstrap's TGSW32 output as the selector and
         // two of its own TLWE rows as data
         std::vector<int32_t> mx((size_t)2 * N1);
@@ -432,7 +492,38 @@ static int run_poc(const char *inp, const char *outp) {
         out.put(mx.data(), 4 * mx.size());
     }
     out.save(outp);
-    return 0;
+    // the driver loop as ONE call (tfhe_CircuitBootstrapFFT_array), on one device and -- with TFHE_COMPAT_DEVICES -- over a pool
+    const size_t rout = (size_t)2 * l1 * 2 * N1;
+    std::vector<int32_t> arr_res(rout * count);
+    std::vector<PPoly32> ap((size_t)count * 2 * l1 * 2);
+    std::vector<PTLwe32> ar((size_t)count * 2 * l1);
+    std::vector<PTLwe32 *> as((size_t)count * 2);
+    std::vector<PTGsw32> ag((size_t)count);
+    std::vector<PTGsw32 *> agp((size_t)count);
+    std::vector<PLwe32> ax((size_t)count);
+    std::vector<const PLwe32 *> axp((size_t)count);
+    for (size_t e = 0; e < ap.size(); e++) ap[e].coefs = arr_res.data() + e * N1;
+    for (size_t e = 0; e < ar.size(); e++) { ar[e].a = &ap[e * 2]; ar[e].b = ar[e].a + 1; }
+    for (size_t e = 0; e < as.size(); e++) as[e] = &ar[e * l1];
+    for (int c = 0; c < count; c++) {
+        ag[c] = PTGsw32{&as[(size_t)c * 2], &ar[(size_t)c * 2 * l1]};
+        agp[c] = &ag[c];
+        ax[c] = PLwe32{(int32_t *)xs + (size_t)c * (N1 + 1), nullptr};
+        axp[c] = &ax[c];
+    }
+    eng.tfhe_CircuitBootstrapFFT_array(agp.data(), axp.data(), count);
+    bool same = arr_res == all_res;
+    const std::vector<int> devs = env_devices();
+    if (devs.size() > 1) {
+        std::fill(arr_res.begin(), arr_res.end(), 0);
+        set_devices(devs.data(), (int)devs.size());
+        eng.tfhe_CircuitBootstrapFFT_array(agp.data(), axp.data(), count);
+        const int zero = 0;
+        set_devices(&zero, 1);
+        same = same && arr_res == all_res;
+    }
+    printf("{\"count\": %d, \"array_identical_to_loop\": %s, \"pool_devices\": %d}\n", count, same ? "true" : "false", (int)devs.size());
+    return same ? 0 : 3;
 }
 
 #endif

@@ -90,8 +90,13 @@ def run_lib_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=
     assert pos == len(raw)
 
 
+def _env(devices):
+    """TFHE_COMPAT_DEVICES for the driver: the array forms then ALSO run over a pool of these devices (exit 3 if they differ)"""
+    return dict(os.environ, TFHE_COMPAT_DEVICES=devices) if devices else None
+
+
 def run_poc_form(driver, tmp_path, n0=3, N1=1024, N2=1024, l1=2, bg1=8, l2=3, bg2=10, t10=3, bb10=2, t21=2, bb21=2,
-                 count=2, phase="both"):
+                 count=2, phase="both", devices=None):
     rs = np.random.RandomState(8)
     key0, key2 = O.keygen_binary(n0, SEED, 21), O.keygen_binary(N2, SEED, 23)
     bk = O.bk_create64(N2, key0, key2, l2, bg2, 2.0 ** -44, SEED, 3000)
@@ -107,7 +112,7 @@ def run_poc_form(driver, tmp_path, n0=3, N1=1024, N2=1024, l1=2, bg1=8, l2=3, bg
                 f.write(np.ascontiguousarray(a).tobytes())
         if phase == "write":  # inputs only (tests/test_dropin.py runs its own driver on them)
             return
-        subprocess.check_call([driver, "poc", fi, fo])
+        subprocess.check_call([driver, "poc", fi, fo], env=_env(devices), stdout=subprocess.DEVNULL)
         if phase == "run":
             return
     raw = open(fo, "rb").read()
@@ -134,7 +139,7 @@ def run_poc_form(driver, tmp_path, n0=3, N1=1024, N2=1024, l1=2, bg1=8, l2=3, bg
     assert pos == len(raw)
 
 
-def run_array_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=6, phase="both", inputs=None):
+def run_array_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=6, phase="both", inputs=None, devices=None):
     """`compat_driver arr`: the array forms behind the reference names (tfhe_bootstrap_FFT_array, tfhe_bootstrap_woKS_FFT_array
     + lweKeySwitch_array) against the driver's own one-by-one loop (exit code 3 if they differ) and against the oracle.
     inputs: (bk, ks, x) to use instead of the generated ones (the GPU leg shares test_ref_batch's full-size set)."""
@@ -154,7 +159,7 @@ def run_array_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, coun
         with open(fi, "wb") as f:
             for a in (hdr, bk, ks, x):
                 f.write(np.ascontiguousarray(a).tobytes())
-        res = subprocess.run([driver, "arr", fi, fo], stdout=subprocess.PIPE, text=True)
+        res = subprocess.run([driver, "arr", fi, fo], stdout=subprocess.PIPE, text=True, env=_env(devices))
         os.remove(fi)
         with open(fs, "w") as f:
             f.write(res.stdout)
@@ -172,6 +177,22 @@ def test_array_forms_emu(emu_lib, tmp_path):
     stats, got, (bk, ks, x) = run_array_form(build_driver(emu_lib, "emu"), tmp_path)
     want = np.stack([O.bootstrap32(1024, bk, ks, 1 << 29, x[c], 2, 10, 8, 2) for c in range(x.shape[0])])
     assert np.array_equal(got, want), "tfhe_bootstrap_FFT_array"
+
+
+def test_array_forms_over_a_pool_emu(emu_lib, tmp_path):
+    """set_devices({1, 4, 6}): the three array forms cut the driver's loop of 7 samples into 3 + 2 + 2 over a pool of three
+    emulated devices (one upload of the driver's key per device); identical to the one-by-one loop on one device.  The
+    emulator aborts on any operand used from another device than its owner's."""
+    stats, got, (bk, ks, x) = run_array_form(build_driver(emu_lib, "emu"), tmp_path, count=7, devices="1,4,6")
+    assert stats["pool_devices"] == 3 and stats["pool_identical_to_loop"] is True
+    want = np.stack([O.bootstrap32(1024, bk, ks, 1 << 29, x[c], 2, 10, 8, 2) for c in range(x.shape[0])])
+    assert np.array_equal(got, want)
+
+
+def test_poc_array_form_over_a_pool_emu(emu_lib, tmp_path):
+    """PocEngine::tfhe_CircuitBootstrapFFT_array on one device and over a tfhe_amd_cb_pool of devices {2, 5}: both identical
+    to the one-sample calls (the driver exits 3 otherwise), which run_poc_form compares with the oracle"""
+    run_poc_form(build_driver(emu_lib, "emu"), tmp_path, count=3, devices="2,5")
 
 
 def test_library_form_shims_emu(emu_lib, tmp_path):
@@ -200,7 +221,7 @@ def prerun_gpu_drivers():
         for f in ("in.bin", "out.bin"):
             if os.path.exists(os.path.join(d, f)):
                 os.remove(os.path.join(d, f))
-        fn(drv, d, phase="run", **args)
+        fn(drv, d, phase="run", **args, **({"devices": "0,0"} if form == "poc" else {}))  # poc: + the array form over a 2-member pool on device 0
     # array forms at BASELINE config 2's size: 4096 gate bootstraps (n = 630) through tfhe_bootstrap_FFT_array, the same
     # 4096 one by one through tfhe_bootstrap_FFT; inputs = test_ref_batch's (whose reference outputs the test compares with)
     import test_ref_batch as RB
@@ -209,7 +230,7 @@ def prerun_gpu_drivers():
     for f in os.listdir(d):
         os.remove(os.path.join(d, f))
     lk, bk, ks, x = RB._inputs()
-    run_array_form(drv, d, n=RB.n, inputs=(bk, ks, x), phase="run")
+    run_array_form(drv, d, n=RB.n, inputs=(bk, ks, x), phase="run", devices="0,0")  # + over a pool of two members, both on device 0
 
 
 def _need(form):
@@ -249,6 +270,8 @@ def test_array_forms_gpu():
             assert np.array_equal(got[c], O.bootstrap32(RB.N, bk, ks, RB.MU, x[c], RB.l, RB.Bgbit, RB.t, RB.bb)), c
     assert stats["array_bootstraps_per_s"] >= 100e3, stats
     assert stats["array_bootstraps_per_s"] > 50 * stats["loop_bootstraps_per_s"], stats
+    # the same loop over a pool of two members sharing the one GPU (two host threads, two streams, two key copies): identical
+    assert stats["pool_devices"] == 2 and stats["pool_identical_to_loop"] is True, stats
 
 
 def _need_arr():
