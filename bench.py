@@ -24,11 +24,20 @@ switch 8x2 bits).  Workload by flags:
                       with the world size --gpus names -- also 1
 value = all ranks' bootstraps / max-over-ranks time.
 
-After the timed region of a one-GPU run (never inside `value`; --headline-only skips them, which is what the
+Beside the timed region of a one-GPU run (never inside `value`; --headline-only skips them, which is what the
 rocprofv3 scripts under tools/ pass so that the default command's kernel table holds the headline kernels only):
+  config3_circuit_bootstrap, config4_transforms   BASELINE configs 3 and 4 as tools/bench_configs.py measures them
+                      (--other-configs), in a CHILD process that runs and exits BEFORE this process touches the GPU: a fault
+                      there costs its own section, never the headline.  Config 3's timed outputs are bit-compared with the oracle.
   config1_latency     BASELINE config 1: one gate bootstrap per call (and 8) through tfhe_amd_bootstrap, HIP events
   streamed_schedule   BASELINE config 2's literal schedule: one external-product launch per CMux step
-  config3_circuit_bootstrap, config4_transforms   BASELINE configs 3 and 4 as tools/bench_configs.py measures them (--other-configs)
+  sustained           >= --sustained-seconds (10) of back-to-back steps after the timed region: bootstraps/s, min / max step
+                      time, and the shader clock the chip held beside one of those steps (tfhe_amd_clock_probe)
+  pool_check          the same batch through tfhe_amd_pool_bootstrap_host (host arrays in, host arrays out, PCIe included): a
+                      pool of one member and of two members sharing this GPU, keys uploaded from HOST arrays
+The `ranks` table carries every rank's PCI bus id; `n_devices` = distinct GPUs.  Under RCCL a run whose ranks do not sit
+on --gpus distinct GPUs exits non-zero.  --broadcast-keys: only rank 0 builds the keys, the others receive the bytes of the
+device layout by torch.distributed broadcast (RCCL) instead of regenerating them from the seed.
 
 The ONE JSON line on stdout is kept compact (~3 KB: a few numbers per section); the full record -- every note, stage and
 per-transform line described below -- is written to gpurun_out/bench_detail_<n>gpu.json (--detail PATH), named by the line's
@@ -157,35 +166,55 @@ def oracle_rows(B):
     return list(range(n, min(n + 8, B)))
 
 
-def other_configs(T, a):
+def other_configs_child(a):
     """config3_circuit_bootstrap / config4_transforms of the bench line: tools/bench_configs.py's own measurements (HIP events
-    through the C ABI, synthetic keys), run after the timed region; their per-line prints are dropped (stderr stays quiet: the driver keeps a tail of it)"""
-    import contextlib
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    out = {}
+    through the C ABI, synthetic keys; config 3's timed outputs bit-compared with the oracle), run as a CHILD process that exits
+    before this process touches the GPU -- a GPU fault, a hang (timeout) or an exception there costs that section only."""
+    import tempfile
+    want = [w.strip() for w in a.other_configs.split(",") if w.strip() in ("3", "4")]
+    if not want:
+        return {}
+    fd, path = tempfile.mkstemp(prefix="tfhe_bench_configs_", suffix=".json")
+    os.close(fd)
+    small = a.lwe_n is not None  # the test hook of the CPU emulator runs: tiny sizes
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_configs.py")] + [{"3": "cb", "4": "fft"}[w] for w in want] + [
+        "--json-out", path, "--reps", str(min(3, max(1, a.extras_reps))), "--cb-batch", "1024", "--batch", "8192"]
+    if small:
+        cmd.append("--small")
+    if a.lib:
+        cmd += ["--lib", a.lib]
+    out, note = {}, None
     try:
-        BC = importlib.import_module("bench_configs")
-        small = a.lwe_n is not None  # the test hook of the CPU emulator runs: tiny sizes
-        ns = argparse.Namespace(small=small, lib=a.lib, reps=min(3, max(1, a.extras_reps)), cb_batch=1024, batch=8192)
-        want = {w.strip() for w in a.other_configs.split(",") if w.strip()}
-        import io
-        with contextlib.redirect_stdout(io.StringIO()):  # their per-line prints: dropped (the lines are returned, and kept in the detail file)
-            if "3" in want:
-                try:
-                    cb, lut = BC.bench_cb(T, ns)
-                    out["config3_circuit_bootstrap"] = dict(cb, baseline_config="BASELINE config 3 (circuit bootstrap TLWE -> TRGSW at "
-                                                            "the PoC parameters, batch 1024)", lut_evaluation=lut)
-                except Exception as e:  # noqa: BLE001 -- reported on the line, the headline stands
-                    out["config3_circuit_bootstrap"] = {"error": repr(e)}
-            if "4" in want:
-                try:
-                    lines = BC.bench_fft(T, ns)
-                    out["config4_transforms"] = {"baseline_config": "BASELINE config 4 (batched anticyclic transforms, N = 2048 batch 8192 and "
-                                                 "4 x that; N = 1024 beside it)", "lines": lines}
-                except Exception as e:  # noqa: BLE001
-                    out["config4_transforms"] = {"error": repr(e)}
-    except Exception as e:  # noqa: BLE001
-        out["other_configs_error"] = repr(e)
+        res = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=a.other_configs_timeout)
+        if res.returncode:
+            note = f"child exit {res.returncode}: {res.stderr[-300:]}"
+    except subprocess.TimeoutExpired:
+        note = f"child killed after {a.other_configs_timeout} s"
+    try:
+        with open(path) as f:
+            got = json.load(f)
+    except (OSError, ValueError):
+        got = {}
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    if "3" in want:
+        sec = got.get("cb")
+        if isinstance(sec, list) and len(sec) == 2:
+            out["config3_circuit_bootstrap"] = dict(sec[0], baseline_config="BASELINE config 3 (circuit bootstrap TLWE -> TRGSW at "
+                                                    "the PoC parameters, batch 1024)", lut_evaluation=sec[1])
+        else:
+            out["config3_circuit_bootstrap"] = {"error": (sec or {}).get("error") if isinstance(sec, dict) else (note or "no result")}
+    if "4" in want:
+        sec = got.get("fft")
+        if isinstance(sec, list):
+            out["config4_transforms"] = {"baseline_config": "BASELINE config 4 (batched anticyclic transforms, N = 2048 batch 8192 and "
+                                         "4 x that; N = 1024 beside it)", "lines": sec}
+        else:
+            out["config4_transforms"] = {"error": (sec or {}).get("error") if isinstance(sec, dict) else (note or "no result")}
+    out["other_configs_run"] = "child process before this process touched the GPU" + (f" ({note})" if note else "")
     return out
 
 
@@ -203,16 +232,18 @@ def write_detail(line, a):
 
 
 def compact_line(full, detail_path):
-    """The ONE JSON line on stdout, kept to ~3 KB: whoever stores only a tail of a run's stdout must still hold the whole line.
-    Contract keys first, with `roofline` and `cpu_baseline` in the contract's shape; the other BASELINE configs measured after the
-    timed region as a few numbers each, at the END of the line; every note, stage and per-transform line is in the detail file."""
+    """The ONE JSON line on stdout, kept to ~3.5 KB: whoever stores only a tail of a run's stdout must still hold the whole line.
+    Contract keys first, with `roofline` and `cpu_baseline` in the contract's shape; the other BASELINE configs and the
+    sections measured after the timed region as a few numbers each, at the END of the line; every note, stage and per-transform
+    line is in the detail file.  Each trailing section is built on its own: a missing key there yields {"error": ...} for that
+    section and never costs the headline."""
     r = full["roofline"]
     c = full["config"]
     out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data")}
     out["config"] = {"workload": c["workload"].split(", persistent")[0] + "; persistent kernel, inputs resident in HBM",
                      "batch_per_gpu": c["batch_per_gpu"], "total_per_step": c["total_per_step"],
-                     "parallelism": f"batch-sharded x{full['n_gpus']}, keys replicated, no data-path collective",
+                     "parallelism": f"batch-sharded x{full['n_gpus']}, keys replicated ({c['key_replication']}), no data-path collective",
                      "process_group": c["process_group"], "library": c["library"]}
     if "launched_by" in c:
         out["config"]["launched_by"] = "bench.py GPU-free parent -> torch.distributed.run child"
@@ -227,44 +258,72 @@ def compact_line(full, detail_path):
                                "sample": b["sample"].split(" composed from")[0] + (" (reference FMA assembly + key switch)" if b["kind"] == "reference" else ""),
                                "per_core_value": b.get("per_core_value"), "measured_by": (b.get("measured_by") or "").split(":")[0].split(" (")[0]}
     out["ranks_seen"] = full["ranks_seen"]
+    out["n_devices"] = full["n_devices"]
+    out["pci"] = full["ranks"][0].get("pci")
     if full["n_gpus"] > 1:
-        out["ranks"] = [[x["rank"], x["device"], x["batch"], round(x["seconds"], 4)] for x in full["ranks"]]  # rank, device, batch, s
+        out["ranks"] = [[x["rank"], x["device"], x["batch"], round(x["seconds"], 4), x.get("pci")] for x in full["ranks"]]  # rank, device, batch, s, PCI bus id
     out["kernels_ms"] = {k: round(v, 4) for k, v in full["kernels_ms"].items()}
     out["checks"] = {"decrypt": full["decrypt_check"],
                      "oracle_bit_identical": None if full["oracle_bit_check"] is None else full["oracle_bit_check"]["identical"],
                      "tail_identical_to_front": None if full["tail_check"] is None else full["tail_check"]["identical_to_front"]}
-    lat = full.get("config1_latency")
-    if lat:
-        out["config1_latency"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in lat.items()
-                                  if k.startswith("latency_batch") and not k.endswith("_wall_ms")}
-        out["config1_latency"]["identical_to_headline"] = all(v for k, v in lat.items() if k.endswith("identical_to_headline_outputs"))
-    st = full.get("streamed_schedule")
-    if st:
-        out["config2_streamed"] = {"bootstraps_per_s": round(st["value"], 1), "launches": st["launches"],
-                                   "extprod_launch_us": round(st["extprod_launch_us"], 3), "hbm_frac": round(st["roofline"]["frac"], 4),
-                                   "identical_to_persistent": st["identical_to_persistent"],
-                                   "hipgraph_bootstraps_per_s": (round(st["hipgraph"]["value"], 1) if "value" in st.get("hipgraph", {}) else None)}
-    c3 = full.get("config3_circuit_bootstrap")
-    if c3:
-        if "error" in c3:
-            out["config3_circuit_bootstrap"] = {"error": c3["error"][:200]}
-        else:
-            br = c3.get("blind_rotation_roofline", {})
-            out["config3_circuit_bootstrap"] = {"circuit_bootstraps_per_s": round(c3["circuit_bootstraps_per_s"], 1), "ms_per_batch": round(c3["ms_min"], 3),
-                                                "blind_rotation_ms": round(c3["stages_ms"]["circuitBootstrapWoKS (one of l1)"], 3),
-                                                "blind_rotation_flops_frac": (round(br["fp64_valu_frac"], 4) if "fp64_valu_frac" in br else None),
-                                                "lut_evaluations_per_s": round(c3["lut_evaluation"]["lut_evaluations_per_s"], 1)}
-    c4 = full.get("config4_transforms")
-    if c4:
-        if "error" in c4:
-            out["config4_transforms"] = {"error": c4["error"][:200]}
-        else:  # HBM fraction (algorithmic bytes / time / 8 TB/s) per conversion, in the order rev_int, rev_t64, dir_t64, dir_t32
-            grp = {}
-            for ln in c4["lines"]:
-                if "roofline" in ln:
-                    w = ln["workload"].split()
-                    grp.setdefault(w[1] + " " + w[2], []).append(round(ln["roofline"]["frac"], 3))
-            out["config4_transforms"] = {"hbm_frac [reverse_int, reverse_torus64, direct_torus64, direct_torus32]": grp}
+
+    def section(name, src, build):
+        v = full.get(src)
+        if not v:
+            return
+        try:
+            out[name] = {"error": str(v["error"])[:200]} if "error" in v else build(v)
+        except (KeyError, TypeError, IndexError, ValueError) as e:
+            out[name] = {"error": "compact form: " + repr(e)[:160]}
+
+    def b_latency(lat):
+        d = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in lat.items() if k.startswith("latency_batch") and not k.endswith("_wall_ms")}
+        d["identical_to_headline"] = all(v for k, v in lat.items() if k.endswith("identical_to_headline_outputs"))
+        return d
+
+    def b_streamed(st):
+        return {"bootstraps_per_s": round(st["value"], 1), "launches": st["launches"], "extprod_launch_us": round(st["extprod_launch_us"], 3),
+                "hbm_frac": round(st["roofline"]["frac"], 4), "identical_to_persistent": st["identical_to_persistent"],
+                "hipgraph_bootstraps_per_s": (round(st["hipgraph"]["value"], 1) if "value" in st.get("hipgraph", {}) else None)}
+
+    def b_sustained(su):
+        clk = su.get("shader_clock_ghz") or {}
+        return {"seconds": round(su["seconds"], 2), "steps": su["steps"], "bootstraps_per_s": round(su["value"], 1),
+                "step_ms_min": round(su["step_ms_min"], 3), "step_ms_max": round(su["step_ms_max"], 3),
+                "over_timed_region": round(su["value"] / full["value"] * full["n_gpus"], 4) if full["value"] else None,
+                "shader_clock_ghz": (round(clk["median"], 3) if "median" in clk else None)}
+
+    def b_pool(pc):
+        return {"members": [[m["devices"], round(m["bootstraps_per_s"], 1)] for m in pc["pools"]], "pcie_included": True,
+                "identical_to_headline": all(m["identical_to_headline"] for m in pc["pools"])}
+
+    def b_c3(c3):
+        br = c3.get("blind_rotation_roofline", {})
+        return {"circuit_bootstraps_per_s": round(c3["circuit_bootstraps_per_s"], 1), "ms_per_batch": round(c3["ms_min"], 3),
+                "oracle_bit_identical": c3.get("oracle_bit_identical"),
+                "blind_rotation_ms": round(c3["stages_ms"]["circuitBootstrapWoKS (one of l1)"], 3),
+                "blind_rotation_flops_frac": (round(br["fp64_valu_frac"], 4) if "fp64_valu_frac" in br else None),
+                "lut_evaluations_per_s": round(c3["lut_evaluation"]["lut_evaluations_per_s"], 1)}
+
+    def b_c4(c4):  # HBM fraction (algorithmic bytes / time / 8 TB/s) per conversion, in the order rev_int, rev_t64, dir_t64, dir_t32
+        grp = {}
+        for ln in c4["lines"]:
+            if "roofline" in ln:
+                w = ln["workload"].split()
+                grp.setdefault(w[1] + " " + w[2], []).append(round(ln["roofline"]["frac"], 3))
+            elif "hbm" in ln:  # the Real96 transforms
+                w = ln["workload"].split()
+                grp.setdefault("Real96 " + w[2] + " " + w[3], []).append(round(ln["hbm"]["frac"], 3))
+        return {"hbm_frac [reverse_int, reverse_torus64, direct_torus64, direct_torus32 | Real96: iFFT, FFT]": grp}
+
+    section("sustained", "sustained", b_sustained)
+    section("config1_latency", "config1_latency", b_latency)
+    section("config2_streamed", "streamed_schedule", b_streamed)
+    section("config3_circuit_bootstrap", "config3_circuit_bootstrap", b_c3)
+    section("config4_transforms", "config4_transforms", b_c4)
+    section("pool_check", "pool_check", b_pool)
+    if "key_broadcast" in full:
+        out["key_broadcast"] = full["key_broadcast"]
     if "pipelined_two_contexts" in full:
         out["pipelined_two_contexts"] = {"value": round(full["pipelined_two_contexts"]["value"], 1)}
     out["detail"] = detail_path
@@ -283,7 +342,7 @@ def launch_ranks(a, argv, shard, cfg):
         hand["cpu_baseline"] = cpu_baseline(cfg, a.cpu_seconds)
         B0 = workload(a, shard, 0, a.gpus)[0]
         idx = oracle_rows(B0)
-        if idx and a.lib is None:
+        if idx and (a.lib is None or a.lwe_n is not None):
             x0 = shard.synthetic_samples(cfg, B0, seed=1234)  # rank 0's inputs
             hand["oracle_idx"] = idx
             hand["oracle_want"] = oracle_answers(cfg, [x0[i] for i in idx]).tolist()
@@ -313,6 +372,8 @@ def launch_ranks(a, argv, shard, cfg):
     d = json.loads(lines[0])
     if d.get("n_gpus") != a.gpus or d.get("ranks_seen") != a.gpus:
         raise SystemExit(f"bench.py: asked for {a.gpus} ranks, the line reports n_gpus={d.get('n_gpus')} ranks_seen={d.get('ranks_seen')}")
+    if a.backend == "nccl" and d.get("n_devices") != a.gpus:
+        raise SystemExit(f"bench.py: {a.gpus} ranks on {d.get('n_devices')} distinct GPUs")
     d["config"]["launched_by"] = "bench.py GPU-free parent -> python -m torch.distributed.run --nproc-per-node %d" % a.gpus
     print(json.dumps(d), flush=True)
 
@@ -364,6 +425,19 @@ def main():
     ap.add_argument("--detail", default=None,
                     help="where the FULL record (all notes, stages, per-transform lines) is written as a file; default: "
                          "gpurun_out/bench_detail_<n>gpu.json under the repository.  stdout carries the compact line only")
+    ap.add_argument("--other-configs-timeout", type=int, default=900, help="seconds the child process measuring configs 3 and 4 may take")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0,
+                    help="after the timed region: at least this many seconds of back-to-back steps (bootstraps/s, min / max step time, "
+                         "shader clock beside one of the steps); 0 = skip.  Never part of `value`; --headline-only skips it too")
+    ap.add_argument("--pool-check", action="store_true",
+                    help="also under --headline-only / several ranks: the batch through tfhe_amd_pool_bootstrap_host (host arrays, PCIe "
+                         "included) on a pool of one member and of two members sharing this rank's GPU; a default one-GPU run does it anyway")
+    ap.add_argument("--pool-devices", default=None,
+                    help="device ordinals of ONE more pool to check, e.g. 0,1,2,3 or 'all' (every device this process sees): one process "
+                         "driving several GPUs")
+    ap.add_argument("--broadcast-keys", action="store_true",
+                    help="multi-rank path: only rank 0 builds the keys; one torch.distributed broadcast per key (RCCL under nccl) hands the "
+                         "other ranks the bytes of the device layout (SURVEY 8e) instead of every rank regenerating them from the seed")
     ap.add_argument("--pipelined", action="store_true",
                     help="also time (after the timed region, one GPU) the same K steps issued alternately on two contexts / "
                          "streams: consecutive batches are independent, the next blind rotation fills the CUs the current "
@@ -417,11 +491,16 @@ def main():
         baseline_by = "rank 0, before torch and the engine were loaded (the other ranks wait in init_process_group)"
         # the checker's answers for a few of the timed inputs, computed NOW (before the GPU is touched);
         # compared bit for bit with the GPU's outputs after the timed region
-        if oracle_idx and a.lib is None:
+        if oracle_idx and (a.lib is None or a.lwe_n is not None):  # (an A/B build at full size: skipped, the A/B tools compare outputs themselves)
             oracle_want = oracle_answers(cfg, [x_host[i] for i in oracle_idx])
 
+    # BASELINE configs 3 and 4 (the other workloads one GPU can run): a child process, now -- before this process touches the GPU
+    other = None
+    if world == 1 and not a.headline_only and a.other_configs.strip():
+        other = other_configs_child(a)
+
     dist, dev, torch = None, None, None
-    device = 0  # gloo (CPU tests on the emulator build): one emulated device for every rank
+    device = 0
     if use_dist:
         import torch  # BEFORE the engine library: one HIP runtime in the process
         import torch.distributed as dist
@@ -437,7 +516,10 @@ def main():
             torch.cuda.set_device(device)
             dev = torch.device("cuda", device)
         else:
+            # gloo: the collectives run on CPU tensors, the engine on whichever devices its library shows (the CPU emulator
+            # of the tests: TFHE_EMU_DEVICES; a GPU box: its GPUs) -- rank r on device r while they last
             dev = torch.device("cpu")
+            device = local % max(1, T.device_count(a.lib))
         # RCCL prints a version banner on STDOUT when its communicator is created (at the first collective); stdout
         # of this program is the one JSON line, so file descriptor 1 points at stderr until that has happened
         sys.stdout.flush()
@@ -463,11 +545,18 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
+    if a.broadcast_keys and dist is None:
+        raise SystemExit("bench.py: --broadcast-keys needs the multi-rank path (--gpus N > 1, or --dist for a world of one)")
+    want_pool = (world == 1 and not a.headline_only) or a.pool_check or a.pool_devices
+    t_keys = time.perf_counter()
     try:
-        job = shard.GateJob(cfg, SEED, device=device, lib_path=a.lib)  # identical key replicas on every rank
+        job = shard.GateJob(cfg, SEED, device=device, lib_path=a.lib, keys="broadcast" if a.broadcast_keys else "seed",
+                            tensor_device=dev, keep_host_keys=bool(want_pool))
     except T.TfheAmdError as e:
         raise SystemExit(f"bench.py needs a GPU: the engine has no CPU path ({e})")
+    t_keys = time.perf_counter() - t_keys
     eng, lib = job.eng, job.eng.lib
+    pci = T.device_pci_bus_id(device, a.lib)
     eng.set_option(T.OPT_KS_GATHER, int(a.ks_gather))
 
     # a few real encryptions at the front: decrypt-checked after the timed region
@@ -510,12 +599,17 @@ def main():
         step(k)
     fence()
     elapsed_local = elapsed = time.perf_counter() - t0
-    ranks_seen, ranks = 1, [{"rank": 0, "device": device, "batch": B, "seconds": elapsed_local}]
+    ranks_seen, ranks = 1, [{"rank": 0, "device": device, "batch": B, "seconds": elapsed_local, "pci": pci}]
     if dist is not None:
         elapsed = shard.max_over_ranks(elapsed_local, dev)
-        ranks_seen, ranks = shard.rank_census(rank, device, B, elapsed_local, dev)
+        ranks_seen, ranks = shard.rank_census(rank, device, B, elapsed_local, dev, pci)
         if ranks_seen != world:
             raise SystemExit(f"bench.py: {ranks_seen} ranks answered the census, world size is {world}")
+    n_devices = shard.distinct_devices(ranks)
+    if dist is not None and a.backend == "nccl" and n_devices != world:
+        # N ranks under RCCL are N GPUs or nothing: two ranks doubled up on one chip would report half the rate as "N GPUs"
+        raise SystemExit(f"bench.py: {world} ranks but {n_devices} distinct GPUs (PCI bus ids {[r['pci'] for r in ranks]}): refusing to "
+                         f"report n_gpus = {world}")
 
     # outside the timed region: the real encryptions must decrypt to their sign
     out_all = out_d.download(np.int32, (B, cfg.n + 1))
@@ -605,11 +699,71 @@ def main():
             streamed["hipgraph"] = {"error": str(e)}
         eng.set_option(T.OPT_STREAMED_GRAPH, 0)
 
-    # BASELINE configs 3 and 4 (the other workloads one GPU can run), through tools/bench_configs.py: the same functions, their
-    # lines collected instead of printed.  A failure here must not cost the main metric line.
-    other = None
-    if extras and a.other_configs.strip():
-        other = other_configs(T, a)
+    # >= --sustained-seconds of back-to-back steps (the timed region is a fraction of a second on a chip that moves its clock
+    # under load): rate, min / max step time by HIP events, and -- about half way in -- the shader clock held BESIDE one step
+    # (32 one-wave probes on a second stream, tfhe_amd_clock_probe).  Every rank runs it (all GPUs of a node loaded); rank 0 reports.
+    sustained = None
+    if a.sustained_seconds > 0 and not a.headline_only:
+        try:
+            RING = 16 if a.lwe_n is None else 2  # (the emulator test hook: a step takes seconds there)
+            sev = [(eng.event(), eng.event()) for _ in range(RING)]
+            step_ms, clock, n_steps = [], None, 0
+            eng.sync()
+            ts = time.perf_counter()
+            while True:
+                for k in range(RING):
+                    eng.record(sev[k][0])
+                    step()
+                    eng.record(sev[k][1])
+                    if clock is None and time.perf_counter() - ts >= 0.5 * a.sustained_seconds:
+                        med, lo, hi = eng.clock_probe(int(0.6 * 1e3 * max(br_ms, 0.05)))  # 60 % of one blind rotation, queued just above
+                        clock = {"median": med, "min": lo, "max": hi, "probes": 32,
+                                 "at_seconds": time.perf_counter() - ts,
+                                 "how": "s_memtime / s_memrealtime of one-wave probes on a second stream, beside a running step"}
+                eng.sync()
+                n_steps += RING
+                step_ms += [eng.elapsed_ms(e0, e1) for e0, e1 in sev]
+                if time.perf_counter() - ts >= a.sustained_seconds:
+                    break
+            t_sus = time.perf_counter() - ts
+            sustained = {"seconds": t_sus, "steps": n_steps, "value": B * n_steps / t_sus, "unit": "bootstraps/s (this rank)",
+                         "step_ms_min": float(min(step_ms)), "step_ms_max": float(max(step_ms)), "step_ms_median": float(np.median(step_ms)),
+                         "shader_clock_ghz": clock,
+                         "note": "back-to-back steps in rings of 16 (one host sync per ring); step time = HIP events around blind rotation + key switch"}
+        except T.TfheAmdError as e:
+            sustained = {"error": str(e)}
+
+    # One process, several members: the same batch through tfhe_amd_pool_bootstrap_host -- host arrays in and out (PCIe included),
+    # keys uploaded from HOST arrays (a caller's key, not a seed), one host thread + pinned staging per member.
+    pool_check = None
+    if want_pool and job.bk_host is not None:
+        pool_check = {"entry_point": "tfhe_amd_pool_load_keys_torus + tfhe_amd_pool_bootstrap_host", "pools": []}
+        lists = [[device], [device, device]]
+        if a.pool_devices:
+            lists.append(list(range(T.device_count(a.lib))) if a.pool_devices == "all" else [int(v) for v in a.pool_devices.split(",")])
+        for devs in lists:
+            try:
+                pool = T.Pool(devs, torus_bits=32, n=cfg.n, N=cfg.N, l=cfg.l, Bgbit=cfg.Bgbit, ks_t=cfg.ks_t, ks_basebit=cfg.ks_basebit,
+                              lib_path=a.lib)
+                tk = time.perf_counter()
+                pool.load_keys_torus(job.bk_host, job.ks_host)
+                tk = time.perf_counter() - tk
+                got = pool.bootstrap(mu, x_host)  # warm-up: staging buffers, kernel selection
+                tp, reps_p = time.perf_counter(), max(1, min(reps, 3))
+                for _ in range(reps_p):
+                    got = pool.bootstrap(mu, x_host)
+                tp = (time.perf_counter() - tp) / reps_p
+                counts, secs = pool.last_split()
+                same = bool(np.array_equal(got, out_all))
+                pool_check["pools"].append({"devices": devs, "pci": [T.device_pci_bus_id(d, a.lib) for d in devs], "key_upload_s": tk,
+                                            "bootstraps_per_s": B / tp, "ms_per_call": 1e3 * tp, "split": counts, "member_seconds": secs,
+                                            "identical_to_headline": same})
+                pool.close()
+                if not same:
+                    extras_ok = False
+            except T.TfheAmdError as e:
+                pool_check["pools"].append({"devices": devs, "error": str(e), "bootstraps_per_s": 0.0, "identical_to_headline": False})
+                extras_ok = False
 
     pipelined = None
     if world == 1 and a.pipelined:
@@ -675,12 +829,15 @@ def main():
             "dtype": "f64 (anticyclic FFT) over int32 torus",
             "data": "synthetic",
             "ranks_seen": ranks_seen,
+            "n_devices": n_devices,
             "ranks": ranks,
             "config": {"workload": f"{baseline_config}: {total_per_step} gate bootstraps per step ({B} on rank 0), "
                                    f"{cfg.describe()}, persistent blind-rotation kernel + key-switch kernel, inputs resident in HBM",
                        "baseline_config": baseline_config,
                        "batch_per_gpu": B, "total_per_step": total_per_step,
                        "parallelism": f"batch-sharded x{world} (contiguous slices), keys replicated, no data-path collective",
+                       "key_replication": ("one broadcast per key of the device-layout bytes from rank 0" if a.broadcast_keys
+                                           else "regenerated from the seed on every rank"),
                        "scaling_note": "--gpus 1 without flags is config 2 (4096 per step); --gpus N > 1 without flags is config 5 "
                                        "(2^20 per step cut into N slices, strong); a strict strong-scaling series takes its "
                                        "N = 1 point from `--gpus 1 --total 1048576` (per-GPU throughput at 4096 and at 2^20 per "
@@ -723,6 +880,13 @@ def main():
             "tail_check": None if tail_ok is None else {"samples": ntail, "identical_to_front": tail_ok},
             "device": T.device_info(device, a.lib),
         }
+        if a.broadcast_keys:
+            line["key_broadcast"] = {"bytes": job.key_bytes_received, "backend": a.backend, "world": world, "setup_seconds": round(t_keys, 3),
+                                     "what": "bkFFT in the kernel layout + key-switch key, torch.distributed.broadcast from rank 0"}
+        if sustained is not None:
+            line["sustained"] = sustained
+        if pool_check is not None:
+            line["pool_check"] = pool_check
         if latency is not None:
             line["config1_latency"] = latency
         if streamed is not None:
@@ -735,14 +899,21 @@ def main():
             cpu_line = dict(cpu_line, measured_by=baseline_by)
             line["cpu_baseline"] = cpu_line
         detail_path = write_detail(line, a)
-        print(json.dumps(compact_line(line, detail_path)), flush=True)
+        try:
+            compact = compact_line(line, detail_path)
+        except Exception as e:  # noqa: BLE001 -- the contract keys alone then (the full record is in the detail file)
+            compact = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                            "scaling", "vs_baseline", "dtype", "data")}
+            compact.update(config={"workload": line["config"]["workload"]}, roofline=line["roofline"], cpu_baseline=line.get("cpu_baseline"),
+                           compact_line_error=repr(e)[:200], detail=detail_path)
+        print(json.dumps(compact), flush=True)
     job.close()
     if dist is not None:
         dist.destroy_process_group()
     if not ok:
         raise SystemExit("decrypt check failed")
     if not extras_ok:
-        raise SystemExit("a schedule measured after the timed region (config 1 latency / streamed) differs from the headline outputs")
+        raise SystemExit("a schedule measured after the timed region (config 1 latency / streamed / pool) differs from the headline outputs")
     if oracle_ok is False:
         raise SystemExit("GPU outputs differ from the oracle")
     if tail_ok is False:

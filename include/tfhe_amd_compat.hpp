@@ -135,10 +135,12 @@ inline void staging(Resident &R, size_t bytes) {
     check(tfhe_amd_malloc(R.ctx, &R.d_aux, bytes), R.ctx, "malloc");
 }
 
-// Resident copies are found by the ADDRESS of the caller's key object.  A key that is freed and rebuilt at the same address
-// without a release() in between must not be served from the stale GPU copy: every lookup re-reads a SAMPLE of the host
-// key (the bit patterns of a few values of its first, middle and last polynomials and key-switch rows: ~50 loads) and
-// compares it with the sample taken at upload time; a difference drops the resident copy and uploads the key again.
+// Resident copies are found by the ADDRESS of the caller's key object.  The CONTRACT is release(): call it whenever a key
+// object's contents change or its memory is reused.  As a guard against the commonest mistake -- a key freed and rebuilt at
+// the same address without a release() in between -- every lookup re-reads a SAMPLE of the host key (the bit patterns of a few
+// values of its first, middle and last polynomials and key-switch rows: ~50 loads) and compares it with the sample taken at
+// upload time; a difference drops the resident copy and uploads the key again.  The detection is probabilistic: a change
+// elsewhere than at the sampled positions is NOT seen and the stale GPU copy is served ("Caveat").
 inline uint64_t fp_mix(uint64_t h, uint64_t v) {
     h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
     return h;
@@ -331,7 +333,7 @@ inline void release_entry(std::map<ResidentKey, Resident>::iterator it) {
 }
 // every resident engine made from this key object, whatever shape it was attached with and whichever of its
 // addresses the caller passes: the LweBootstrappingKeyFFT, its bkFFT array or its key-switch key.  (The copies are
-// keyed by ADDRESS and guarded by a content sample, see key_fingerprint: a key rebuilt in place is uploaded again.)
+// keyed by ADDRESS; the content sample of key_fingerprint catches most keys rebuilt in place, not all: release() is the contract.)
 inline void release(const void *key_object) {
     TFHE_AMD_SHIM_GUARD();
     auto &reg = registry();

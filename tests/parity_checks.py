@@ -508,6 +508,58 @@ def check_circuit_bootstrap(lib_path, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t
         cb.close()
 
 
+def check_privks_wide(lib_path, N1=1024, N2=2048, t21=10, bb21=3, counts=(300, 1031), pipeline_B=600, n0=4, l1=2, bg1=8, l2=4, bg2=9,
+                      t10=6, bb10=2, seed=65):
+    """circuitPrivKS (poc:667-698) on MANY samples per launch: the int64 instantiation of the matrix-core key switch with
+    several 256-sample tiles and every wave of a tile live -- the launch shape BASELINE config 3's number comes from (1024
+    circuit bootstraps = 2048 samples per plane).  For each count: 8 scattered rows (+ first / last row of every tile boundary)
+    against the oracle, the first 3 rows against a count-3 launch of the same inputs, and every shorter count a prefix of the
+    longest.  Then the whole pipeline at `pipeline_B` inputs (l1 * pipeline_B samples per plane, in the grouped output layout):
+    scattered rows against the oracle and against a 3-input launch of the same rows."""
+    rs = np.random.RandomState(seed)
+    key0, key2 = O.keygen_binary(n0, SEED, 21), O.keygen_binary(N2, SEED, 23)
+    bk = O.bk_create64(N2, key0, key2, l2, bg2, 2.0 ** -44, SEED, 3000)
+    preks = O.fill32(101, N1 * t10 * (1 << bb10) * (n0 + 1)).reshape(N1, t10, 1 << bb10, n0 + 1)
+    privks = O.fill32(202, 2 * (N2 + 1) * t21 * (1 << bb21) * 2 * N1).reshape(2, N2 + 1, t21, 1 << bb21, 2, N1)
+    cb = T.CircuitBootstrap(n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, lib_path=lib_path)
+    try:
+        cb.load_preks(preks)
+        cb.load_bk_fft(bk)
+        cb.load_privks(privks)
+        cmax = max(counts)
+        x64 = np.frombuffer(rs.bytes(cmax * (N2 + 1) * 8), dtype=np.int64).reshape(cmax, N2 + 1).copy()
+        x64[0, :3] = [0, -1, 1 << (63 - t21 * bb21)]  # digit rounding boundary
+        for u in (0, 1):
+            small = cb.privks(u, x64[:3])
+            for b in range(3):
+                assert np.array_equal(small[b].ravel(), O.privks(privks[u], x64[b], N2, N1, t21, bb21)), f"u={u} row {b} of 3"
+            full = None
+            for count in sorted(counts, reverse=True):
+                got = cb.privks(u, x64[:count])
+                assert np.array_equal(got[:3], small), f"circuitPrivKS u={u} count={count}: first rows vs the 3-sample launch"
+                rows = sorted(set([r for r in (0, 255, 256, 257, 511, 512, 767, 768, 1023, 1024, count - 1) if r < count]
+                                  + list(rs.choice(count, min(8, count), replace=False))))
+                for r in rows:
+                    assert np.array_equal(got[r].ravel(), O.privks(privks[u], x64[r], N2, N1, t21, bb21)), f"circuitPrivKS u={u} count={count} row {r}"
+                if full is None:
+                    full = got
+                else:
+                    assert np.array_equal(got, full[:count]), f"u={u}: count={count} is not a prefix of the longest launch"
+        B = pipeline_B
+        if B < 3:
+            return
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(B, N1 + 1)).astype(np.int32)
+        got = cb.circuit_bootstrap(x)
+        rows = sorted(set([0, 127, 128, 255, 256, B // 2, B - 1]) & set(range(B)))
+        for r in rows[:5] + rows[-1:]:
+            want = O.circuit_bootstrap(x[r], preks, bk, privks, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21)
+            assert np.array_equal(got[r], want), f"tfhe_CircuitBootstrapFFT, input {r} of {B}"
+        pick = [0, B // 2, B - 1]
+        assert np.array_equal(cb.circuit_bootstrap(x[pick]), got[pick]), "the same inputs in a 3-input launch"
+    finally:
+        cb.close()
+
+
 # ------------------------------------------------- empty batches, state and parameter errors
 def check_abi_edges(lib_path):
     """Empty batches are no-ops that touch nothing; calls made in the wrong state or with bad arguments fail
@@ -550,6 +602,16 @@ def check_abi_edges(lib_path):
         assert lib.tfhe_amd_bootstrap(e.ctx, d_out.ptr, 1 << 29, d_in.ptr, -1) == T.ERR_PARAM
         assert lib.tfhe_amd_extern_mul(e.ctx, d_in.ptr, g, n, 1) == T.ERR_PARAM  # TGSW index out of range
         assert lib.tfhe_amd_set_option(e.ctx, 99, 0) == T.ERR_PARAM
+        # the bare transforms are out of place and their operands share an element type: ANY overlap of the two ranges is
+        # refused (the same pointer, or an output that starts inside the input batch), disjoint neighbours are accepted
+        d_lag = e.alloc(4 * N * 8)
+        for fn in (lib.tfhe_amd_ifft_f64, lib.tfhe_amd_fft_f64):
+            assert fn(e.ctx, d_lag.ptr, d_lag.ptr, 1) == T.ERR_PARAM
+            assert fn(e.ctx, d_lag.ptr + N * 8, d_lag.ptr, 2) == T.ERR_PARAM
+            assert fn(e.ctx, d_lag.ptr, d_lag.ptr + N * 8, 2) == T.ERR_PARAM
+            assert b"overlap" in lib.tfhe_amd_last_error(e.ctx)
+            assert fn(e.ctx, d_lag.ptr + 2 * N * 8, d_lag.ptr, 2) == T.OK
+        e.sync()
         # a batch of one still works after all of that (state intact)
         x = O.lwe_encrypt32(1 << 29, 2.0 ** -15, lk, O.rng(SEED, 77))
         got = e.bootstrap(1 << 29, x[None, :])

@@ -169,6 +169,116 @@ def test_privks_two_word_digits(gpu_lib):
                               bb21=3, B=3, seed=64)
 
 
+def test_privks_wide_counts_and_pipeline_poc_shape(gpu_lib):
+    """the launch shape BASELINE config 3's number comes from: circuitPrivKS at the PoC shape (N2=2048 -> N1=1024, 10 x 3 bits,
+    1.34 GB per plane) with 300 and 1031 samples per launch -- several 256-sample tiles, every wave of a tile live, a ragged
+    last tile -- and tfhe_CircuitBootstrapFFT on 600 inputs (1200 samples per plane, grouped output layout); against the
+    oracle on scattered rows and on the rows around every tile boundary, and against 3-sample launches of the same inputs"""
+    P.check_privks_wide(gpu_lib)
+
+
+def test_privks_wide_counts_other_bases(gpu_lib):
+    """the same for the int64 key switch's other digit widths (base 4: two K-steps per coefficient; base 2), 2 tiles each"""
+    P.check_privks_wide(gpu_lib, N2=1024, t21=12, bb21=2, counts=(300,), pipeline_B=140, l2=3, bg2=10, seed=66)
+    P.check_privks_wide(gpu_lib, N2=1024, t21=20, bb21=1, counts=(259,), pipeline_B=0, l2=3, bg2=10, seed=67)
+
+
+def test_pool_two_members_on_device_0(gpu_lib):
+    """tfhe_amd_pool_* on hardware: two members that share the one GPU (two host threads, two streams, two pinned staging
+    buffers, the key uploaded once per member from HOST arrays).  1031 samples = 516 + 515; equal to the single-context
+    engine and, on a subset, to the oracle; per-member split reported."""
+    N, n, l, Bgbit, t, bb = 1024, 24, 2, 10, 8, 2
+    s = P.GateSetup(gpu_lib, N, n, l, Bgbit, t, bb)
+    pool = T.Pool([0, 0], torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=t, ks_basebit=bb, lib_path=gpu_lib)
+    try:
+        pool.load_keys(s.bk, s.ks)
+        rs = np.random.RandomState(1031)
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(1031, n + 1)).astype(np.int32)
+        single = s.eng.bootstrap(1 << 29, x)
+        for rep in range(3):
+            assert np.array_equal(pool.bootstrap(1 << 29, x), single), rep
+        counts, seconds = pool.last_split()
+        assert counts == [516, 515] and min(seconds) > 0
+        for i in (0, 515, 516, 1030):
+            assert np.array_equal(single[i], O.bootstrap32(N, s.bk, s.ks, 1 << 29, x[i], l, Bgbit, t, bb)), i
+        u = pool.bootstrap_woks(1 << 29, x[:7])
+        assert np.array_equal(pool.keyswitch(u), single[:7])
+        assert np.array_equal(pool.bootstrap(1 << 29, x[:1]), single[:1])  # one sample: the second member idles
+        bk_t = T.keygen_bk_torus(32, s.lwe_key, s.tkey, l, Bgbit, 2.0 ** -25, P.SEED, 1000, lib_path=gpu_lib)
+        pool.load_keys_torus(bk_t, None)  # the key again, in coefficient form: converted on the device, replaces the first
+        assert np.array_equal(pool.bootstrap(1 << 29, x), single)
+    finally:
+        pool.close()
+        s.close()
+
+
+def test_circuit_bootstrap_pool_two_members_on_device_0(gpu_lib):
+    n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21 = 6, 1024, 2048, 2, 8, 4, 9, 6, 2, 3, 3
+    key0, key2 = O.keygen_binary(n0, P.SEED, 21), O.keygen_binary(N2, P.SEED, 23)
+    bk = O.bk_create64(N2, key0, key2, l2, bg2, 2.0 ** -44, P.SEED, 3000)
+    preks = O.fill32(101, N1 * t10 * (1 << bb10) * (n0 + 1)).reshape(N1, t10, 1 << bb10, n0 + 1)
+    privks = O.fill32(202, 2 * (N2 + 1) * t21 * (1 << bb21) * 2 * N1).reshape(2, N2 + 1, t21, 1 << bb21, 2, N1)
+    pool = T.CircuitBootstrapPool([0, 0], n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, lib_path=gpu_lib)
+    try:
+        pool.load_preks(preks)
+        pool.load_bk_fft(bk)
+        pool.load_privks(privks)
+        x = np.random.RandomState(9).randint(-2 ** 31, 2 ** 31, size=(37, N1 + 1)).astype(np.int32)
+        got = pool.circuit_bootstrap(x)
+        for b in (0, 18, 19, 36):
+            want = O.circuit_bootstrap(x[b], preks, bk, privks, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21)
+            assert np.array_equal(got[b], want), b
+    finally:
+        pool.close()
+
+
+def test_keys_as_device_layout_bytes(gpu_lib):
+    """the bytes a key broadcast carries: context A's resident keys exported in their device layout, imported by context B
+    (nothing regenerated or re-converted; the matrix-core key-switch layout rebuilt locally), same outputs"""
+    N, n, l, Bgbit, t, bb = 1024, 12, 2, 10, 8, 2
+    src = P.GateSetup(gpu_lib, N, n, l, Bgbit, t, bb)
+    dst = T.Engine(torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=t, ks_basebit=bb, lib_path=gpu_lib)
+    try:
+        bk_bytes = np.empty(src.eng.gsw_packed_bytes(n), np.uint8)
+        ks_bytes = np.empty(src.eng.keyswitch_key_bytes(), np.uint8)
+        src.eng.gsw_export_packed(src.gsw, T._np_ptr(bk_bytes))
+        src.eng.keyswitch_key_export(T._np_ptr(ks_bytes))
+        assert np.array_equal(ks_bytes.view(np.int32).reshape(src.ks.shape), src.ks)
+        # through device memory, as a collective delivers them
+        d_bk, d_ks = dst.to_device(bk_bytes), dst.to_device(ks_bytes)
+        dst.set_bootstrap_key(dst.gsw_from_packed(d_bk.ptr, n))
+        dst.load_keyswitch_key_d(d_ks.ptr)
+        x = np.random.RandomState(3).randint(-2 ** 31, 2 ** 31, size=(70, n + 1)).astype(np.int32)
+        got = dst.bootstrap(1 << 29, x)
+        assert np.array_equal(got, src.eng.bootstrap(1 << 29, x))
+        assert np.array_equal(got[5], O.bootstrap32(N, src.bk, src.ks, 1 << 29, x[5], l, Bgbit, t, bb))
+    finally:
+        dst.close()
+        src.close()
+
+
+def test_device_identity_and_clock_probe(gpu_lib):
+    """PCI bus id of the device behind ordinal 0 (what the bench line's rank table carries), and the shader-clock probe
+    run BESIDE a blind rotation that fills the chip: a plausible clock, below the 2.4 GHz the data sheet names"""
+    import re
+    assert T.device_count(gpu_lib) >= 1
+    bus = T.device_pci_bus_id(0, gpu_lib)
+    assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", bus), bus
+    assert bus in T.device_info(0, gpu_lib)
+    s = P.GateSetup(gpu_lib, 1024, 64, 2, 10, 8, 2)
+    try:
+        x = np.random.RandomState(1).randint(-2 ** 31, 2 ** 31, size=(4096, 65)).astype(np.int32)
+        d_x, d_o = s.eng.to_device(x), s.eng.alloc(4096 * 1025 * 4)
+        idle = s.eng.clock_probe(500)
+        s.eng._chk(s.eng.lib.tfhe_amd_bootstrap_woks(s.eng.ctx, d_o.ptr, 1 << 29, d_x.ptr, 4096))  # ~1.7 ms of full-chip work
+        busy = s.eng.clock_probe(1000)
+        s.eng.sync()
+        for med, lo, hi in (idle, busy):
+            assert 0.3 < lo <= med <= hi < 2.6, (idle, busy)
+    finally:
+        s.close()
+
+
 def test_batch_4096_properties(gpu_lib):
     """BASELINE config 2 at full size: 4096 gate bootstraps.  Checked by (i) decrypt-sign of every
     output, (ii) bit-equality with the oracle on a subset, (iii) persistent schedule == one launch

@@ -10,18 +10,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, emu_lib, q):
+def _worker(rank, world, port, emu_lib, q, keys="seed"):
+    import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), TFHE_EMU_DEVICES="8")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     shard = importlib.import_module("experimental-tfhe_amd.shard")
     T = importlib.import_module("experimental-tfhe_amd")
     cfg = shard.GateConfig(N=1024, n=4, l=2, Bgbit=10, ks_t=8, ks_basebit=2)
     total = 7  # ragged: 4 + 3
     lo, hi = shard.shard_range(total, rank, world)
-    job = shard.GateJob(cfg, seed=0x5446484500000001, device=0, lib_path=emu_lib)  # keys replicated from the seed
+    # keys replicated from the seed, or built by rank 0 alone and broadcast as device-layout bytes; rank r on emulated device 3 r
+    job = shard.GateJob(cfg, seed=0x5446484500000001, device=3 * rank, lib_path=emu_lib, keys=keys, tensor_device=torch.device("cpu"))
+    if keys == "broadcast":
+        assert job.key_bytes_received == 4 * 4 * 2 * 1024 * 8 + 1024 * 8 * 4 * 5 * 4
+        assert (job.tlwe_key is None) == (rank != 0)  # only rank 0 ever held the host keys
     x_all = shard.synthetic_samples(cfg, total, seed=77)
     out = job.bootstrap(1 << 29, x_all[lo:hi])
     t_local = 0.25 * (rank + 1)
@@ -34,12 +39,18 @@ def _worker(rank, world, port, emu_lib, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding(emu_lib):
+import pytest
+
+
+@pytest.mark.parametrize("keys", ["seed", "broadcast"])
+def test_two_rank_sharding(emu_lib, keys):
+    """keys="broadcast": rank 1 never generates a key -- it bootstraps with the bytes rank 0 broadcast, on another
+    (emulated) device, and the gathered outputs still equal the single-rank result"""
     import torch.multiprocessing as mp  # imported lazily: collecting -m gpu tests must stay light
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if keys == "broadcast" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib, q, keys)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

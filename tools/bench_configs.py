@@ -123,15 +123,29 @@ def bench_cb(T, a):
     else:
         n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, B, d = 500, 1024, 2048, 2, 8, 4, 9, 6, 2, 10, 3, a.cb_batch, 16
     B -= B % d
+    preks = rand_bits(rs, (N1, t10, 1 << bb10, n0 + 1), np.int32)
+    bk = rand_bits(rs, (n0, 2 * l2, 2, N2), np.int64)
+    x = rand_bits(rs, (B, N1 + 1), np.int32)
+    planes = [rand_bits(rs, ((N2 + 1) * t21 * (1 << bb21) * 2 * N1,), np.int32) for _ in range(2)]  # 1.35 GB each
+    # The checker's answers for a few of the TIMED inputs, computed before the engine exists (no GPU use yet in a process that
+    # starts here): tfhe_CircuitBootstrapFFT (poc:823-873) restated by the oracle on the same synthetic keys -- first, last and
+    # the rows either side of a 256-sample tile boundary of the private key switch.  Compared bit for bit after the timed runs.
+    check_rows, want = [r for r in (0, 255, 256, B - 1) if 0 <= r < B], None
+    if not getattr(a, "no_oracle", False):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_py as O
+        bkfft = O.execute_reverse_torus64(N2, bk.reshape(-1, N2)).reshape(bk.shape)  # tGswToFFTConvert
+        table = np.stack([p.reshape(N2 + 1, t21, 1 << bb21, 2, N1) for p in planes])
+        want = np.stack([O.circuit_bootstrap(x[r], preks, bkfft, table, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21) for r in check_rows])
+        del bkfft, table
     cb = T.CircuitBootstrap(n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21, lib_path=a.lib)
     lib = cb.lib
-    cb.load_preks(rand_bits(rs, (N1, t10, 1 << bb10, n0 + 1), np.int32))
-    cb.load_bk_torus(rand_bits(rs, (n0, 2 * l2, 2, N2), np.int64))        # tGswToFFTConvert on the GPU
+    cb.load_preks(preks)
+    cb.load_bk_torus(bk)                                                  # tGswToFFTConvert on the GPU
     for u in range(2):                                                    # one 1.35 GB plane at a time
-        plane = rand_bits(rs, ((N2 + 1) * t21 * (1 << bb21) * 2 * N1,), np.int32)
-        cb._chk(lib.tfhe_amd_cb_load_privks_plane(cb.cb, u, T._np_ptr(plane)))
-        del plane
-    x = rand_bits(rs, (B, N1 + 1), np.int32)
+        cb._chk(lib.tfhe_amd_cb_load_privks_plane(cb.cb, u, T._np_ptr(planes[u])))
+        planes[u] = None
+    del planes
     d_x = cb._dev(x)
     d_out = cb._dev(np.zeros((B, 2, l1, 2, N1), np.int32))
 
@@ -140,6 +154,14 @@ def bench_cb(T, a):
     line = {"workload": f"tfhe_CircuitBootstrapFFT n0={n0} N1={N1} N2={N2} l2={l2} Bgbit2={bg2} l1={l1} Bgbit1={bg1} "
                         f"preKS {t10}x{bb10} privKS {t21}x{bb21}, batch {B}, synthetic keys",
             "ms_min": whole_min, "ms_mean": whole_mean, "circuit_bootstraps_per_s": B / (whole_min * 1e-3)}
+    if want is not None:
+        got = np.empty((B, 2, l1, 2, N1), np.int32)
+        cb._chk(lib.tfhe_amd_memcpy_d2h(cb.ctx, T._np_ptr(got), d_out, got.nbytes))
+        line["oracle_bit_identical"] = bool(np.array_equal(got[check_rows], want))
+        line["oracle_rows"] = check_rows
+        del got
+        if not line["oracle_bit_identical"]:
+            raise RuntimeError(f"circuit bootstrap: the timed outputs of rows {check_rows} differ from the oracle")
     # stages, timed separately through the same entry points the pipeline composes
     c10, c2 = cb.ctx10, cb.ctx
     d_pre = cb._dev(np.zeros((B, n0 + 1), np.int32))
@@ -247,7 +269,11 @@ def bench_latency(T, a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["fft", "cb", "lat", "all"])
+    ap.add_argument("what", nargs="+", choices=["fft", "cb", "lat", "all"])
+    ap.add_argument("--json-out", default=None,
+                    help="also write {'cb': [...], 'fft': [...]} (the lines of the sections that ran, or {'error': ...} for one that "
+                         "failed) to this file: how bench.py collects configs 3 and 4 from a child process")
+    ap.add_argument("--no-oracle", action="store_true", help="cb: skip the oracle check of the timed outputs")
     ap.add_argument("--lat-batches", default="1,8,64,256,512,768,1024,2048,4096")
     ap.add_argument("--batch", type=int, default=8192, help="polynomials per launch (fft)")
     ap.add_argument("--cb-batch", type=int, default=1024,
@@ -260,12 +286,27 @@ def main():
     T = importlib.import_module("experimental-tfhe_amd")
     if a.lib is None and not os.path.exists(T.DEFAULT_LIB):
         importlib.import_module("experimental-tfhe_amd.build").build()  # child process before any GPU use
-    if a.what in ("lat", "all"):   # first: it times the reference in a child process before the GPU is in use
+    want = set(a.what)
+    if "all" in want:
+        want = {"lat", "fft", "cb"}
+    out, failed = {}, False
+    if "lat" in want:   # first: it times the reference in a child process before the GPU is in use
         bench_latency(T, a)
-    if a.what in ("fft", "all"):
-        bench_fft(T, a)
-    if a.what in ("cb", "all"):
-        bench_cb(T, a)
+    # cb before fft: its oracle leg wants a process that has not touched the GPU yet
+    for name, fn in (("cb", bench_cb), ("fft", bench_fft)):
+        if name not in want:
+            continue
+        try:
+            out[name] = fn(T, a)
+        except Exception as e:  # noqa: BLE001 -- one section must not cost the other
+            out[name] = {"error": repr(e)}
+            failed = True
+            sys.stderr.write(f"bench_configs {name}: {e!r}\n")
+        if a.json_out:  # after every section: a crash in the next one keeps this one
+            with open(a.json_out, "w") as f:
+                json.dump(out, f)
+    if failed:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include <algorithm>
 
@@ -21,7 +22,7 @@ struct Stamp { unsigned long long cyc, real; };
 
 enum Op { FMA64, ADD64, MUL64, FMA64NEG, FMA32, ADDU32, SUBU32, XOR32, AND32, LSHL32, ASHR32, BFEI32, BFEU32, CNDMASK, LSHLADD,
           CVT64I32, TRUNC64, CVTI32F64, DPPMOV, PERM32SWAP, PERM16SWAP, MIX_F64_INT, MIX_F64_2INT, DSW64, DSW2_64, DSR64, DSR2_64, DSR128,
-          DSW64_FMA2, DSR64_FMA2, NOPS, DEP1, DEP2, DEP4, BFLY, BFLY_LDS };
+          DSW64_FMA2, DSR64_FMA2, NOPS, DEP1, DEP2, DEP4, BFLY, BFLY_LDS, MADU64, MULHI32, MULLO32, ADDC64 };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_issue(Stamp *out, int iters, double seed) {
@@ -30,6 +31,8 @@ __global__ void __launch_bounds__(256) k_issue(Stamp *out, int iters, double see
     double a0 = seed + t, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const double b = 1.0000001, c = 0.9999999;
     int i0 = t, i1 = t + 1, i2 = t + 2, i3 = t + 3, i4 = t + 4, i5 = t + 5, i6 = t + 6, i7 = t + 7;
+    int j0 = t, j1 = t + 1, j2 = t + 2, j3 = t + 3, j4 = t + 4, j5 = t + 5, j6 = t + 6, j7 = t + 7;
+    unsigned long long q0 = t, q1 = t + 1, q2 = t + 2, q3 = t + 3, q4 = t + 4, q5 = t + 5, q6 = t + 6, q7 = t + 7;
     const unsigned lds = (unsigned)(t * 8);       // conflict-free 8-byte slots, 2 KB per wave-instruction group
     const unsigned lds16 = (unsigned)(t * 16);
     __syncthreads();
@@ -37,6 +40,8 @@ __global__ void __launch_bounds__(256) k_issue(Stamp *out, int iters, double see
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
 #define A(k) a##k
 #define I(k) i##k
+#define Q(k) q##k
+#define J(k) j##k
     for (int it = 0; it < iters; it++) {
         if (OP == FMA64) {
 #define X(k) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(A(k)) : "v"(b), "v"(c));
@@ -121,6 +126,22 @@ __global__ void __launch_bounds__(256) k_issue(Stamp *out, int iters, double see
         } else if (OP == PERM16SWAP) {
 #define X(k) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(I(k)), "+v"(I(k)));
             REP128(X)
+#undef X
+        } else if (OP == MADU64) {        // the 32 x 32 + 64 -> 64 multiply-add of the Real96 (128-bit fixed point) products
+#define X(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(Q(k)) : "v"(I(k)), "v"(t) : "vcc");
+            REP128(X)
+#undef X
+        } else if (OP == MULHI32) {
+#define X(k) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(I(k)) : "v"(t));
+            REP128(X)
+#undef X
+        } else if (OP == MULLO32) {
+#define X(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(I(k)) : "v"(t));
+            REP128(X)
+#undef X
+        } else if (OP == ADDC64) {        // 64 x (add_co ; addc_co): one 64-bit add through the carry
+#define X(k) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc" : "+v"(I(k)), "+v"(J(k)) : "v"(t) : "vcc");
+            REP64(X)
 #undef X
         } else if (OP == MIX_F64_INT) {   // 64 x (fma_f64 ; add_u32)
 #define X(k) asm volatile("v_fma_f64 %0, %0, %2, %3\n\tv_add_u32 %1, %1, %4" : "+v"(A(k)), "+v"(I(k)) : "v"(b), "v"(c), "v"(t));
@@ -214,7 +235,8 @@ __global__ void __launch_bounds__(256) k_issue(Stamp *out, int iters, double see
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-    double s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7);
+    double s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7) + (double)(j0 + j1 + j2 + j3 + j4 + j5 + j6 + j7) +
+               (double)(q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7);
     if (s == 1.2345e-300) smem[0] = 1;  // keep everything alive
     if ((t & 63) == 0) {
         Stamp st{c1 - c0, r1 - r0};
@@ -248,6 +270,17 @@ static void run(const char *name, int per_iter, int k, Stamp *d_out, int iters) 
 
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 2000;
+    if (argc > 2 && std::string(argv[2]) == "int") {  // only the integer-multiply cases (round 5: the Real96 transforms' bound)
+        Stamp *d;
+        CHECK(hipMalloc(&d, sizeof(Stamp) * 256 * 8 * 4));
+        for (int k : {1, 2, 4}) {
+#define R(OP, n) run<OP>(#OP, n, k, d, iters);
+            R(MADU64, 128) R(MULHI32, 128) R(MULLO32, 128) R(ADDC64, 128) R(ADDU32, 128) R(FMA64, 128)
+#undef R
+            printf("\n");
+        }
+        return 0;
+    }
     Stamp *d_out;
     CHECK(hipMalloc(&d_out, sizeof(Stamp) * 256 * 8 * 4));
     for (int k : {1, 2}) {
