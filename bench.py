@@ -32,7 +32,9 @@ rocprofv3 scripts under tools/ pass so that the default command's kernel table h
   config1_latency     BASELINE config 1: one gate bootstrap per call (and 8) through tfhe_amd_bootstrap, HIP events
   streamed_schedule   BASELINE config 2's literal schedule: one external-product launch per CMux step
   sustained           >= --sustained-seconds (10) of back-to-back steps after the timed region: bootstraps/s, min / max step
-                      time, and the shader clock the chip held beside one of those steps (tfhe_amd_clock_probe)
+                      time; with it the shader clock the chip holds UNDER the blind-rotation kernel, from the probe build of the
+                      same sources (libtfhe_amd_probe.so: s_memtime / s_memrealtime around every wave's CMux loop, one stamped
+                      launch after 2 s of back-to-back ones) run in a child process before this one touches the GPU
   pool_check          the same batch through tfhe_amd_pool_bootstrap_host (host arrays in, host arrays out, PCIe included): a
                       pool of one member and of two members sharing this GPU, keys uploaded from HOST arrays
 The `ranks` table carries every rank's PCI bus id; `n_devices` = distinct GPUs.  Under RCCL a run whose ranks do not sit
@@ -218,6 +220,35 @@ def other_configs_child(a):
     return out
 
 
+def shader_clock_child(a):
+    """The shader clock the chip holds UNDER the headline kernel: the probe build of the same sources
+    (experimental-tfhe_amd/libtfhe_amd_probe.so, -DTFHE_PROBE: s_memtime / s_memrealtime stamped around every wave's CMux loop)
+    run by tools/wave_probe.py in a CHILD process before this process touches the GPU -- 2 s of back-to-back launches, then one
+    stamped launch (MI355X_MICROARCH.md, DVFS give-back item 6).  The shipped kernel executes no stamp.  (A co-resident probe
+    kernel cannot see it: the blind rotation's two waves per SIMD hold all 512 registers, nothing becomes resident beside them.)"""
+    import tempfile
+    T = importlib.import_module("experimental-tfhe_amd")
+    lib = os.path.join(os.path.dirname(T.DEFAULT_LIB), "libtfhe_amd_probe.so")
+    if a.lib is not None or not os.path.exists(lib):
+        return None
+    fd, path = tempfile.mkstemp(prefix="tfhe_bench_clock_", suffix=".json")
+    os.close(fd)
+    try:
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wave_probe.py"), lib, "--batch", str(BATCH_PER_GPU), "--warm-seconds", "2",
+                              "--json-out", path, "--quiet"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=180)
+        if res.returncode:
+            return {"error": f"child exit {res.returncode}: {res.stderr[-200:]}"}
+        with open(path) as f:
+            return json.load(f)
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": repr(e)[:200]}
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+
+
 def write_detail(line, a):
     """the FULL record (every note, every stage, every config-4 line) as a file: gpurun_out/bench_detail_<n>gpu.json next to the
     repository root (gpurun merges that directory back; the driver pulls it), or --detail PATH.  Returns the path or None."""
@@ -287,11 +318,12 @@ def compact_line(full, detail_path):
                 "hipgraph_bootstraps_per_s": (round(st["hipgraph"]["value"], 1) if "value" in st.get("hipgraph", {}) else None)}
 
     def b_sustained(su):
-        clk = su.get("shader_clock_ghz") or {}
+        clk = su.get("shader_clock") or {}
         return {"seconds": round(su["seconds"], 2), "steps": su["steps"], "bootstraps_per_s": round(su["value"], 1),
                 "step_ms_min": round(su["step_ms_min"], 3), "step_ms_max": round(su["step_ms_max"], 3),
                 "over_timed_region": round(su["value"] / full["value"] * full["n_gpus"], 4) if full["value"] else None,
-                "shader_clock_ghz": (round(clk["median"], 3) if "median" in clk else None)}
+                "shader_clock_ghz": (round(clk["shader_clock_ghz"], 3) if "shader_clock_ghz" in clk else None),
+                "probe_build_kernel_ms": (round(clk["kernel_ms"], 3) if "kernel_ms" in clk else None)}
 
     def b_pool(pc):
         return {"members": [[m["devices"], round(m["bootstraps_per_s"], 1)] for m in pc["pools"]], "pcie_included": True,
@@ -495,9 +527,11 @@ def main():
             oracle_want = oracle_answers(cfg, [x_host[i] for i in oracle_idx])
 
     # BASELINE configs 3 and 4 (the other workloads one GPU can run): a child process, now -- before this process touches the GPU
-    other = None
+    other, shader_clock = None, None
     if world == 1 and not a.headline_only and a.other_configs.strip():
         other = other_configs_child(a)
+    if world == 1 and not a.headline_only and a.sustained_seconds > 0:
+        shader_clock = shader_clock_child(a)
 
     dist, dev, torch = None, None, None
     device = 0
@@ -700,14 +734,14 @@ def main():
         eng.set_option(T.OPT_STREAMED_GRAPH, 0)
 
     # >= --sustained-seconds of back-to-back steps (the timed region is a fraction of a second on a chip that moves its clock
-    # under load): rate, min / max step time by HIP events, and -- about half way in -- the shader clock held BESIDE one step
-    # (32 one-wave probes on a second stream, tfhe_amd_clock_probe).  Every rank runs it (all GPUs of a node loaded); rank 0 reports.
+    # under load): rate, min / max step time by HIP events.  Every rank runs it (all GPUs of a node loaded); rank 0 reports.
+    # The shader clock under the kernel comes from the probe build's stamped launch (shader_clock_child, above).
     sustained = None
     if a.sustained_seconds > 0 and not a.headline_only:
         try:
             RING = 16 if a.lwe_n is None else 2  # (the emulator test hook: a step takes seconds there)
             sev = [(eng.event(), eng.event()) for _ in range(RING)]
-            step_ms, clock, n_steps = [], None, 0
+            step_ms, n_steps = [], 0
             eng.sync()
             ts = time.perf_counter()
             while True:
@@ -715,11 +749,6 @@ def main():
                     eng.record(sev[k][0])
                     step()
                     eng.record(sev[k][1])
-                    if clock is None and time.perf_counter() - ts >= 0.5 * a.sustained_seconds:
-                        med, lo, hi = eng.clock_probe(int(0.6 * 1e3 * max(br_ms, 0.05)))  # 60 % of one blind rotation, queued just above
-                        clock = {"median": med, "min": lo, "max": hi, "probes": 32,
-                                 "at_seconds": time.perf_counter() - ts,
-                                 "how": "s_memtime / s_memrealtime of one-wave probes on a second stream, beside a running step"}
                 eng.sync()
                 n_steps += RING
                 step_ms += [eng.elapsed_ms(e0, e1) for e0, e1 in sev]
@@ -728,7 +757,7 @@ def main():
             t_sus = time.perf_counter() - ts
             sustained = {"seconds": t_sus, "steps": n_steps, "value": B * n_steps / t_sus, "unit": "bootstraps/s (this rank)",
                          "step_ms_min": float(min(step_ms)), "step_ms_max": float(max(step_ms)), "step_ms_median": float(np.median(step_ms)),
-                         "shader_clock_ghz": clock,
+                         "shader_clock": shader_clock,
                          "note": "back-to-back steps in rings of 16 (one host sync per ring); step time = HIP events around blind rotation + key switch"}
         except T.TfheAmdError as e:
             sustained = {"error": str(e)}

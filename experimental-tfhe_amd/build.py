@@ -15,9 +15,13 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtfhe_amd.so")
 OUT_DROPIN = os.path.join(HERE, "libtfhe_amd_dropin.so")  # global-scope reference entry points (csrc/dropin_library.cpp)
 OUT_SPQLIOS = os.path.join(HERE, "libtfhe_amd_spqlios.so")  # the reference's FFT plugin symbols (csrc/spqlios_seam.cpp)
+# DIAGNOSTIC build of the same sources with -DTFHE_PROBE (csrc/probe_hooks.h): the blind-rotation kernel stamps s_memtime /
+# s_memrealtime around its CMux loop.  Never loaded by the product or the tests' parity checks; bench.py runs it in a child
+# process to read the shader clock the chip holds UNDER the headline kernel (tools/wave_probe.py)
+OUT_PROBE = os.path.join(HERE, "libtfhe_amd_probe.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SOURCES = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp"), os.path.join(CSRC, "hp_twiddles.cpp"), os.path.join(CSRC, "pool.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "devport.h"),
+DEPS = SOURCES + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "devport.h"), os.path.join(CSRC, "probe_hooks.h"),
                   os.path.join(os.path.dirname(HERE), "include", "tfhe_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
@@ -76,6 +80,13 @@ def build_spqlios(engine_lib=None, out=None, force=False):
     return out
 
 
+def build_probe(force=False):
+    """libtfhe_amd_probe.so (see OUT_PROBE): rebuilt when any kernel source is newer"""
+    if not force and os.path.exists(OUT_PROBE) and all(os.path.getmtime(d) <= os.path.getmtime(OUT_PROBE) for d in DEPS):
+        return OUT_PROBE
+    return build(out=OUT_PROBE, defines=["TFHE_PROBE"])
+
+
 def build(force=False, verbose=False, out=None, defines=()):
     """default: the shipped library.  `out` + `defines`: an experiment build for A/B timing (tools/ab.py),
     never loaded by default"""
@@ -88,6 +99,7 @@ def build(force=False, verbose=False, out=None, defines=()):
     if not force and not stale():
         build_dropin()
         build_spqlios()
+        build_probe()
         return OUT
     cmd = [hipcc()] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + SOURCES + ["-o", OUT]
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -97,6 +109,7 @@ def build(force=False, verbose=False, out=None, defines=()):
         raise RuntimeError("hipcc failed")
     build_dropin(force=True)
     build_spqlios(force=True)
+    build_probe(force=True)
     return OUT
 
 

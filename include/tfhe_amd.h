@@ -78,9 +78,12 @@ int tfhe_amd_device_count(int *count);
 /* "domain:bus:device.function" of the GPU behind an ordinal (hipDeviceGetPCIBusId): ordinals are per process -- a launcher
  * may show every rank ONE device, all of them "device 0" -- the bus id is what tells two GPUs apart; len >= 13 */
 int tfhe_amd_device_pci_bus_id(int device, char *buf, size_t len);
-/* the shader clock (GHz) the chip holds WHILE the work already queued on the context's stream runs: 32 one-wave
- * probes on a second stream stamp s_memtime / s_memrealtime around a sleep of duration_us; median, and optionally
- * min / max over the probes.  Blocks for about duration_us.  Diagnostic only. */
+/* shader clock (GHz) read by 32 one-wave probes on a second stream: s_memtime / s_memrealtime around a sleep of duration_us;
+ * median, and optionally min / max over the probes.  Blocks for about duration_us.  Diagnostic only.  The probes run BESIDE
+ * the work queued on the context's stream only where a CU has a wave slot and registers to spare: the transforms and key
+ * switches leave them, the blind-rotation kernels do not (two waves per SIMD hold all 512 registers) -- the probes then run
+ * after them and read the idle clock (2.4 GHz).  The clock UNDER a blind rotation comes from the probe build of the library
+ * (libtfhe_amd_probe.so, tools/wave_probe.py), which stamps inside the kernel. */
 int tfhe_amd_clock_probe(tfhe_amd_ctx *ctx, int duration_us, double *ghz_median, double *ghz_min, double *ghz_max);
 /* use an existing hipStream_t (passed as void*); NULL = the context's own stream */
 int tfhe_amd_set_stream(tfhe_amd_ctx *ctx, void *hip_stream);

@@ -112,7 +112,7 @@ def test_bench_starts_its_own_ranks_on_emulator(emu_lib):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "strong" and d["n_devices"] == 2
     assert d["sustained"]["steps"] >= 2 and d["sustained"]["seconds"] >= 1.0 and d["sustained"]["step_ms_max"] >= d["sustained"]["step_ms_min"] > 0
-    assert abs(d["sustained"]["shader_clock_ghz"] - 2.4) < 0.01  # (the emulator's nominal clock: 24 "cycles" per 100 MHz tick)
+    assert d["sustained"]["shader_clock_ghz"] is None  # (the probe build exists for the GPU library only)
     assert [(r[0], r[2]) for r in d["ranks"]] == [(0, 3), (1, 2)]
     assert "parent" in d["cpu_baseline"]["measured_by"] and d["cpu_baseline"]["value"] > 0
     assert "GPU-free parent" in d["config"]["launched_by"]
@@ -170,7 +170,7 @@ def test_bench_post_region_sections_on_emulator(emu_lib):
     pc = d["pool_check"]
     assert [m[0] for m in pc["members"]] == [[0], [0, 0]] and all(m[1] > 0 for m in pc["members"]) and pc["identical_to_headline"] is True
     su = d["sustained"]
-    assert su["steps"] >= 2 and su["bootstraps_per_s"] > 0 and su["step_ms_max"] >= su["step_ms_min"] > 0 and su["shader_clock_ghz"] > 0
+    assert su["steps"] >= 2 and su["bootstraps_per_s"] > 0 and su["step_ms_max"] >= su["step_ms_min"] > 0
     f = json.load(open(os.path.join(ROOT, d["detail"])))  # the full record: every stage and line
     assert "child process" in f["other_configs_run"] and f["pool_check"]["pools"][1]["split"] == [1, 1]
     assert f["streamed_schedule"]["roofline"]["bound"] == "hbm" and f["streamed_schedule"]["roofline"]["algorithmic_bytes_per_launch"] == 2 * 16388 + 65536

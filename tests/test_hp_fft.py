@@ -111,6 +111,30 @@ def test_transform_pair_multiplies_polynomials():
 
 
 # ------------------------------------------------------------------ kernels vs restatement
+def check_hp_kernels_wide(lib_path, N, B):
+    """more polynomials than the device keeps workgroups resident (the kernels' workgroups are persistent over the batch and
+    stage their twiddles once): a subset against the restatement, and the duplicated first rows at the far end of the batch"""
+    rs = np.random.RandomState(60 + N)
+    pa, pb = O.hp_twiddles(2 * N)
+    x = np.frombuffer(rs.bytes(B * N * 8), dtype=np.int64).reshape(B, N).copy()
+    x[B - 5:] = x[:5]
+    e = T.Engine(torus_bits=64, n=1, N=N, l=2, Bgbit=8, ks_t=0, lib_path=lib_path)
+    try:
+        spec = e.hp_ifft(x)
+        sub = sorted(set([0, 1, B // 2, B - 6, B - 1]) | set(rs.choice(B, 6, replace=False).tolist()))
+        for b in sub:
+            assert np.array_equal(spec[b], O.hp_ifft(x[b], pa)), f"Real96 iFFT, polynomial {b} of {B}"
+        assert np.array_equal(spec[B - 5:], spec[:5])
+        back = e.hp_fft(spec)
+        for b in sub:
+            assert np.array_equal(back[b], O.hp_fft(spec[b], pb)), f"Real96 FFT, polynomial {b} of {B}"
+        assert np.array_equal(back[B - 5:], back[:5])
+        # FFT(iFFT(x)) returns x up to the transforms' truncations (HP's own round-trip check, very_close)
+        assert np.abs((back - x).astype(np.int64)).max() < 2 ** 16
+    finally:
+        e.close()
+
+
 def check_hp_kernels(lib_path, N, B):
     rs = np.random.RandomState(6)
     pa, pb = O.hp_twiddles(2 * N)
@@ -136,7 +160,14 @@ def test_hp_kernels_emu(emu_lib, N):
     check_hp_kernels(emu_lib, N, B=3)
 
 
+def test_hp_kernels_persistent_loop_emu(emu_lib):
+    """11 polynomials on the emulator's 3 resident workgroups: 4 + 4 + 3"""
+    check_hp_kernels_wide(emu_lib, 2048, B=11)
+    check_hp_kernels_wide(emu_lib, 1024, B=10)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N", [1024, 2048])
 def test_hp_kernels_gpu(gpu_lib, N):
     check_hp_kernels(gpu_lib, N, B=9)
+    check_hp_kernels_wide(gpu_lib, N, B=1301)  # the chip keeps 512 workgroups resident (two per CU): three rounds, the last ragged

@@ -6,8 +6,12 @@ workgroup; the shipped library has none of this):
     python -c "import importlib; B = importlib.import_module('experimental-tfhe_amd.build'); \
                B.build(out='build/ab/lib_probe.so', defines=['TFHE_PROBE'])"
     python tools/wave_probe.py build/ab/lib_probe.so [--batch 4096]
+    python tools/wave_probe.py experimental-tfhe_amd/libtfhe_amd_probe.so --warm-seconds 2 --json-out clock.json --quiet
 
-profiles/r02_wave_balance.txt is this tool's output before and after WaveLds::balance."""
+(build.py also ships that probe build as experimental-tfhe_amd/libtfhe_amd_probe.so.)  The second form is what bench.py runs
+in a child process: back-to-back launches for --warm-seconds (the chip settles its clock under the load), then ONE stamped
+launch: shader clock = sum of d s_memtime / sum of d s_memrealtime x 100 MHz over all waves' CMux loops
+(MI355X_MICROARCH.md, "DVFS give-back" item 6).  profiles/r02_wave_balance.txt is this tool's output before and after WaveLds::balance."""
 import argparse
 import ctypes
 import importlib
@@ -23,7 +27,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("lib")
     ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--warm-seconds", type=float, default=0.0, help="back-to-back launches for this long before the stamped ones")
+    ap.add_argument("--json-out", default=None, help="write {'shader_clock_ghz': ..., 'kernel_ms': ..., ...} of the last stamped launch here")
+    ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args()
+    if a.quiet:
+        sys.stdout = open(os.devnull, "w")
     shard = importlib.import_module("experimental-tfhe_amd.shard")
     cfg = shard.GateConfig()
     job = shard.GateJob(cfg, 0x5446484500000001, device=0, lib_path=os.path.abspath(a.lib))
@@ -33,7 +42,18 @@ def main():
     ev = [eng.event(), eng.event()]
     out = (ctypes.c_ulonglong * 32)()
     eng.lib.tfhe_amd_dbg_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
-    for r in range(3):
+    import json
+    import time
+    warm_launches, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < a.warm_seconds:
+        for _ in range(8):
+            eng._chk(eng.lib.tfhe_amd_bootstrap_woks(eng.ctx, u_d.ptr, 1 << 29, x_d.ptr, a.batch))
+        eng.sync()
+        warm_launches += 8
+    if warm_launches:
+        assert eng.lib.tfhe_amd_dbg_read(out) == 0  # reset the totals the warm launches accumulated
+    record = None
+    for r in range(3 if not a.json_out else 1):
         eng.record(ev[0])
         eng._chk(eng.lib.tfhe_amd_bootstrap_woks(eng.ctx, u_d.ptr, 1 << 29, x_d.ptr, a.batch))
         eng.record(ev[1])
@@ -43,10 +63,17 @@ def main():
         clk, real, waves = out[0], out[1], out[2]
         ghz = clk / real * 0.1  # s_memrealtime ticks at 100 MHz
         per_cmux = clk / waves / cfg.n
+        record = {"shader_clock_ghz": ghz, "kernel_ms": ms, "waves": int(waves), "cycles_per_cmux_per_wave": per_cmux, "batch": a.batch,
+                  "warm_seconds": a.warm_seconds, "warm_launches": warm_launches,
+                  "how": "probe build (-DTFHE_PROBE): s_memtime / s_memrealtime stamped around the CMux loop of every wave of ONE "
+                         "k_blind_rotate launch, after the warm launches; clock = sum of cycles / sum of 100 MHz ticks"}
         print("run %d: %.3f ms  waves %d  shader clock %.3f GHz  wave lifetime %.3f ms  cycles per CMux per wave %.0f" % (
             r, ms, waves, ghz, real / waves / 1e5, per_cmux))
         nw = max(1, waves // 8)
         print("    in-loop lifetime by wave index (ms):", " ".join("%.3f" % (out[16 + k] / nw / 1e5) for k in range(8)))
+    if a.json_out:
+        with open(a.json_out, "w") as f:
+            json.dump(record, f)
     # workgroup schedule of the last launch: residency per CU and the gaps
     wg = (ctypes.c_ulonglong * 4096)()
     eng.lib.tfhe_amd_dbg_read_wg.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
