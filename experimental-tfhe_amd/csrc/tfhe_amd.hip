@@ -317,28 +317,6 @@ int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
     return launch_fft_w<TOUT, LOGN, FFT_WAVES>(c, out_d, in_d, batch);
 }
 
-// Real96 transforms: persistent workgroups (the stage twiddles are staged into LDS once per workgroup)
-template <int LOGN>
-int launch_hp_ifft(tfhe_amd_ctx *c, HpCplx *out_d, const int64_t *in_d, const HpCplx *pw, int batch) {
-    auto kernel = k_hp_ifft<LOGN>;
-    if (int rc = set_lds(c, kernel, HpGeom<LOGN>::lds_bytes)) return rc;
-    int grid = 0;
-    if (int rc = persistent_grid(c, kernel, 256, HpGeom<LOGN>::lds_bytes, batch, &grid)) return rc;
-    TFHE_LAUNCH((k_hp_ifft<LOGN>), dim3(grid), dim3(256), HpGeom<LOGN>::lds_bytes, c->stream, out_d, in_d, pw, batch);
-    HIPCHECK(c, hipGetLastError());
-    return TFHE_AMD_OK;
-}
-template <int LOGN>
-int launch_hp_fft(tfhe_amd_ctx *c, int64_t *out_d, const HpCplx *in_d, const HpCplx *pwbar, int batch) {
-    auto kernel = k_hp_fft<LOGN>;
-    if (int rc = set_lds(c, kernel, HpGeom<LOGN>::lds_bytes)) return rc;
-    int grid = 0;
-    if (int rc = persistent_grid(c, kernel, 256, HpGeom<LOGN>::lds_bytes, batch, &grid)) return rc;
-    TFHE_LAUNCH((k_hp_fft<LOGN>), dim3(grid), dim3(256), HpGeom<LOGN>::lds_bytes, c->stream, out_d, in_d, pwbar, batch);
-    HIPCHECK(c, hipGetLastError());
-    return TFHE_AMD_OK;
-}
-
 void drop_streamed_graph(tfhe_amd_ctx *c) {
     if (c->sg.exec) (void)hipGraphExecDestroy((hipGraphExec_t)c->sg.exec);
     c->sg.exec = nullptr;
@@ -1414,7 +1392,12 @@ int tfhe_amd_hp_ifft(tfhe_amd_ctx *c, uint64_t *out_d, const int64_t *in_d, int 
     if (batch == 0) return TFHE_AMD_OK;
     if (int rc = hp_prepare(c)) return rc;
     const HpCplx *pw = (const HpCplx *)c->hp_tw_d;
-    return c->logn == 10 ? launch_hp_ifft<10>(c, (HpCplx *)out_d, in_d, pw, batch) : launch_hp_ifft<11>(c, (HpCplx *)out_d, in_d, pw, batch);
+    if (c->logn == 10)
+        TFHE_LAUNCH((k_hp_ifft<10>), dim3(batch), dim3(256), HpGeom<10>::lds_bytes, c->stream, (HpCplx *)out_d, in_d, pw, batch);
+    else
+        TFHE_LAUNCH((k_hp_ifft<11>), dim3(batch), dim3(256), HpGeom<11>::lds_bytes, c->stream, (HpCplx *)out_d, in_d, pw, batch);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
 }
 int tfhe_amd_hp_fft(tfhe_amd_ctx *c, int64_t *out_d, const uint64_t *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
@@ -1422,7 +1405,12 @@ int tfhe_amd_hp_fft(tfhe_amd_ctx *c, int64_t *out_d, const uint64_t *in_d, int b
     if (batch == 0) return TFHE_AMD_OK;
     if (int rc = hp_prepare(c)) return rc;
     const HpCplx *pwbar = (const HpCplx *)c->hp_tw_d + 2 * c->p.N;
-    return c->logn == 10 ? launch_hp_fft<10>(c, out_d, (const HpCplx *)in_d, pwbar, batch) : launch_hp_fft<11>(c, out_d, (const HpCplx *)in_d, pwbar, batch);
+    if (c->logn == 10)
+        TFHE_LAUNCH((k_hp_fft<10>), dim3(batch), dim3(256), HpGeom<10>::lds_bytes, c->stream, out_d, (const HpCplx *)in_d, pwbar, batch);
+    else
+        TFHE_LAUNCH((k_hp_fft<11>), dim3(batch), dim3(256), HpGeom<11>::lds_bytes, c->stream, out_d, (const HpCplx *)in_d, pwbar, batch);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
 }
 
 }  // extern "C"

@@ -1780,9 +1780,10 @@ TFHE_GLOBAL void __launch_bounds__(256)
 // ------------------------------------- Real96 high-precision anticyclic transforms
 // high-precision-anticyclic-fft/src/code.cpp ("HP"): the same radix-2 structure as spqlios, on
 // 128-bit fixed point (a Real96 is a two's-complement integer v standing for v / 2^64, HP:17-40),
-// n = 2N, N/2 complex points.  One 256-thread workgroup per polynomial at a time, points in LDS.
-// Integer arithmetic: results are exact functions of the inputs, so parity with the CPU restatement
-// is equality.
+// n = 2N, N/2 complex points.  One 256-thread workgroup per polynomial, points in LDS (32 B each:
+// 32 KB at N = 2048), one workgroup barrier per stage, twiddles read from the [n] table in global
+// memory (128 KB at n = 4096: L2-resident).  Integer arithmetic: results are exact functions of
+// the inputs, so parity with the CPU restatement is equality.
 typedef unsigned __int128 u128;
 struct HpCplx {
     u128 re, im;
@@ -1811,226 +1812,80 @@ TFHE_DEVICE HpCplx hp_cmul(const HpCplx &a, const HpCplx &w) {
     r.im = hp_intmul(a.re, w.im) + hp_intmul(a.im, w.re);
     return r;
 }
-// Round-5 form (the round-2 one kept every stage behind its own barrier and fetched each butterfly's twiddle from global
-// memory: 164 KB of L2 reads per polynomial against 48 KB of algorithmic bytes):
-//   * TWO radix-2 stages per pass in registers: a work-item owns the 4 points base + {0, q, 2q, 3q} of the stage pair
-//     (half sizes 2q and q), so N = 2048 takes 5 passes (4 LDS round trips) instead of 10 stages and 11 round trips; every
-//     output point is the same expression of the same operands as in HP:391-512 -- the order of independent butterflies is
-//     the only thing that changes, and integer arithmetic does not see it;
-//   * the first pass reads global memory (twist fused, iFFT) and the last pass writes it (twist + >> fused, FFT);
-//   * the stage twiddles -- only the multiples of 4 of the [n] table are ever used by a stage: N/4 entries, 16 KB at
-//     N = 2048 -- are staged into LDS once per workgroup, and workgroups are persistent over the batch;
-//   * points in LDS as two planes (re, im) of 16-byte slots, slot(i) = i + (i >> 2): conflict-free ds_*_b128 for the
-//     last two passes (q = 4, 1), at most 2-way for the others.
 template <int LOGN>
 struct HpGeom {
     static constexpr int N = 1 << LOGN, NS4 = N / 2, n = 2 * N;
-    static constexpr int TW = NS4 / 2;                        // stage twiddles T[k] = table[4 k]
-    static constexpr int SLOTS = NS4 + NS4 / 4;               // padded plane
-    static constexpr size_t lds_bytes = (size_t)16 * (2 * SLOTS + 2 * TW);
-    static constexpr int STAGES = LOGN - 1;                   // log2(NS4)
+    static constexpr size_t lds_bytes = sizeof(HpCplx) * NS4;
 };
-TFHE_DEVICE int hp_slot(int i) { return i + (i >> 2); }
-struct HpLds {
-    u128 *re, *im, *twr, *twi;
-};
-template <int LOGN>
-TFHE_DEVICE HpLds hp_lds(unsigned char *smem) {
-    using G = HpGeom<LOGN>;
-    HpLds l;
-    l.re = reinterpret_cast<u128 *>(smem);
-    l.im = l.re + G::SLOTS;
-    l.twr = l.im + G::SLOTS;
-    l.twi = l.twr + G::TW;
-    return l;
-}
-TFHE_DEVICE HpCplx hp_tw(const HpLds &l, int k) {
-    HpCplx w;
-    w.re = l.twr[k];
-    w.im = l.twi[k];
-    return w;
-}
-TFHE_DEVICE HpCplx hp_add(const HpCplx &a, const HpCplx &b) {
-    HpCplx r;
-    r.re = a.re + b.re;
-    r.im = a.im + b.im;
-    return r;
-}
-TFHE_DEVICE HpCplx hp_sub(const HpCplx &a, const HpCplx &b) {
-    HpCplx r;
-    r.re = a.re - b.re;
-    r.im = a.im - b.im;
-    return r;
-}
-TFHE_DEVICE HpCplx hp_ld(const HpLds &l, int i) {
-    HpCplx v;
-    v.re = l.re[hp_slot(i)];
-    v.im = l.im[hp_slot(i)];
-    return v;
-}
-TFHE_DEVICE void hp_st(const HpLds &l, int i, const HpCplx &v) {
-    l.re[hp_slot(i)] = v.re;
-    l.im[hp_slot(i)] = v.im;
-}
-
-// iFFT (HP:391-444): Torus64 coefficients -> N/2 complex Real96 values.  Decimation in frequency: stage half sizes
-// NS4/2, NS4/4, ..., 1; a stage of half size h multiplies (t1 - t2) by table[(2 NS4 / h) off] = T[(NS4 / 2h) off].
-// One pass = the stages of half sizes 2Q and Q on the points base + {0, Q, 2Q, 3Q}, base = 4Q (g / Q) + g % Q.
-template <int LOGN, int Q, bool FIRST, bool LAST>
-TFHE_DEVICE void hp_ifft_pass2(const HpLds &l, HpCplx *__restrict__ o, const int64_t *__restrict__ p, const HpCplx *__restrict__ pw, int tid) {
-    using G = HpGeom<LOGN>;
-    constexpr int NS4 = G::NS4, KA = NS4 / (4 * Q), KB = 2 * KA;
-    for (int g = tid; g < NS4 / 4; g += 256) {
-        const int off = g & (Q - 1), base = ((g - off) << 2) + off;
-        HpCplx x[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = base + k * Q;
-            if (FIRST) {  // interpret the coefficients as real and imaginary parts and multiply by omega^j (HP:407-408)
-                HpCplx v;
-                v.re = (u128)(__int128)p[j];  // t64tor96, HP:184-189
-                v.im = (u128)(__int128)p[j + NS4];
-                x[k] = hp_cmul(v, pw[j]);
-            } else {
-                x[k] = hp_ld(l, j);
-            }
-        }
-        const HpCplx y0 = hp_add(x[0], x[2]), y2 = hp_cmul(hp_sub(x[0], x[2]), hp_tw(l, KA * off));
-        const HpCplx y1 = hp_add(x[1], x[3]), y3 = hp_cmul(hp_sub(x[1], x[3]), hp_tw(l, KA * (off + Q)));
-        const HpCplx wb = hp_tw(l, KB * off);
-        const HpCplx z[4] = {hp_add(y0, y1), hp_cmul(hp_sub(y0, y1), wb), hp_add(y2, y3), hp_cmul(hp_sub(y2, y3), wb)};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (LAST)
-                o[base + k * Q] = z[k];
-            else
-                hp_st(l, base + k * Q, z[k]);
-        }
-    }
-}
-// the lone last stage (half size 1) of a transform with an odd number of stages (N = 1024)
-template <int LOGN, bool LAST>
-TFHE_DEVICE void hp_ifft_pass1(const HpLds &l, HpCplx *__restrict__ o, int tid) {
-    constexpr int NS4 = HpGeom<LOGN>::NS4;
-    for (int g = tid; g < NS4 / 2; g += 256) {
-        const HpCplx t1 = hp_ld(l, 2 * g), t2 = hp_ld(l, 2 * g + 1);
-        const HpCplx s = hp_add(t1, t2), d = hp_cmul(hp_sub(t1, t2), hp_tw(l, 0));
-        if (LAST) {
-            o[2 * g] = s;
-            o[2 * g + 1] = d;
-        } else {
-            hp_st(l, 2 * g, s);
-            hp_st(l, 2 * g + 1, d);
-        }
-    }
-}
-template <int LOGN, int Q, bool FIRST>
-TFHE_DEVICE void hp_ifft_passes(const HpLds &l, HpCplx *__restrict__ o, const int64_t *__restrict__ p, const HpCplx *__restrict__ pw, int tid) {
-    if constexpr (Q >= 1) {
-        constexpr bool last = (Q == 1);  // half sizes 2 and 1: nothing follows
-        hp_ifft_pass2<LOGN, Q, FIRST, last>(l, o, p, pw, tid);
-        if constexpr (!last) {
-            __syncthreads();
-            if constexpr (Q == 2)
-                hp_ifft_pass1<LOGN, true>(l, o, tid);  // half size 1 is left over
-            else
-                hp_ifft_passes<LOGN, Q / 4, false>(l, o, p, pw, tid);
-        }
-    }
-}
+// iFFT (HP:391-444): Torus64 coefficients -> N/2 complex Real96 values
 template <int LOGN>
 TFHE_GLOBAL void __launch_bounds__(256)
     k_hp_ifft(HpCplx *__restrict__ out, const int64_t *__restrict__ in, const HpCplx *__restrict__ pw, int batch) {
     using G = HpGeom<LOGN>;
+    constexpr int NS4 = G::NS4;
     TFHE_DYN_LDS(smem);
-    const HpLds l = hp_lds<LOGN>(smem);
-    const int tid = threadIdx.x;
-    for (int k = tid; k < G::TW; k += 256) {
-        const HpCplx w = pw[4 * k];
-        l.twr[k] = w.re;
-        l.twi[k] = w.im;
+    HpCplx *buf = reinterpret_cast<HpCplx *>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= batch) return;
+    const int64_t *p = in + (size_t)b * G::N;
+    for (int j = tid; j < NS4; j += 256) {
+        HpCplx v;
+        v.re = (u128)(__int128)p[j];  // t64tor96, HP:184-189
+        v.im = (u128)(__int128)p[j + NS4];
+        buf[j] = hp_cmul(v, pw[j]);
     }
     __syncthreads();
-    for (int b = blockIdx.x; b < batch; b += gridDim.x) {
-        hp_ifft_passes<LOGN, G::NS4 / 4, true>(l, out + (size_t)b * G::NS4, in + (size_t)b * G::N, pw, tid);
-        __syncthreads();  // the next polynomial's first pass overwrites the planes
-    }
-}
-
-// FFT (HP:446-512): N/2 complex Real96 values -> Torus64 coefficients, divided by N/2 (">> 10", HP:499-500).  Decimation in
-// time: stage half sizes 1, 2, ..., NS4/2; a stage multiplies t2 by tablebar[(2 NS4 / h) off] before the butterfly.
-// One pass = the stages of half sizes Q and 2Q on the points base + {0, Q, 2Q, 3Q}.
-template <int LOGN, int Q, bool FIRST, bool LAST>
-TFHE_DEVICE void hp_fft_pass2(const HpLds &l, int64_t *__restrict__ o, const HpCplx *__restrict__ p, const HpCplx *__restrict__ pwbar, int tid) {
-    using G = HpGeom<LOGN>;
-    constexpr int NS4 = G::NS4, KA = NS4 / (4 * Q), KB = 2 * KA;
-    for (int g = tid; g < NS4 / 4; g += 256) {
-        const int off = g & (Q - 1), base = ((g - off) << 2) + off;
-        HpCplx x[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = FIRST ? p[base + k * Q] : hp_ld(l, base + k * Q);
-        const HpCplx wb = hp_tw(l, KB * off);
-        const HpCplx t1 = hp_cmul(x[1], wb), t3 = hp_cmul(x[3], wb);
-        const HpCplx y0 = hp_add(x[0], t1), y1 = hp_sub(x[0], t1), y2 = hp_add(x[2], t3), y3 = hp_sub(x[2], t3);
-        const HpCplx u2 = hp_cmul(y2, hp_tw(l, KA * off)), u3 = hp_cmul(y3, hp_tw(l, KA * (off + Q)));
-        const HpCplx z[4] = {hp_add(y0, u2), hp_add(y1, u3), hp_sub(y0, u2), hp_sub(y1, u3)};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = base + k * Q;
-            if (LAST) {  // multiply by omegabar^j and divide by N/2 (HP:497-501)
-                const HpCplx v = hp_cmul(z[k], pwbar[j]);
-                o[j] = (int64_t)(uint64_t)(v.re >> (LOGN - 1));
-                o[j + NS4] = (int64_t)(uint64_t)(v.im >> (LOGN - 1));
-            } else {
-                hp_st(l, j, z[k]);
-            }
+    for (int nn = NS4; nn >= 2; nn >>= 1) {
+        const int halfnn = nn >> 1, step = 2 * (NS4 / halfnn);
+        for (int bf = tid; bf < NS4 / 2; bf += 256) {
+            const int off = bf & (halfnn - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + halfnn;
+            const HpCplx t1 = buf[i1], t2 = buf[i2];
+            HpCplx sum, dif;
+            sum.re = t1.re + t2.re;
+            sum.im = t1.im + t2.im;
+            dif.re = t1.re - t2.re;
+            dif.im = t1.im - t2.im;
+            buf[i1] = sum;
+            buf[i2] = hp_cmul(dif, pw[step * off]);
         }
-    }
-}
-// the lone first stage (half size 1) of a transform with an odd number of stages (N = 1024): reads global memory
-template <int LOGN>
-TFHE_DEVICE void hp_fft_pass1_first(const HpLds &l, const HpCplx *__restrict__ p, int tid) {
-    constexpr int NS4 = HpGeom<LOGN>::NS4;
-    for (int g = tid; g < NS4 / 2; g += 256) {
-        const HpCplx t1 = p[2 * g], t2 = hp_cmul(p[2 * g + 1], hp_tw(l, 0));
-        hp_st(l, 2 * g, hp_add(t1, t2));
-        hp_st(l, 2 * g + 1, hp_sub(t1, t2));
-    }
-}
-template <int LOGN, int Q, bool FIRST>
-TFHE_DEVICE void hp_fft_passes(const HpLds &l, int64_t *__restrict__ o, const HpCplx *__restrict__ p, const HpCplx *__restrict__ pwbar, int tid) {
-    constexpr int NS4 = HpGeom<LOGN>::NS4;
-    constexpr bool last = (4 * Q == NS4);  // half sizes NS4/4 and NS4/2: nothing follows
-    hp_fft_pass2<LOGN, Q, FIRST, last>(l, o, p, pwbar, tid);
-    if constexpr (!last) {
         __syncthreads();
-        hp_fft_passes<LOGN, 4 * Q, false>(l, o, p, pwbar, tid);
     }
+    HpCplx *o = out + (size_t)b * NS4;
+    for (int j = tid; j < NS4; j += 256) o[j] = buf[j];
 }
+// FFT (HP:446-512): N/2 complex Real96 values -> Torus64 coefficients, divided by N/2 (">> 10", HP:499-500)
 template <int LOGN>
 TFHE_GLOBAL void __launch_bounds__(256)
     k_hp_fft(int64_t *__restrict__ out, const HpCplx *__restrict__ in, const HpCplx *__restrict__ pwbar, int batch) {
     using G = HpGeom<LOGN>;
+    constexpr int NS4 = G::NS4;
     TFHE_DYN_LDS(smem);
-    const HpLds l = hp_lds<LOGN>(smem);
-    const int tid = threadIdx.x;
-    for (int k = tid; k < G::TW; k += 256) {
-        const HpCplx w = pwbar[4 * k];
-        l.twr[k] = w.re;
-        l.twi[k] = w.im;
-    }
+    HpCplx *buf = reinterpret_cast<HpCplx *>(smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= batch) return;
+    const HpCplx *p = in + (size_t)b * NS4;
+    for (int j = tid; j < NS4; j += 256) buf[j] = p[j];
     __syncthreads();
-    for (int b = blockIdx.x; b < batch; b += gridDim.x) {
-        const HpCplx *p = in + (size_t)b * G::NS4;
-        int64_t *o = out + (size_t)b * G::N;
-        if constexpr (G::STAGES & 1) {  // odd number of stages: half size 1 first, then the pairs (2, 4), (8, 16), ...
-            hp_fft_pass1_first<LOGN>(l, p, tid);
-            __syncthreads();
-            hp_fft_passes<LOGN, 2, false>(l, o, p, pwbar, tid);
-        } else {
-            hp_fft_passes<LOGN, 1, true>(l, o, p, pwbar, tid);
+    for (int nn = 2; nn <= NS4; nn <<= 1) {
+        const int halfnn = nn >> 1, step = 2 * (NS4 / halfnn);
+        for (int bf = tid; bf < NS4 / 2; bf += 256) {
+            const int off = bf & (halfnn - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + halfnn;
+            const HpCplx t1 = buf[i1], t2 = hp_cmul(buf[i2], pwbar[step * off]);
+            HpCplx sum, dif;
+            sum.re = t1.re + t2.re;
+            sum.im = t1.im + t2.im;
+            dif.re = t1.re - t2.re;
+            dif.im = t1.im - t2.im;
+            buf[i1] = sum;
+            buf[i2] = dif;
         }
         __syncthreads();
+    }
+    int64_t *o = out + (size_t)b * G::N;
+    for (int j = tid; j < NS4; j += 256) {
+        const HpCplx v = hp_cmul(buf[j], pwbar[j]);
+        o[j] = (int64_t)(uint64_t)(v.re >> (LOGN - 1));
+        o[j + NS4] = (int64_t)(uint64_t)(v.im >> (LOGN - 1));
     }
 }
 

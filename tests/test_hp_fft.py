@@ -112,8 +112,8 @@ def test_transform_pair_multiplies_polynomials():
 
 # ------------------------------------------------------------------ kernels vs restatement
 def check_hp_kernels_wide(lib_path, N, B):
-    """more polynomials than the device keeps workgroups resident (the kernels' workgroups are persistent over the batch and
-    stage their twiddles once): a subset against the restatement, and the duplicated first rows at the far end of the batch"""
+    """a batch of many polynomials (one workgroup each): a subset against the restatement, the duplicated first rows at the far
+    end of the batch, and the round trip on all of them"""
     rs = np.random.RandomState(60 + N)
     pa, pb = O.hp_twiddles(2 * N)
     x = np.frombuffer(rs.bytes(B * N * 8), dtype=np.int64).reshape(B, N).copy()
@@ -160,8 +160,7 @@ def test_hp_kernels_emu(emu_lib, N):
     check_hp_kernels(emu_lib, N, B=3)
 
 
-def test_hp_kernels_persistent_loop_emu(emu_lib):
-    """11 polynomials on the emulator's 3 resident workgroups: 4 + 4 + 3"""
+def test_hp_kernels_wider_batch_emu(emu_lib):
     check_hp_kernels_wide(emu_lib, 2048, B=11)
     check_hp_kernels_wide(emu_lib, 1024, B=10)
 
@@ -170,4 +169,4 @@ def test_hp_kernels_persistent_loop_emu(emu_lib):
 @pytest.mark.parametrize("N", [1024, 2048])
 def test_hp_kernels_gpu(gpu_lib, N):
     check_hp_kernels(gpu_lib, N, B=9)
-    check_hp_kernels_wide(gpu_lib, N, B=1301)  # the chip keeps 512 workgroups resident (two per CU): three rounds, the last ragged
+    check_hp_kernels_wide(gpu_lib, N, B=1301)
