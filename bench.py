@@ -326,7 +326,8 @@ def compact_line(full, detail_path):
                 "probe_build_kernel_ms": (round(clk["kernel_ms"], 3) if "kernel_ms" in clk else None)}
 
     def b_pool(pc):
-        return {"members": [[m["devices"], round(m["bootstraps_per_s"], 1)] for m in pc["pools"]], "pcie_included": True,
+        return {"[devices, samples per call, bootstraps/s]": [[m["devices"], m.get("samples_per_call"), round(m["bootstraps_per_s"], 1)] for m in pc["pools"]],
+                "pcie_included": True,
                 "identical_to_headline": all(m["identical_to_headline"] for m in pc["pools"])}
 
     def b_c3(c3):
@@ -767,26 +768,29 @@ def main():
     pool_check = None
     if want_pool and job.bk_host is not None:
         pool_check = {"entry_point": "tfhe_amd_pool_load_keys_torus + tfhe_amd_pool_bootstrap_host", "pools": []}
-        lists = [[device], [device, device]]
+        lists = [([device], 1), ([device, device], 1), ([device], 4)]  # (members, how many times the batch per call)
         if a.pool_devices:
-            lists.append(list(range(T.device_count(a.lib))) if a.pool_devices == "all" else [int(v) for v in a.pool_devices.split(",")])
-        for devs in lists:
+            lists.append((list(range(T.device_count(a.lib))) if a.pool_devices == "all" else [int(v) for v in a.pool_devices.split(",")], 4))
+        for devs, times in lists:
             try:
                 pool = T.Pool(devs, torus_bits=32, n=cfg.n, N=cfg.N, l=cfg.l, Bgbit=cfg.Bgbit, ks_t=cfg.ks_t, ks_basebit=cfg.ks_basebit,
                               lib_path=a.lib)
                 tk = time.perf_counter()
                 pool.load_keys_torus(job.bk_host, job.ks_host)
                 tk = time.perf_counter() - tk
-                got = pool.bootstrap(mu, x_host)  # warm-up: staging buffers, kernel selection
+                xp = x_host if times == 1 else np.tile(x_host, (times, 1))
+                got = pool.bootstrap(mu, xp)  # warm-up: staging buffers, streams, kernel selection
                 tp, reps_p = time.perf_counter(), max(1, min(reps, 3))
                 for _ in range(reps_p):
-                    got = pool.bootstrap(mu, x_host)
+                    got = pool.bootstrap(mu, xp)
                 tp = (time.perf_counter() - tp) / reps_p
                 counts, secs = pool.last_split()
-                same = bool(np.array_equal(got, out_all))
+                same = bool(np.array_equal(got, out_all if times == 1 else np.tile(out_all, (times, 1))))
                 pool_check["pools"].append({"devices": devs, "pci": [T.device_pci_bus_id(d, a.lib) for d in devs], "key_upload_s": tk,
-                                            "bootstraps_per_s": B / tp, "ms_per_call": 1e3 * tp, "split": counts, "member_seconds": secs,
-                                            "identical_to_headline": same})
+                                            "samples_per_call": B * times, "bootstraps_per_s": B * times / tp, "ms_per_call": 1e3 * tp,
+                                            "split": counts, "member_seconds": secs, "identical_to_headline": same,
+                                            "pipelined": "slices of >= 4096 samples go as chunks of 2048: kernels back to back on the member's stream, copies in / out on two more"})
+                del xp, got
                 pool.close()
                 if not same:
                     extras_ok = False

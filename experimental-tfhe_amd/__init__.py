@@ -19,6 +19,7 @@ DEFAULT_LIB = os.path.join(HERE, "libtfhe_amd.so")
 
 OK, ERR_PARAM, ERR_DEVICE, ERR_STATE, ERR_ALLOC = range(5)
 OPT_KS_GATHER, OPT_STREAMED_GRAPH, OPT_BR_SPLIT = 2, 4, 5
+POOL_OPT_CHUNK_ROWS = 1
 
 # every symbol include/tfhe_amd.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
@@ -42,11 +43,13 @@ ABI_SYMBOLS = [
     "tfhe_amd_keygen_binary", "tfhe_amd_lwe_encrypt32", "tfhe_amd_lwe_phase32",
     "tfhe_amd_keygen_bk_torus32", "tfhe_amd_keygen_bk_torus64", "tfhe_amd_keygen_ks32",
     "tfhe_amd_device_count", "tfhe_amd_device_pci_bus_id", "tfhe_amd_clock_probe",
+    "tfhe_amd_memcpy_h2d_async", "tfhe_amd_memcpy_d2h_async", "tfhe_amd_stream_create", "tfhe_amd_stream_sync", "tfhe_amd_stream_destroy",
+    "tfhe_amd_event_sync", "tfhe_amd_stream_wait_event",
     "tfhe_amd_load_keyswitch_key_d", "tfhe_amd_keyswitch_key_bytes", "tfhe_amd_keyswitch_key_export",
     "tfhe_amd_gsw_packed_bytes", "tfhe_amd_gsw_export_packed", "tfhe_amd_gsw_from_packed",
     "tfhe_amd_pool_create", "tfhe_amd_pool_destroy", "tfhe_amd_pool_last_error", "tfhe_amd_pool_size", "tfhe_amd_pool_device",
     "tfhe_amd_pool_ctx", "tfhe_amd_pool_load_keys", "tfhe_amd_pool_load_keys_torus", "tfhe_amd_pool_bootstrap_host",
-    "tfhe_amd_pool_bootstrap_woks_host", "tfhe_amd_pool_keyswitch_host", "tfhe_amd_pool_last_split",
+    "tfhe_amd_pool_bootstrap_woks_host", "tfhe_amd_pool_keyswitch_host", "tfhe_amd_pool_last_split", "tfhe_amd_pool_set_option",
     "tfhe_amd_cb_pool_create", "tfhe_amd_cb_pool_destroy", "tfhe_amd_cb_pool_last_error", "tfhe_amd_cb_pool_size",
     "tfhe_amd_cb_pool_member", "tfhe_amd_cb_pool_load_preks", "tfhe_amd_cb_pool_load_bk_fft", "tfhe_amd_cb_pool_load_bk_torus",
     "tfhe_amd_cb_pool_load_privks_plane", "tfhe_amd_cb_pool_circuit_bootstrap_host",
@@ -162,6 +165,13 @@ def load_library(path=None):
     lib.tfhe_amd_keygen_bk_torus64.argtypes = list(lib.tfhe_amd_keygen_bk_torus32.argtypes)
     lib.tfhe_amd_keygen_ks32.argtypes = [i32p, i32p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_double,
                                          C.c_uint64, C.c_uint64]
+    lib.tfhe_amd_memcpy_h2d_async.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.tfhe_amd_memcpy_d2h_async.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.tfhe_amd_stream_create.argtypes = [vp, C.POINTER(vp)]
+    lib.tfhe_amd_stream_sync.argtypes = [vp, vp]
+    lib.tfhe_amd_stream_destroy.argtypes = [vp, vp]
+    lib.tfhe_amd_event_sync.argtypes = [vp, vp]
+    lib.tfhe_amd_stream_wait_event.argtypes = [vp, vp]
     lib.tfhe_amd_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     lib.tfhe_amd_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.tfhe_amd_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
@@ -188,6 +198,7 @@ def load_library(path=None):
     lib.tfhe_amd_pool_bootstrap_woks_host.argtypes = [vp, i32p, C.c_int32, i32p, C.c_int]
     lib.tfhe_amd_pool_keyswitch_host.argtypes = [vp, i32p, i32p, C.c_int]
     lib.tfhe_amd_pool_last_split.argtypes = [vp, ip, C.POINTER(C.c_double)]
+    lib.tfhe_amd_pool_set_option.argtypes = [vp, C.c_int, C.c_int]
     lib.tfhe_amd_cb_pool_create.argtypes = [C.POINTER(CbParams), ip, C.c_int, C.POINTER(vp)]
     lib.tfhe_amd_cb_pool_destroy.argtypes = [vp]
     lib.tfhe_amd_cb_pool_destroy.restype = None
@@ -705,6 +716,10 @@ class Pool:
 
     def keyswitch(self, x):
         return self._rows(self.lib.tfhe_amd_pool_keyswitch_host, x, self.params.N + 1, self.params.ks_n_out + 1)
+
+    def set_chunk_rows(self, rows):
+        """rows per chunk of the pipelined form (slices of >= 2 x rows are cut into chunks on two streams); 0 = never"""
+        self._chk(self.lib.tfhe_amd_pool_set_option(self.pool, POOL_OPT_CHUNK_ROWS, int(rows)))
 
     def last_split(self):
         m = len(self.devices)

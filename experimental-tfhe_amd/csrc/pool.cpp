@@ -7,8 +7,13 @@
 // per thread, and a thread that only ever serves one device never switches -- and its own pinned staging buffers;
 // the caller's keys are uploaded once to every member (key ownership as CB/lwe_functions.cpp:287-316: the caller keeps
 // the host key); a call cuts its batch into contiguous slices (experimental-tfhe_amd/shard.py's rule), every member runs
-// copy in -> launch -> copy out on its slice, and nothing is exchanged between devices.
+// copy in -> launch -> copy out on its slice, and nothing is exchanged between devices.  Inside a member a long slice is cut
+// into chunks whose kernels run back to back on the context's stream while a second stream copies the next chunk in and a
+// third copies the previous one out (three sets of pinned staging buffers, events between the streams): the host-array
+// rate approaches the device-resident one.
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -78,7 +83,17 @@ class Worker {
 // pinned host + device staging of one member, grown on demand through the member's own context
 struct Staging {
     void *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
-    size_t in_bytes = 0, out_bytes = 0;
+    void *d_mid = nullptr;  // intermediate of a two-kernel operation (blind rotation -> key switch), owned here so that two sets can be in flight
+    size_t in_bytes = 0, out_bytes = 0, mid_bytes = 0;
+    int ensure_mid(tfhe_amd_ctx *c, size_t need) {
+        if (mid_bytes >= need) return TFHE_AMD_OK;
+        if (d_mid) tfhe_amd_free(c, d_mid);
+        d_mid = nullptr;
+        mid_bytes = 0;
+        if (int rc = tfhe_amd_malloc(c, &d_mid, need)) return rc;
+        mid_bytes = need;
+        return TFHE_AMD_OK;
+    }
     int ensure(tfhe_amd_ctx *c, size_t in_need, size_t out_need) {
         if (in_bytes < in_need) {
             if (h_in) tfhe_amd_host_free(c, h_in);
@@ -105,10 +120,123 @@ struct Staging {
         if (h_out) tfhe_amd_host_free(c, h_out);
         if (d_in) tfhe_amd_free(c, d_in);
         if (d_out) tfhe_amd_free(c, d_out);
-        h_in = h_out = d_in = d_out = nullptr;
-        in_bytes = out_bytes = 0;
+        if (d_mid) tfhe_amd_free(c, d_mid);
+        h_in = h_out = d_in = d_out = d_mid = nullptr;
+        in_bytes = out_bytes = mid_bytes = 0;
     }
 };
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// rows of one chunk of the pipelined form: below 2 x this a slice goes as one piece (the blind rotation needs ~2048 samples
+// per launch for its full rate: 2 waves per SIMD on every CU).  TFHE_AMD_POOL_OPT_CHUNK_ROWS changes it per pool.
+constexpr int DEFAULT_CHUNK_ROWS = 2048;
+
+// Pipelined copy in -> launch -> copy out of rows [lo, hi) inside ONE context: the kernels of all chunks back to back on the
+// context's own stream (exactly the device-resident loop), copies in on a second stream, copies out on a third, tied by events;
+// three staging sets, so that while chunk k computes, chunk k + 1 is already queued behind it (copied in, kernels enqueued)
+// and chunk k - 1 is being copied out and scattered by this thread.  (Round 5 measured the simpler form -- whole chunks
+// alternating on two streams -- first: the key switch of chunk k then waits for a CU behind the blind rotation of chunk k + 1,
+// which has taken every CU's LDS, and the host learns of chunk k a whole chunk late: 0.93 of the resident rate instead of ~1.)
+// launch(set, d_out, d_in, rows) issues the kernels on the context's current stream and may use set.d_mid; it must not touch
+// the context's own scratch.
+constexpr int SETS = 3;
+struct Pipe {
+    Staging st[SETS];
+    void *ev_in[SETS] = {nullptr, nullptr, nullptr}, *ev_done[SETS] = {nullptr, nullptr, nullptr}, *ev_out[SETS] = {nullptr, nullptr, nullptr};
+    void *s_in = nullptr, *s_out = nullptr;
+    int prepare(tfhe_amd_ctx *c, size_t in_need, size_t out_need, size_t mid_need) {
+        for (int s = 0; s < SETS; s++) {
+            if (int rc = st[s].ensure(c, in_need, out_need)) return rc;
+            if (mid_need)
+                if (int rc = st[s].ensure_mid(c, mid_need)) return rc;
+            if (!ev_in[s]) {
+                if (int rc = tfhe_amd_event_create(c, &ev_in[s])) return rc;
+                if (int rc = tfhe_amd_event_create(c, &ev_done[s])) return rc;
+                if (int rc = tfhe_amd_event_create(c, &ev_out[s])) return rc;
+            }
+        }
+        if (!s_in)
+            if (int rc = tfhe_amd_stream_create(c, &s_in)) return rc;
+        if (!s_out)
+            if (int rc = tfhe_amd_stream_create(c, &s_out)) return rc;
+        return TFHE_AMD_OK;
+    }
+    void release(tfhe_amd_ctx *c) {
+        for (int s = 0; s < SETS; s++) {
+            st[s].release(c);
+            if (ev_in[s]) tfhe_amd_event_destroy(c, ev_in[s]);
+            if (ev_done[s]) tfhe_amd_event_destroy(c, ev_done[s]);
+            if (ev_out[s]) tfhe_amd_event_destroy(c, ev_out[s]);
+            ev_in[s] = ev_done[s] = ev_out[s] = nullptr;
+        }
+        if (s_in) tfhe_amd_stream_destroy(c, s_in);
+        if (s_out) tfhe_amd_stream_destroy(c, s_out);
+        s_in = s_out = nullptr;
+    }
+};
+template <class Launch>
+int pipelined_rows(tfhe_amd_ctx *c, Pipe &p, char *out, size_t out_row, const char *in, size_t in_row, size_t mid_row, int lo, int hi, int chunk,
+                   Launch launch) {
+    if (int rc = p.prepare(c, (size_t)chunk * in_row, (size_t)chunk * out_row, (size_t)chunk * mid_row)) return rc;
+    int rows_of[SETS] = {0, 0, 0}, at_of[SETS] = {0, 0, 0};
+    static const bool trace = getenv("TFHE_AMD_POOL_TRACE") != nullptr;  // host-side phase times of one call on stderr (experiments)
+    double t_wait = 0, t_out = 0, t_in = 0, t_enq = 0;
+    const double t_call = now_s();
+    auto drain = [&](int s) -> int {  // wait for set s's chunk to have been copied out and hand its rows to the caller
+        if (!rows_of[s]) return TFHE_AMD_OK;
+        double t0 = now_s();
+        if (int rc = tfhe_amd_event_sync(c, p.ev_out[s])) return rc;
+        double t1 = now_s();
+        memcpy(out + (size_t)at_of[s] * out_row, p.st[s].h_out, (size_t)rows_of[s] * out_row);
+        t_wait += t1 - t0;
+        t_out += now_s() - t1;
+        rows_of[s] = 0;
+        return TFHE_AMD_OK;
+    };
+    int rc = TFHE_AMD_OK, k = 0;
+    for (int at = lo; at < hi && !rc; at += chunk, k++) {
+        const int s = k % SETS, rows = hi - at < chunk ? hi - at : chunk;
+        Staging &set = p.st[s];
+        rc = drain(s);  // the set's previous chunk (k - 3): its buffers are reused now
+        if (rc) break;
+        double t0 = now_s();
+        memcpy(set.h_in, in + (size_t)at * in_row, (size_t)rows * in_row);
+        double t1 = now_s();
+        t_in += t1 - t0;
+        rc = tfhe_amd_set_stream(c, p.s_in);                                              // copy in
+        if (!rc) rc = tfhe_amd_memcpy_h2d_async(c, set.d_in, set.h_in, (size_t)rows * in_row);
+        if (!rc) rc = tfhe_amd_event_record(c, p.ev_in[s]);
+        if (!rc) rc = tfhe_amd_set_stream(c, nullptr);                                    // kernels: the context's own stream
+        if (!rc) rc = tfhe_amd_stream_wait_event(c, p.ev_in[s]);
+        if (!rc) rc = launch(set, set.d_out, set.d_in, rows);
+        if (!rc) rc = tfhe_amd_event_record(c, p.ev_done[s]);
+        if (!rc) rc = tfhe_amd_set_stream(c, p.s_out);                                    // copy out
+        if (!rc) rc = tfhe_amd_stream_wait_event(c, p.ev_done[s]);
+        if (!rc) rc = tfhe_amd_memcpy_d2h_async(c, set.h_out, set.d_out, (size_t)rows * out_row);
+        if (!rc) rc = tfhe_amd_event_record(c, p.ev_out[s]);
+        if (!rc) {
+            rows_of[s] = rows;
+            at_of[s] = at;
+        }
+        t_enq += now_s() - t1;
+    }
+    const int r0 = tfhe_amd_set_stream(c, nullptr);
+    if (rc) {  // something failed mid-way: let everything queued finish before the buffers can be touched again
+        (void)tfhe_amd_sync(c);
+        (void)tfhe_amd_stream_sync(c, p.s_in);
+        (void)tfhe_amd_stream_sync(c, p.s_out);
+        return rc;
+    }
+    for (int j = 0; j < SETS; j++) {  // oldest first
+        const int r = drain((k + j) % SETS);
+        if (!rc) rc = r;
+    }
+    if (trace)
+        fprintf(stderr, "pool member: %d rows in %d chunks, %.3f ms: gather %.3f, enqueue %.3f, wait %.3f, scatter %.3f\n", hi - lo, k,
+                1e3 * (now_s() - t_call), 1e3 * t_in, 1e3 * t_enq, 1e3 * t_wait, 1e3 * t_out);
+    return rc ? rc : r0;
+}
 
 // [lo, hi) of `total` rows owned by member r of m: contiguous, sizes differ by at most one
 void slice_of(int total, int r, int m, int *lo, int *hi) {
@@ -117,14 +245,16 @@ void slice_of(int total, int r, int m, int *lo, int *hi) {
     *hi = *lo + base + (r < rem ? 1 : 0);
 }
 
-// copy in -> launch -> copy out of rows [lo, hi), in rounds of at most STAGE_BYTES per direction
+// copy in -> launch -> copy out of rows [lo, hi) as one piece (in rounds of at most STAGE_BYTES per direction)
 template <class Launch>
-int staged_rows(tfhe_amd_ctx *c, Staging &st, char *out, size_t out_row, const char *in, size_t in_row, int lo, int hi, Launch launch) {
+int staged_rows(tfhe_amd_ctx *c, Staging &st, char *out, size_t out_row, const char *in, size_t in_row, size_t mid_row, int lo, int hi, Launch launch) {
     const size_t big = in_row > out_row ? in_row : out_row;
     int per_round = (int)(STAGE_BYTES / big);
     if (per_round < 1) per_round = 1;
     if (per_round > hi - lo) per_round = hi - lo;
     if (int rc = st.ensure(c, (size_t)per_round * in_row, (size_t)per_round * out_row)) return rc;
+    if (mid_row)
+        if (int rc = st.ensure_mid(c, (size_t)per_round * mid_row)) return rc;
     for (int at = lo; at < hi; at += per_round) {
         const int rows = hi - at < per_round ? hi - at : per_round;
         memcpy(st.h_in, in + (size_t)at * in_row, (size_t)rows * in_row);  // pageable -> pinned: the copy below then runs at the link's rate
@@ -136,8 +266,6 @@ int staged_rows(tfhe_amd_ctx *c, Staging &st, char *out, size_t out_row, const c
     return TFHE_AMD_OK;
 }
 
-double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
 }  // namespace
 
 // ------------------------------------------------------------------ gate-bootstrap pool
@@ -147,15 +275,17 @@ struct tfhe_amd_pool {
         int device = 0;
         tfhe_amd_ctx *ctx = nullptr;
         tfhe_amd_gsw *bk = nullptr;
-        Staging st;
+        Staging st;  // one-piece form
+        Pipe pipe;   // pipelined form: three sets, copy-in / compute / copy-out streams
         Worker *worker = nullptr;
-        int last_count = 0;
+        int last_count = 0, last_chunks = 0;
         double last_seconds = 0;
         std::string err;
     };
     std::vector<Member> m;
     std::mutex call_mu;  // one sharded call at a time
     std::string err;
+    int chunk_rows = DEFAULT_CHUNK_ROWS;
 };
 
 namespace {
@@ -178,8 +308,9 @@ int member_status(tfhe_amd_pool::Member &mb, int rc) {
     return rc;
 }
 
+// launch(ctx, d_mid, d_out, d_in, rows): the operation on device buffers; d_mid (rows x mid_ints) is scratch owned by the caller
 template <class Launch>
-int pool_rows(tfhe_amd_pool *pool, int32_t *out, size_t out_ints, const int32_t *x, size_t in_ints, int count, Launch launch) {
+int pool_rows(tfhe_amd_pool *pool, int32_t *out, size_t out_ints, const int32_t *x, size_t in_ints, size_t mid_ints, int count, Launch launch) {
     if (!pool || !out || !x || count < 0) return TFHE_AMD_ERR_PARAM;
     std::lock_guard<std::mutex> lk(pool->call_mu);
     const int members = (int)pool->m.size();
@@ -189,10 +320,24 @@ int pool_rows(tfhe_amd_pool *pool, int32_t *out, size_t out_ints, const int32_t 
         slice_of(count, i, members, &lo, &hi);
         mb.last_count = hi - lo;
         mb.last_seconds = 0;
+        mb.last_chunks = 0;
         if (hi == lo) return (int)TFHE_AMD_OK;
         const double t0 = now_s();
-        const int rc = staged_rows(mb.ctx, mb.st, (char *)out, out_ints * 4, (const char *)x, in_ints * 4, lo, hi,
-                                   [&](void *o, const void *in, int rows) { return launch(mb.ctx, (int32_t *)o, (const int32_t *)in, rows); });
+        const int chunk = pool->chunk_rows;
+        int rc;
+        if (chunk > 0 && hi - lo >= 2 * chunk) {
+            mb.last_chunks = (hi - lo + chunk - 1) / chunk;
+            rc = pipelined_rows(mb.ctx, mb.pipe, (char *)out, out_ints * 4, (const char *)x, in_ints * 4, mid_ints * 4, lo, hi, chunk,
+                                [&](Staging &set, void *o, const void *in, int rows) {
+                                    return launch(mb.ctx, (int32_t *)set.d_mid, (int32_t *)o, (const int32_t *)in, rows);
+                                });
+        } else {
+            mb.last_chunks = 1;
+            rc = staged_rows(mb.ctx, mb.st, (char *)out, out_ints * 4, (const char *)x, in_ints * 4, mid_ints * 4, lo, hi,
+                             [&](void *o, const void *in, int rows) {
+                                 return launch(mb.ctx, (int32_t *)mb.st.d_mid, (int32_t *)o, (const int32_t *)in, rows);
+                             });
+        }
         mb.last_seconds = now_s() - t0;
         return member_status(mb, rc);
     });
@@ -232,6 +377,7 @@ void tfhe_amd_pool_destroy(tfhe_amd_pool *pool) {
         tfhe_amd_pool::Member &mb = pool->m[i];
         if (mb.ctx) {
             mb.st.release(mb.ctx);
+            mb.pipe.release(mb.ctx);
             if (mb.bk) tfhe_amd_gsw_free(mb.bk);
             tfhe_amd_ctx_destroy(mb.ctx);
         }
@@ -282,18 +428,35 @@ int tfhe_amd_pool_load_keys_torus(tfhe_amd_pool *pool, const void *bk_torus, con
 int tfhe_amd_pool_bootstrap_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
     const size_t row = (size_t)pool->p.n + 1;
-    return pool_rows(pool, out, row, x, row, count,
-                     [mu](tfhe_amd_ctx *c, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_bootstrap(c, o, mu, in, rows); });
+    // blind rotation + extraction into the member's own intermediate buffer, then the key switch: tfhe_amd_bootstrap's two
+    // kernels without the context's scratch, so that two chunks can be in flight
+    return pool_rows(pool, out, row, x, row, (size_t)pool->p.N + 1, count, [mu](tfhe_amd_ctx *c, int32_t *mid, int32_t *o, const int32_t *in, int rows) {
+        const int rc = tfhe_amd_bootstrap_woks(c, mid, mu, in, rows);
+        return rc ? rc : tfhe_amd_keyswitch(c, o, mid, rows);
+    });
 }
 int tfhe_amd_pool_bootstrap_woks_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
-    return pool_rows(pool, out, (size_t)pool->p.N + 1, x, (size_t)pool->p.n + 1, count,
-                     [mu](tfhe_amd_ctx *c, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_bootstrap_woks(c, o, mu, in, rows); });
+    return pool_rows(pool, out, (size_t)pool->p.N + 1, x, (size_t)pool->p.n + 1, 0, count,
+                     [mu](tfhe_amd_ctx *c, int32_t *, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_bootstrap_woks(c, o, mu, in, rows); });
 }
 int tfhe_amd_pool_keyswitch_host(tfhe_amd_pool *pool, int32_t *out, const int32_t *x, int count) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
-    return pool_rows(pool, out, (size_t)pool->p.ks_n_out + 1, x, (size_t)pool->p.N + 1, count,
-                     [](tfhe_amd_ctx *c, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_keyswitch(c, o, in, rows); });
+    return pool_rows(pool, out, (size_t)pool->p.ks_n_out + 1, x, (size_t)pool->p.N + 1, 0, count,
+                     [](tfhe_amd_ctx *c, int32_t *, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_keyswitch(c, o, in, rows); });
+}
+int tfhe_amd_pool_set_option(tfhe_amd_pool *pool, int option, int value) {
+    if (!pool) return TFHE_AMD_ERR_PARAM;
+    std::lock_guard<std::mutex> lk(pool->call_mu);
+    switch (option) {
+        case TFHE_AMD_POOL_OPT_CHUNK_ROWS:
+            if (value < 0) return TFHE_AMD_ERR_PARAM;
+            pool->chunk_rows = value;
+            return TFHE_AMD_OK;
+        default:
+            pool->err = "unknown pool option";
+            return TFHE_AMD_ERR_PARAM;
+    }
 }
 int tfhe_amd_pool_last_split(const tfhe_amd_pool *pool, int *counts, double *seconds) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
@@ -406,7 +569,7 @@ int tfhe_amd_cb_pool_circuit_bootstrap_host(tfhe_amd_cb_pool *pool, int32_t *out
         int lo, hi;
         slice_of(count, i, members, &lo, &hi);
         if (hi == lo) return (int)TFHE_AMD_OK;
-        const int rc = staged_rows(mb.ctx, mb.st, (char *)out, out_row, (const char *)x, in_row, lo, hi, [&](void *o, const void *in, int rows) {
+        const int rc = staged_rows(mb.ctx, mb.st, (char *)out, out_row, (const char *)x, in_row, 0, lo, hi, [&](void *o, const void *in, int rows) {
             return tfhe_amd_circuit_bootstrap(mb.cb, (int32_t *)o, (const int32_t *)in, rows);
         });
         if (rc) {  // the pipeline's message, or the level-2 context's when a copy failed

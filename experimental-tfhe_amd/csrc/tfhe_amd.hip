@@ -28,8 +28,8 @@ struct tfhe_amd_ctx {
     tfhe_amd_params p;
     int device;
     int logn;
-    hipStream_t stream;
-    bool own_stream;
+    hipStream_t stream;  // the stream work is issued on: `own`, or the caller's (tfhe_amd_set_stream)
+    hipStream_t own;     // created with the context, alive until it is destroyed (switching streams costs nothing)
     std::string err;
     std::vector<double> fft_trig, ifft_trig;  // reference layout
     double2 *tw_d;                            // [2*NC]
@@ -561,7 +561,7 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->device = device;
     c->logn = ilog2(p->N);
     c->stream = nullptr;
-    c->own_stream = false;
+    c->own = nullptr;
     c->tw_d = nullptr;
     c->bk = nullptr;
     c->ks_d = nullptr;
@@ -581,11 +581,11 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
         delete c;
         return TFHE_AMD_ERR_DEVICE;
     }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return TFHE_AMD_ERR_DEVICE;
     }
-    c->own_stream = true;
+    c->stream = c->own;
     // from here on the context owns device objects: failures go through tfhe_amd_ctx_destroy
     std::vector<double2> tw;
     if (!build_tables(p->N, c->fft_trig, c->ifft_trig, tw)) {
@@ -621,6 +621,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->own && c->own != c->stream) (void)hipStreamSynchronize(c->own);
     if (c->tw_d) (void)hipFree(c->tw_d);
     if (c->ks_d) (void)hipFree(c->ks_d);
     if (c->ksm_d) (void)hipFree(c->ksm_d);
@@ -631,7 +632,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     if (c->probe_d) (void)hipFree(c->probe_d);
     if (c->probe_stream) (void)hipStreamDestroy(c->probe_stream);
     drop_streamed_graph(c);
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->own) (void)hipStreamDestroy(c->own);
     delete c;
 }
 
@@ -640,17 +641,10 @@ const char *tfhe_amd_last_error(const tfhe_amd_ctx *c) { return c ? c->err.c_str
 int tfhe_amd_set_stream(tfhe_amd_ctx *c, void *s) {
     if (!c) return TFHE_AMD_ERR_PARAM;
     ENTER(c);
-    drop_streamed_graph(c);  // a captured schedule replays on the stream it was captured on
-    if (s) {
-        if (c->own_stream) {
-            HIPCHECK(c, hipStreamSynchronize(c->stream));
-            HIPCHECK(c, hipStreamDestroy(c->stream));
-            c->own_stream = false;
-        }
-        c->stream = (hipStream_t)s;
-    } else if (!c->own_stream) {
-        HIPCHECK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
+    hipStream_t next = s ? (hipStream_t)s : c->own;
+    if (next != c->stream) {
+        drop_streamed_graph(c);  // a captured schedule replays on the stream it was captured on
+        c->stream = next;        // (no wait: work already queued on the previous stream stays ordered there)
     }
     return TFHE_AMD_OK;
 }
@@ -692,6 +686,20 @@ int tfhe_amd_event_record(tfhe_amd_ctx *c, void *event) {
     if (!c || !event) return TFHE_AMD_ERR_PARAM;
     ENTER(c);
     HIPCHECK(c, hipEventRecord((hipEvent_t)event, c->stream));
+    return TFHE_AMD_OK;
+}
+// host waits for a recorded event; the context's CURRENT stream waits for one (work queued after this call starts only once
+// the event has happened): the two halves of a copy / compute pipeline over several streams of one context
+int tfhe_amd_event_sync(tfhe_amd_ctx *c, void *event) {
+    if (!c || !event) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    HIPCHECK(c, hipEventSynchronize((hipEvent_t)event));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_stream_wait_event(tfhe_amd_ctx *c, void *event) {
+    if (!c || !event) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    HIPCHECK(c, hipStreamWaitEvent(c->stream, (hipEvent_t)event, 0));
     return TFHE_AMD_OK;
 }
 int tfhe_amd_event_elapsed_ms(tfhe_amd_ctx *c, void *start, void *stop, float *ms) {
@@ -760,6 +768,46 @@ int tfhe_amd_memcpy_h2d(tfhe_amd_ctx *c, void *dst_d, const void *src, size_t by
     ENTER(c);
     HIPCHECK(c, hipMemcpyAsync(dst_d, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return TFHE_AMD_OK;
+}
+// the same copies WITHOUT the wait: ordered on the context's current stream like a launch; the host buffer must stay valid
+// (and should be page-locked: tfhe_amd_host_alloc) until that stream is synchronised
+int tfhe_amd_memcpy_h2d_async(tfhe_amd_ctx *c, void *dst_d, const void *src, size_t bytes) {
+    if (!c || (!dst_d && bytes) || (!src && bytes)) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    HIPCHECK(c, hipMemcpyAsync(dst_d, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_memcpy_d2h_async(tfhe_amd_ctx *c, void *dst, const void *src_d, size_t bytes) {
+    if (!c || (!dst && bytes) || (!src_d && bytes)) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    HIPCHECK(c, hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToHost, c->stream));
+    return TFHE_AMD_OK;
+}
+// more streams on the context's device (for tfhe_amd_set_stream): work of independent batches issued alternately on two
+// streams overlaps one batch's copies with the other's kernels
+int tfhe_amd_stream_create(tfhe_amd_ctx *c, void **stream) {
+    if (!c || !stream) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    hipStream_t s = nullptr;
+    HIPCHECK(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_stream_sync(tfhe_amd_ctx *c, void *stream) {
+    if (!c || !stream) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    HIPCHECK(c, hipStreamSynchronize((hipStream_t)stream));
+    return TFHE_AMD_OK;
+}
+int tfhe_amd_stream_destroy(tfhe_amd_ctx *c, void *stream) {
+    if (!c) return TFHE_AMD_ERR_PARAM;
+    ENTER(c);
+    if (stream) {
+        REQUIRE(c, (hipStream_t)stream != c->stream, "the stream is the context's current one: tfhe_amd_set_stream(ctx, NULL) first");
+        HIPCHECK(c, hipStreamSynchronize((hipStream_t)stream));
+        HIPCHECK(c, hipStreamDestroy((hipStream_t)stream));
+    }
     return TFHE_AMD_OK;
 }
 int tfhe_amd_memcpy_d2h(tfhe_amd_ctx *c, void *dst, const void *src_d, size_t bytes) {

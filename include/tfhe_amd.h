@@ -109,6 +109,10 @@ int tfhe_amd_set_option(tfhe_amd_ctx *ctx, int option, int value);
 int tfhe_amd_event_create(tfhe_amd_ctx *ctx, void **event);
 int tfhe_amd_event_record(tfhe_amd_ctx *ctx, void *event);
 int tfhe_amd_event_elapsed_ms(tfhe_amd_ctx *ctx, void *start, void *stop, float *ms);
+/* host waits for a recorded event / the context's CURRENT stream waits for it (work queued afterwards starts only once the
+ * event has happened): with tfhe_amd_set_stream and tfhe_amd_stream_create, a copy / compute pipeline inside one context */
+int tfhe_amd_event_sync(tfhe_amd_ctx *ctx, void *event);
+int tfhe_amd_stream_wait_event(tfhe_amd_ctx *ctx, void *event);
 int tfhe_amd_event_destroy(tfhe_amd_ctx *ctx, void *event);
 /* twiddle tables as the reference lays them out (new_fft_table / new_ifft_table,
  * CB/spqlios/spqlios-fft-impl.cpp:158-193,400-437): 2N-8 doubles each; for SHA pinning. */
@@ -125,6 +129,17 @@ int tfhe_amd_host_alloc(tfhe_amd_ctx *ctx, void **hptr, size_t bytes);
 int tfhe_amd_host_free(tfhe_amd_ctx *ctx, void *hptr);
 int tfhe_amd_memcpy_h2d(tfhe_amd_ctx *ctx, void *dst_d, const void *src, size_t bytes);
 int tfhe_amd_memcpy_d2h(tfhe_amd_ctx *ctx, void *dst, const void *src_d, size_t bytes);
+/* the same copies without the wait: ordered on the context's current stream like a launch; the host buffer must stay valid
+ * (and should be page-locked: tfhe_amd_host_alloc) until that stream has been synchronised */
+int tfhe_amd_memcpy_h2d_async(tfhe_amd_ctx *ctx, void *dst_d, const void *src, size_t bytes);
+int tfhe_amd_memcpy_d2h_async(tfhe_amd_ctx *ctx, void *dst, const void *src_d, size_t bytes);
+/* more streams on the context's device, for tfhe_amd_set_stream: independent batches issued alternately on two streams
+ * overlap one batch's copies with the other's kernels (what the pool does inside a member).  Entry points that use the
+ * context's own scratch (tfhe_amd_bootstrap, _bootstrap_streamed, _lut_eval) must not be in flight on two streams at once;
+ * tfhe_amd_bootstrap_woks + tfhe_amd_keyswitch on caller-owned buffers may. */
+int tfhe_amd_stream_create(tfhe_amd_ctx *ctx, void **stream);
+int tfhe_amd_stream_sync(tfhe_amd_ctx *ctx, void *stream);
+int tfhe_amd_stream_destroy(tfhe_amd_ctx *ctx, void *stream);
 
 /* ---- keys --------------------------------------------------------------------------- */
 /* TGSW samples already in Lagrange form, host layout [count][(k+1)l][k+1][N] doubles
@@ -330,6 +345,12 @@ int tfhe_amd_pool_load_keys_torus(tfhe_amd_pool *pool, const void *bk_torus, con
 int tfhe_amd_pool_bootstrap_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count);
 int tfhe_amd_pool_bootstrap_woks_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count);
 int tfhe_amd_pool_keyswitch_host(tfhe_amd_pool *pool, int32_t *out, const int32_t *x, int count);
+/* Inside a member a slice of at least 2 x CHUNK_ROWS samples is PIPELINED: chunks of CHUNK_ROWS whose kernels run back to
+ * back on the member's stream while a second stream copies the next chunk in and a third copies the previous one out (three
+ * sets of pinned staging buffers; shorter slices go as one piece).  TFHE_AMD_POOL_OPT_CHUNK_ROWS: default 2048 -- the blind
+ * rotation needs about that many samples per launch for its full rate; 0 = never pipeline.  Same results bit for bit. */
+enum { TFHE_AMD_POOL_OPT_CHUNK_ROWS = 1 };
+int tfhe_amd_pool_set_option(tfhe_amd_pool *pool, int option, int value);
 /* what the last sharded call did: per member the number of samples and the host seconds its thread spent; arrays of
  * tfhe_amd_pool_size entries, either may be NULL */
 int tfhe_amd_pool_last_split(const tfhe_amd_pool *pool, int *counts, double *seconds);

@@ -479,6 +479,11 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t stream) {
     e->t = emu_now_ms();
     return hipSuccess;
 }
+hipError_t hipStreamWaitEvent(hipStream_t stream, hipEvent_t e, unsigned) {
+    emu::check_stream(stream, "hipStreamWaitEvent");
+    if (e->device != emu::t_device) emu::die("hipStreamWaitEvent", "the event", e->device);
+    return hipSuccess;
+}
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
     if (a->device != b->device) emu::die("hipEventElapsedTime", "one of the two events", a->device);
     *ms = (float)(b->t - a->t);

@@ -170,6 +170,7 @@ double emu_now_ms();
 hipError_t hipEventCreate(hipEvent_t *e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t);
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned);  // (launches run synchronously: only the device checks remain)
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t emu_func_set_attribute(const void *fn, int bytes);

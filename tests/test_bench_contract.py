@@ -168,7 +168,8 @@ def test_bench_post_region_sections_on_emulator(emu_lib):
     assert "config3_circuit_bootstrap" not in d
     # the pool: one member, and two members sharing the device; host arrays in and out; identical to the headline outputs
     pc = d["pool_check"]
-    assert [m[0] for m in pc["members"]] == [[0], [0, 0]] and all(m[1] > 0 for m in pc["members"]) and pc["identical_to_headline"] is True
+    rows = pc["[devices, samples per call, bootstraps/s]"]
+    assert [(m[0], m[1]) for m in rows] == [([0], 2), ([0, 0], 2), ([0], 8)] and all(m[2] > 0 for m in rows) and pc["identical_to_headline"] is True
     su = d["sustained"]
     assert su["steps"] >= 2 and su["bootstraps_per_s"] > 0 and su["step_ms_max"] >= su["step_ms_min"] > 0
     f = json.load(open(os.path.join(ROOT, d["detail"])))  # the full record: every stage and line

@@ -207,6 +207,32 @@ def test_pool_two_members_on_device_0(gpu_lib):
         bk_t = T.keygen_bk_torus(32, s.lwe_key, s.tkey, l, Bgbit, 2.0 ** -25, P.SEED, 1000, lib_path=gpu_lib)
         pool.load_keys_torus(bk_t, None)  # the key again, in coefficient form: converted on the device, replaces the first
         assert np.array_equal(pool.bootstrap(1 << 29, x), single)
+        # the pipelined form inside each member: 516 = 128 + 128 + 128 + 128 + 4 on two streams per member, four streams on the GPU
+        pool.set_chunk_rows(128)
+        for rep in range(3):
+            assert np.array_equal(pool.bootstrap(1 << 29, x), single), ("pipelined", rep)
+        assert np.array_equal(pool.keyswitch(pool.bootstrap_woks(1 << 29, x)), single)
+    finally:
+        pool.close()
+        s.close()
+
+
+def test_pool_pipelined_member_full_parameters(gpu_lib):
+    """one member, BASELINE config 2's parameters and batch: 4096 host samples through tfhe_amd_pool_bootstrap_host = two chunks
+    of 2048 on two streams (the default), and 4500 = 2048 + 2048 + 404; equal to the single-context engine on every row and to
+    the oracle on a subset"""
+    N, n, l, Bgbit, t, bb = 1024, 630, 2, 10, 8, 2
+    s = P.GateSetup(gpu_lib, N, n, l, Bgbit, t, bb)
+    pool = T.Pool([0], torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=t, ks_basebit=bb, lib_path=gpu_lib)
+    try:
+        pool.load_keys(s.bk, s.ks)
+        rs = np.random.RandomState(4500)
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(4500, n + 1)).astype(np.int32)
+        single = s.eng.bootstrap(1 << 29, x)
+        assert np.array_equal(pool.bootstrap(1 << 29, x[:4096]), single[:4096])
+        assert np.array_equal(pool.bootstrap(1 << 29, x), single)
+        for i in (0, 2047, 2048, 4095, 4096, 4499):
+            assert np.array_equal(single[i], O.bootstrap32(N, s.bk, s.ks, 1 << 29, x[i], l, Bgbit, t, bb)), i
     finally:
         pool.close()
         s.close()

@@ -141,6 +141,33 @@ def test_pool_equals_single_device_and_oracle(emu_lib, devices, count):
         s.close()
 
 
+@pytest.mark.parametrize("devices,count,chunk", [([3], 7, 2), ([1, 5], 11, 2), ([6, 6], 9, 1), ([2], 5, 0)])
+def test_pool_pipelined_chunks(emu_lib, devices, count, chunk):
+    """the pipelined form inside a member -- chunks issued alternately on two streams with two staging sets (chunk k + 1 copied
+    in while chunk k computes) -- with a ragged last chunk (7 = 2 + 2 + 2 + 1), two members pipelining at once, two members of
+    ONE device, and switched off: the same bits as the single-context engine, for all three sharded operations"""
+    N, n, l, Bgbit, t, bb = 1024, 2, 2, 10, 8, 2
+    s = P.GateSetup(emu_lib, N, n, l, Bgbit, t, bb)
+    pool = T.Pool(devices, torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=t, ks_basebit=bb, lib_path=emu_lib)
+    try:
+        pool.load_keys(s.bk, s.ks)
+        pool.set_chunk_rows(chunk)
+        rs = np.random.RandomState(count + chunk)
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(count, n + 1)).astype(np.int32)
+        single = s.eng.bootstrap(1 << 29, x)
+        for rep in range(2):  # the second call reuses streams and staging sets
+            assert np.array_equal(pool.bootstrap(1 << 29, x), single), rep
+        u = pool.bootstrap_woks(1 << 29, x)
+        assert np.array_equal(u, s.eng.bootstrap_woks(1 << 29, x))
+        assert np.array_equal(pool.keyswitch(u), single)
+        assert np.array_equal(pool.bootstrap(1 << 29, x[:1]), single[:1])  # a short call after a pipelined one: one piece
+        with pytest.raises(T.TfheAmdError):
+            pool.set_chunk_rows(-1)
+    finally:
+        pool.close()
+        s.close()
+
+
 def test_pool_errors(emu_lib):
     with pytest.raises(T.TfheAmdError):
         T.Pool([0, 9], n=2, lib_path=emu_lib)  # device 9 does not exist: the whole pool fails, nothing half-made is returned
