@@ -168,6 +168,39 @@ def test_pool_pipelined_chunks(emu_lib, devices, count, chunk):
         s.close()
 
 
+def test_pool_calls_from_several_host_threads_are_serialised(emu_lib):
+    """a pool is not re-entrant: calls from several host threads take its one lock and run one after the other, each with the
+    right answer (the shims' array forms rely on it)"""
+    N, n, l, Bgbit, t, bb = 1024, 2, 2, 10, 8, 2
+    s = P.GateSetup(emu_lib, N, n, l, Bgbit, t, bb)
+    pool = T.Pool([0, 7], torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=t, ks_basebit=bb, lib_path=emu_lib)
+    try:
+        pool.load_keys(s.bk, s.ks)
+        pool.set_chunk_rows(1)
+        rs = np.random.RandomState(4)
+        xs = [rs.randint(-2 ** 31, 2 ** 31, size=(c, n + 1)).astype(np.int32) for c in (5, 3, 6, 2)]
+        want = [s.eng.bootstrap(1 << 29, x) for x in xs]
+        bad = []
+
+        def work(k):
+            try:
+                for rep in range(2):
+                    if not np.array_equal(pool.bootstrap(1 << 29, xs[k]), want[k]):
+                        bad.append((k, rep))
+            except Exception as ex:
+                bad.append((k, repr(ex)))
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not bad, bad
+    finally:
+        pool.close()
+        s.close()
+
+
 def test_pool_errors(emu_lib):
     with pytest.raises(T.TfheAmdError):
         T.Pool([0, 9], n=2, lib_path=emu_lib)  # device 9 does not exist: the whole pool fails, nothing half-made is returned
