@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--device", type=int, default=0, help="device ordinal of the pool members of the `pool` checks")
     ap.add_argument("--lib", default=None, help="engine library (default: the shipped HIP build; the CPU emulation build for a dry run)")
     a = ap.parse_args()
     import oracle_py as O
@@ -37,7 +38,7 @@ def main():
     runs = 0
     while time.time() < t_end:
         seed = rnd.randrange(1, 1 << 30)
-        kind = rnd.choice(["gate", "gate", "gate", "t64", "ks", "cmux", "lut", "fft", "exact", "wide"])
+        kind = rnd.choice(["gate", "gate", "gate", "t64", "ks", "cmux", "lut", "fft", "exact", "wide", "pool", "privks"])
         if kind == "gate":      # N=1024 Torus32: compile-time and run-time gadgets, ragged batches 1..41
             l, bg = rnd.choice([(2, 10), (2, 10), (2, 8), (2, 9), (3, 7), (4, 6), (1, 12)])
             t, bb = rnd.choice([(8, 2), (16, 1), (5, 3), (6, 2)])
@@ -55,6 +56,14 @@ def main():
         elif kind == "ks":      # matrix-core key switch and its fallbacks, ragged sample tiles
             t, bb = rnd.choice([(8, 2), (6, 2), (16, 1), (10, 3), (5, 3), (15, 2)])
             P.check_keyswitch_shapes(lib, 1024, rnd.choice([500, 630, 37]), t, bb, rnd.randrange(1, 300), seed=seed)
+        elif kind == "pool":    # host arrays through a pool of 1..3 members sharing the device, pipelined chunks of every size
+            members = rnd.randrange(1, 4)
+            P.check_pool(lib, [a.device] * members, count=rnd.randrange(1, 2600), chunk=rnd.choice([0, 1, 7, 64, 256, 1000, 2048]),
+                         n=rnd.randrange(2, 6), seed=seed % 100000)
+        elif kind == "privks":  # the int64 key switch with many samples per launch (several 256-sample tiles), small tables
+            t21, bb21 = rnd.choice([(2, 3), (3, 3), (4, 2), (6, 1)])
+            P.check_privks_wide(lib, N2=1024, t21=t21, bb21=bb21, counts=(rnd.randrange(257, 1100),), pipeline_B=rnd.choice([0, 0, 130]),
+                                n0=2, l2=3, bg2=10, t10=2, seed=seed % 100000)
         elif kind == "cmux":
             P.check_cmux_data(lib, B=rnd.randrange(1, 30), seed=seed)
         elif kind == "lut":

@@ -560,6 +560,40 @@ def check_privks_wide(lib_path, N1=1024, N2=2048, t21=10, bb21=3, counts=(300, 1
         cb.close()
 
 
+def check_pool(lib_path, devices, count, chunk, n=4, l=2, Bgbit=10, ks_t=8, ks_bb=2, seed=71):
+    """tfhe_amd_pool_*: host arrays through a pool of `devices` (entries may repeat) with the pipeline chunk `chunk`, against the
+    single-context engine on every row and the oracle on a few; keys handed over as device-layout bytes to a third context too"""
+    N = 1024
+    s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb, seed=SEED + seed)
+    pool = T.Pool(devices, torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=ks_t, ks_basebit=ks_bb, lib_path=lib_path)
+    other = T.Engine(torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=ks_t, ks_basebit=ks_bb, device=devices[-1], lib_path=lib_path)
+    try:
+        pool.load_keys(s.bk, s.ks)
+        pool.set_chunk_rows(chunk)
+        rs = np.random.RandomState(seed)
+        x = rs.randint(-2 ** 31, 2 ** 31, size=(count, n + 1)).astype(np.int32)
+        mu = 1 << 29
+        single = s.eng.bootstrap(mu, x)
+        assert np.array_equal(pool.bootstrap(mu, x), single), "tfhe_amd_pool_bootstrap_host"
+        for i in sorted(set([0, count // 2, count - 1])):
+            assert np.array_equal(single[i], O.bootstrap32(N, s.bk, s.ks, mu, x[i], l, Bgbit, ks_t, ks_bb)), i
+        u = pool.bootstrap_woks(mu, x)
+        assert np.array_equal(u, s.eng.bootstrap_woks(mu, x)), "tfhe_amd_pool_bootstrap_woks_host"
+        assert np.array_equal(pool.keyswitch(u), single), "tfhe_amd_pool_keyswitch_host"
+        base, rem = divmod(count, len(devices))
+        assert pool.last_split()[0] == [base + (1 if r < rem else 0) for r in range(len(devices))]
+        bk_bytes, ks_bytes = np.empty(s.eng.gsw_packed_bytes(n), np.uint8), np.empty(s.eng.keyswitch_key_bytes(), np.uint8)
+        s.eng.gsw_export_packed(s.gsw, T._np_ptr(bk_bytes))
+        s.eng.keyswitch_key_export(T._np_ptr(ks_bytes))
+        other.set_bootstrap_key(other.gsw_from_packed(T._np_ptr(bk_bytes), n))
+        other.load_keyswitch_key_d(T._np_ptr(ks_bytes))
+        assert np.array_equal(other.bootstrap(mu, x[:min(count, 70)]), single[:70]), "keys handed over as device-layout bytes"
+    finally:
+        other.close()
+        pool.close()
+        s.close()
+
+
 # ------------------------------------------------- empty batches, state and parameter errors
 def check_abi_edges(lib_path):
     """Empty batches are no-ops that touch nothing; calls made in the wrong state or with bad arguments fail
