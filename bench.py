@@ -531,7 +531,7 @@ def main():
     other, shader_clock = None, None
     if world == 1 and not a.headline_only and a.other_configs.strip():
         other = other_configs_child(a)
-    if world == 1 and not a.headline_only and a.sustained_seconds > 0:
+    if rank == 0 and not a.headline_only and a.sustained_seconds > 0:  # (several ranks: the others wait in init_process_group meanwhile)
         shader_clock = shader_clock_child(a)
 
     dist, dev, torch = None, None, None
@@ -740,7 +740,8 @@ def main():
     sustained = None
     if a.sustained_seconds > 0 and not a.headline_only:
         try:
-            RING = 16 if a.lwe_n is None else 2  # (the emulator test hook: a step takes seconds there)
+            # steps per host sync: about one second's worth, at most 16 (a step is 17 ms at batch 4096, 4 s at 2^20 per GPU)
+            RING = max(1, min(16, int(1.0 / max(elapsed_local / max(a.steps, 1), 1e-3)))) if a.lwe_n is None else 2
             sev = [(eng.event(), eng.event()) for _ in range(RING)]
             step_ms, n_steps = [], 0
             eng.sync()
@@ -759,7 +760,7 @@ def main():
             sustained = {"seconds": t_sus, "steps": n_steps, "value": B * n_steps / t_sus, "unit": "bootstraps/s (this rank)",
                          "step_ms_min": float(min(step_ms)), "step_ms_max": float(max(step_ms)), "step_ms_median": float(np.median(step_ms)),
                          "shader_clock": shader_clock,
-                         "note": "back-to-back steps in rings of 16 (one host sync per ring); step time = HIP events around blind rotation + key switch"}
+                         "note": f"back-to-back steps in rings of {RING} (one host sync per ring); step time = HIP events around blind rotation + key switch"}
         except T.TfheAmdError as e:
             sustained = {"error": str(e)}
 
@@ -874,7 +875,7 @@ def main():
                        "scaling_note": "--gpus 1 without flags is config 2 (4096 per step); --gpus N > 1 without flags is config 5 "
                                        "(2^20 per step cut into N slices, strong); a strict strong-scaling series takes its "
                                        "N = 1 point from `--gpus 1 --total 1048576` (per-GPU throughput at 4096 and at 2^20 per "
-                                       "launch agree within 1 %: profiles/r03_bench_dist_world1_config5.json)",
+                                       "launch agree within 1 %: profiles/r05_bench_selflaunch_world1.json)",
                        "process_group": (f"torch.distributed {a.backend}, world {world}" if dist is not None else "none (single process)"),
                        "ks_kernel": "gather" if a.ks_gather else "matrix-core (k_ks_mfma)",
                        "library": os.path.basename(a.lib) if a.lib else "libtfhe_amd.so"},

@@ -41,6 +41,22 @@ def stale():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+def linked_against(out, engine_lib, deps):
+    """True when `out` exists, is newer than `deps` AND was linked against this very `engine_lib` (recorded in out + ".engine"):
+    the test builds link the same forwarder sources against several engine builds (emulator, its sanitizer variant) under one name"""
+    stamp = out + ".engine"
+    try:
+        same = open(stamp).read().strip() == os.path.abspath(engine_lib)
+    except OSError:
+        same = False
+    return same and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps)
+
+
+def record_engine(out, engine_lib):
+    with open(out + ".engine", "w") as f:
+        f.write(os.path.abspath(engine_lib) + "\n")
+
+
 def build_dropin(engine_lib=None, out=None, force=False):
     """libtfhe_amd_dropin.so: host C++ (g++) forwarding object with the reference's extern "C" names, linked
     against the engine library (default: the shipped one; tests link it against the emulation build)"""
@@ -48,7 +64,7 @@ def build_dropin(engine_lib=None, out=None, force=False):
     out = out or OUT_DROPIN
     src = os.path.join(CSRC, "dropin_library.cpp")
     deps = [src, engine_lib, os.path.join(INCLUDE, "tfhe_amd_dropin.h"), os.path.join(INCLUDE, "tfhe_amd_compat.hpp")]
-    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+    if not force and linked_against(out, engine_lib, deps):
         return out
     libdir, libname = os.path.dirname(engine_lib), os.path.basename(engine_lib)
     res = subprocess.run(["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-I" + INCLUDE, src, "-o", out, "-L" + libdir,
@@ -56,6 +72,7 @@ def build_dropin(engine_lib=None, out=None, force=False):
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
         raise RuntimeError("g++ failed (dropin library)")
+    record_engine(out, engine_lib)
     return out
 
 
@@ -68,7 +85,7 @@ def build_spqlios(engine_lib=None, out=None, force=False):
     out = out or OUT_SPQLIOS
     src = os.path.join(CSRC, "spqlios_seam.cpp")
     deps = [src, engine_lib, os.path.join(INCLUDE, "tfhe_amd_spqlios.h"), os.path.join(INCLUDE, "tfhe_amd.h")]
-    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+    if not force and linked_against(out, engine_lib, deps):
         return out
     libdir, libname = os.path.dirname(engine_lib), os.path.basename(engine_lib)
     rpath = "$ORIGIN" if os.path.abspath(libdir) == os.path.abspath(os.path.dirname(out)) else libdir
@@ -77,6 +94,7 @@ def build_spqlios(engine_lib=None, out=None, force=False):
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
         raise RuntimeError("g++ failed (spqlios seam library)")
+    record_engine(out, engine_lib)
     return out
 
 

@@ -509,7 +509,7 @@ def check_circuit_bootstrap(lib_path, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t
 
 
 def check_privks_wide(lib_path, N1=1024, N2=2048, t21=10, bb21=3, counts=(300, 1031), pipeline_B=600, n0=4, l1=2, bg1=8, l2=4, bg2=9,
-                      t10=6, bb10=2, seed=65):
+                      t10=6, bb10=2, seed=65, planes=(0, 1)):
     """circuitPrivKS (poc:667-698) on MANY samples per launch: the int64 instantiation of the matrix-core key switch with
     several 256-sample tiles and every wave of a tile live -- the launch shape BASELINE config 3's number comes from (1024
     circuit bootstraps = 2048 samples per plane).  For each count: 8 scattered rows (+ first / last row of every tile boundary)
@@ -529,7 +529,7 @@ def check_privks_wide(lib_path, N1=1024, N2=2048, t21=10, bb21=3, counts=(300, 1
         cmax = max(counts)
         x64 = np.frombuffer(rs.bytes(cmax * (N2 + 1) * 8), dtype=np.int64).reshape(cmax, N2 + 1).copy()
         x64[0, :3] = [0, -1, 1 << (63 - t21 * bb21)]  # digit rounding boundary
-        for u in (0, 1):
+        for u in planes:
             small = cb.privks(u, x64[:3])
             for b in range(3):
                 assert np.array_equal(small[b].ravel(), O.privks(privks[u], x64[b], N2, N1, t21, bb21)), f"u={u} row {b} of 3"

@@ -33,10 +33,11 @@ def build_lib_driver(engine_lib, tag):
     dropin = b.build_dropin(engine_lib, os.path.join(BUILD, f"libtfhe_amd_dropin_{tag}.so")) if tag != "hip" else b.build_dropin()
     out = os.path.join(BUILD, f"dropin_driver_lib_{tag}")
     src = os.path.join(ROOT, "tests", "compat", "compat_driver.cpp")
-    if not _newer(out, [src, dropin, os.path.join(INC, "tfhe_amd_dropin.h")]):
+    if not b.linked_against(out, engine_lib, [src, dropin, os.path.join(INC, "tfhe_amd_dropin.h")]):
         d = os.path.dirname(dropin)
         subprocess.check_call(["g++", "-std=c++11", "-O1", "-DDROPIN", "-I" + INC, src, "-o", out, "-L" + d,
                                "-l:" + os.path.basename(dropin), "-Wl,-rpath," + d, "-lpthread"])
+        b.record_engine(out, engine_lib)
     return out
 
 
@@ -48,7 +49,8 @@ def build_poc_driver(engine_lib, tag, real_header=False, POC=POC):
     srcs = [os.path.join(ROOT, "tests", "compat", "dropin_driver_poc.cpp"),
             os.path.join(ROOT, "experimental-tfhe_amd", "csrc", "dropin_poc.cpp")]
     hdr = REF_SRC if real_header else os.path.join(ROOT, "tests", "compat", "poc_stub")
-    if not _newer(out, srcs + [engine_lib, os.path.join(INC, "tfhe_amd_compat.hpp"), os.path.join(INC, "tfhe_amd_dropin.h")]):
+    b = importlib.import_module("experimental-tfhe_amd.build")
+    if not b.linked_against(out, engine_lib, srcs + [engine_lib, os.path.join(INC, "tfhe_amd_compat.hpp"), os.path.join(INC, "tfhe_amd_dropin.h")]):
         defs = [f"-DP_N0={POC['n0']}", f"-DP_N1={POC['N1']}", f"-DP_N2={POC['N2']}", f"-DP_L1={POC['l1']}", f"-DP_BG1={POC['bg1']}",
                 f"-DP_L2={POC['l2']}", f"-DP_BG2={POC['bg2']}", f"-DP_T10={POC['t10']}", f"-DP_BB10={POC['bb10']}",
                 f"-DP_T21={POC['t21']}", f"-DP_BB21={POC['bb21']}"]
@@ -57,6 +59,7 @@ def build_poc_driver(engine_lib, tag, real_header=False, POC=POC):
         d = os.path.dirname(engine_lib)
         subprocess.check_call(["g++", "-std=gnu++11", "-O1", "-I" + hdr, "-I" + INC] + defs + srcs + ["-o", out, "-L" + d,
                                "-l:" + os.path.basename(engine_lib), "-Wl,-rpath," + d, "-lpthread"])
+        b.record_engine(out, engine_lib)
     return out
 
 

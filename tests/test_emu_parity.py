@@ -136,7 +136,7 @@ def test_circuit_bootstrap_emu(emu_lib):
 def test_privks_wide_logic_emu(emu_lib):
     """the wide-count private-key-switch check of the GPU suite at a size the emulator finishes: 259 samples = one full
     256-sample tile + a ragged one, int64 inputs, base 8"""
-    P.check_privks_wide(emu_lib, N2=1024, t21=2, bb21=3, counts=(259,), pipeline_B=0, n0=2, l2=3, bg2=10, t10=2)
+    P.check_privks_wide(emu_lib, N2=1024, t21=2, bb21=3, counts=(259,), pipeline_B=0, n0=2, l2=3, bg2=10, t10=2, planes=(1,))
 
 
 @pytest.mark.parametrize("N,l,Bgbit,B", [(2048, 4, 9, 4), (1024, 3, 10, 5)])

@@ -1,0 +1,20 @@
+set -u
+O=gpurun_out
+python -m pytest tests -m gpu -q > $O/r05_pytest_gpu.log 2>&1; echo "rc=$?" >> $O/r05_pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/r05_smoke.log 2>&1; echo "rc=$?" >> $O/r05_smoke.log
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r05_bench.json 2> $O/r05_bench.err; echo "rc=$?" >> $O/r05_bench.err
+cp $O/bench_detail_1gpu.json $O/r05_bench_detail.json
+python bench.py > $O/r05_bench_noflags.json 2> $O/r05_bench_noflags.err; echo "rc=$?" >> $O/r05_bench_noflags.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --dist --broadcast-keys --steps 5 --warmup 2 --headline-only --detail $O/r05_bcast_detail.json > $O/r05_bench_broadcast_world1.json 2> $O/r05_bcast.err; echo "rc=$?" >> $O/r05_bcast.err
+python bench.py --gpus 2 --backend gloo --total 8192 --steps 5 --warmup 2 --no-cpu-baseline --sustained-seconds 0 --broadcast-keys --detail $O/r05_2ranks_detail.json > $O/r05_bench_2ranks_gloo_onegpu.json 2> $O/r05_2ranks.err; echo "rc=$?" >> $O/r05_2ranks.err
+python bench.py --gpus 1 --self-launch --total 1048576 --steps 3 --warmup 1 --sustained-seconds 0 --detail $O/r05_selflaunch_detail.json > $O/r05_bench_selflaunch_world1.json 2> $O/r05_selflaunch.err; echo "rc=$?" >> $O/r05_selflaunch.err
+python tools/pool_rate.py > $O/r05_pool_rate.jsonl 2>&1
+python tools/pool_rate.py --samples 4096 --chunks 0,2048 >> $O/r05_pool_rate.jsonl 2>&1
+python tools/pool_rate.py --members 2 --chunks 0,2048 >> $O/r05_pool_rate.jsonl 2>&1
+bash tools/prof_trace.sh r05 > $O/r05_prof_trace.txt 2>&1
+bash tools/prof_pmc.sh r05 fetch FETCH_SIZE > $O/r05_pmc_fetch.txt 2>&1
+bash tools/prof_pmc.sh r05 write WRITE_SIZE > $O/r05_pmc_write.txt 2>&1
+bash tools/prof_pmc.sh r05 sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS > $O/r05_pmc_sq1.txt 2>&1
+bash tools/prof_pmc.sh r05 sq2 GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE > $O/r05_pmc_sq2.txt 2>&1
+bash tools/prof_pmc.sh r05 sq3 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL > $O/r05_pmc_sq3.txt 2>&1
+bash tools/prof_pmc.sh r05 tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum > $O/r05_pmc_tcc.txt 2>&1
