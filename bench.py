@@ -769,6 +769,7 @@ def main():
     pool_check = None
     if want_pool and job.bk_host is not None:
         pool_check = {"entry_point": "tfhe_amd_pool_load_keys_torus + tfhe_amd_pool_bootstrap_host", "pools": []}
+        Bp = min(B, BATCH_PER_GPU)  # (a config-5 sized batch would make the 4 x call a 10 GB host array)
         lists = [([device], 1), ([device, device], 1), ([device], 4)]  # (members, how many times the batch per call)
         if a.pool_devices:
             lists.append((list(range(T.device_count(a.lib))) if a.pool_devices == "all" else [int(v) for v in a.pool_devices.split(",")], 4))
@@ -779,16 +780,16 @@ def main():
                 tk = time.perf_counter()
                 pool.load_keys_torus(job.bk_host, job.ks_host)
                 tk = time.perf_counter() - tk
-                xp = x_host if times == 1 else np.tile(x_host, (times, 1))
+                xp = x_host[:Bp] if times == 1 else np.tile(x_host[:Bp], (times, 1))
                 got = pool.bootstrap(mu, xp)  # warm-up: staging buffers, streams, kernel selection
                 tp, reps_p = time.perf_counter(), max(1, min(reps, 3))
                 for _ in range(reps_p):
                     got = pool.bootstrap(mu, xp)
                 tp = (time.perf_counter() - tp) / reps_p
                 counts, secs = pool.last_split()
-                same = bool(np.array_equal(got, out_all if times == 1 else np.tile(out_all, (times, 1))))
+                same = bool(np.array_equal(got, out_all[:Bp] if times == 1 else np.tile(out_all[:Bp], (times, 1))))
                 pool_check["pools"].append({"devices": devs, "pci": [T.device_pci_bus_id(d, a.lib) for d in devs], "key_upload_s": tk,
-                                            "samples_per_call": B * times, "bootstraps_per_s": B * times / tp, "ms_per_call": 1e3 * tp,
+                                            "samples_per_call": Bp * times, "bootstraps_per_s": Bp * times / tp, "ms_per_call": 1e3 * tp,
                                             "split": counts, "member_seconds": secs, "identical_to_headline": same,
                                             "pipelined": "slices of >= 4096 samples go as chunks of 2048: kernels back to back on the member's stream, copies in / out on two more"})
                 del xp, got
