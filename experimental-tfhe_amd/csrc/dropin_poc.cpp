@@ -10,7 +10,9 @@
 // (add it to the PoC's build in place of the bodies above) and linked with
 // libtfhe_amd.so.  One engine per `env` pointer, created on first use: Globals::preKS, bkFFT and privKS
 // are flattened and uploaded once.  Every entry point takes the shims' one lock (tfhe_amd_compat::shim_mutex): callers on
-// several host threads are serialised.
+// several host threads are serialised -- except tfhe_CircuitBootstrapFFT, whose concurrent callers are COALESCED into one
+// array launch (the reference's parallel construct is an OpenMP loop over one-item calls,
+// parallel/src/test_parallel_multiplications.cpp:62).
 #include <cstring>
 #include <map>
 
@@ -73,8 +75,13 @@ void circuitBootstrapWoKS(LweSample64 *result, const Torus64 mu, const int *abar
 void circuitPrivKS(TLweSample32 *result, const int u, const LweSample64 *x, const Globals *env) { TFHE_AMD_SHIM_GUARD();
     engine_of(env).circuitPrivKS(result, u, x);
 }
-void tfhe_CircuitBootstrapFFT(TGswSample32 *result, const LweSample32 *sample, const Globals *env) { TFHE_AMD_SHIM_GUARD();
-    engine_of(env).tfhe_CircuitBootstrapFFT(result, sample);
+void tfhe_CircuitBootstrapFFT(TGswSample32 *result, const LweSample32 *sample, const Globals *env) {
+    Engine *e;
+    {  // the lookup under the lock, the call outside it: concurrent callers meet in the engine's coalescer and share a launch
+        TFHE_AMD_SHIM_GUARD();
+        e = &engine_of(env);
+    }
+    e->tfhe_CircuitBootstrapFFT(result, sample);
 }
 void tfhe_CircuitBootstrapFFT_array(TGswSample32 *const *results, const LweSample32 *const *samples, const Globals *env, int count) { TFHE_AMD_SHIM_GUARD();
     engine_of(env).tfhe_CircuitBootstrapFFT_array(results, samples, count);

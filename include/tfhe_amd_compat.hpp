@@ -21,7 +21,11 @@
 //       any structs with the same members.
 //
 // Like the reference these calls process ONE sample and are synchronous; they copy the sample
-// to the GPU and back, so they are for drop-in correctness, not throughput.  The ARRAY FORMS
+// to the GPU and back.  Called from ONE thread they are for drop-in correctness, not throughput; called from SEVERAL host
+// threads at once -- the reference's own parallel construct is `#pragma omp parallel for` over independent items,
+// parallel/src/test_parallel_multiplications.cpp:62 -- the bootstrap, key-switch and circuit-bootstrap calls are COALESCED:
+// while one launch runs, the calls that arrive are gathered and go out together as one array launch (Coalescer below), so an
+// unmodified OpenMP loop over one-sample calls gets batch launches (and, with set_devices, several GPUs).  The ARRAY FORMS
 // (tfhe_bootstrap_FFT_array, tfhe_bootstrap_woKS_FFT_array, lweKeySwitch_array,
 // PocEngine::tfhe_CircuitBootstrapFFT_array) take the caller's whole loop of samples -- still on the
 // reference's struct types -- as one gather, one launch, one scatter: the batch engine's rate behind the
@@ -37,9 +41,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "tfhe_amd.h"
@@ -101,13 +107,84 @@ inline std::map<ResidentKey, Resident> &registry() {
     return r;
 }
 // One lock around every public entry point of this header (the registry, its staging buffers and the PoC engines are
-// shared state): callers on several host threads are SERIALISED, never corrupted.  Concurrency that pays goes through the
-// array forms or the batch C ABI (one context per thread).
+// shared state): launches issued through this header are SERIALISED, never corrupted.  On top of it the one-sample bootstrap,
+// key-switch and circuit-bootstrap calls are coalesced across host threads (Coalescer): concurrency pays there, and through
+// the array forms or the batch C ABI (one context per thread).
 inline std::recursive_mutex &shim_mutex() {
     static std::recursive_mutex m;
     return m;
 }
 #define TFHE_AMD_SHIM_GUARD() std::lock_guard<std::recursive_mutex> tfhe_amd_shim_guard_(::tfhe_amd_compat::shim_mutex())
+// One-sample calls from several host threads, coalesced.  The first caller to find the coalescer idle becomes the LEADER: it
+// takes everything pending (its own request included), runs it as one batch, marks those requests done and -- if more have
+// arrived meanwhile -- hands the lead to one of the waiting callers before it returns (no caller serves more than one batch: a
+// call waits for at most the batch in flight plus its own).  A lone caller is a batch of one at the one-sample path's latency.
+template <class Item>
+class Coalescer {
+   public:
+    // run(items): executes the batch; called without the coalescer's lock, by exactly one thread at a time
+    template <class RunBatch>
+    void call(const Item &item, RunBatch run) {
+        Req me;
+        me.item = item;
+        std::unique_lock<std::mutex> lk(mu_);
+        pending_.push_back(&me);
+        if (busy_) {
+            cv_.wait(lk, [&] { return me.done || me.lead; });
+            if (me.done) return;  // another caller's batch carried this request
+        }
+        busy_ = true;  // (already true when the lead was handed over)
+        std::vector<Req *> batch;
+        batch.swap(pending_);
+        lk.unlock();
+        std::vector<Item> items;
+        items.reserve(batch.size());
+        for (Req *r : batch) items.push_back(r->item);
+        run(items);
+        lk.lock();
+        for (Req *r : batch) r->done = true;  // (a waiter's Req lives on its stack until it wakes under this lock)
+        if (!pending_.empty())
+            pending_.front()->lead = true;
+        else
+            busy_ = false;
+        lk.unlock();
+        cv_.notify_all();
+    }
+
+   private:
+    struct Req {
+        Item item;
+        bool done = false, lead = false;
+    };
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Req *> pending_;
+    bool busy_ = false;
+};
+struct LweCall {
+    LweSample *result;
+    const LweSample *x;
+};
+// one coalescer per (entry point, key object, mu): only calls that can share a launch meet in it
+struct CoalesceKey {
+    int kind;
+    const void *key;
+    int32_t mu;
+    bool operator<(const CoalesceKey &o) const {
+        if (kind != o.kind) return kind < o.kind;
+        if (key != o.key) return key < o.key;
+        return mu < o.mu;
+    }
+};
+inline Coalescer<LweCall> &lwe_coalescer(int kind, const void *key, int32_t mu) {
+    static std::mutex m;
+    static std::map<CoalesceKey, Coalescer<LweCall> *> reg;  // entries live for the process (a few dozen bytes per key and mu)
+    std::lock_guard<std::mutex> lk(m);
+    Coalescer<LweCall> *&c = reg[CoalesceKey{kind, key, mu}];
+    if (!c) c = new Coalescer<LweCall>();
+    return *c;
+}
+
 inline int &device_ordinal() {
     static int d = 0;
     return d;
@@ -386,19 +463,51 @@ inline void get_tlwe(Resident &R, TLweSample *s, const void *src_d, int N) {
     for (int q = 0; q < 2; q++) std::memcpy(s->a[q].coefsT, &f[(size_t)q * N], sizeof(int32_t) * (size_t)N);
 }
 
+inline void tfhe_bootstrap_woKS_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
+                                          const LweSample *const *xs, int count);
+inline void tfhe_bootstrap_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
+                                     const LweSample *const *xs, int count);
+inline void lweKeySwitch_array(LweSample *const *results, const LweKeySwitchKey *ks, const LweSample *const *samples, int count);
+// a coalesced batch of one-sample calls: one call -> `one` (the one-sample path), several -> `many` (the array form)
+template <class One, class Many>
+inline void run_lwe_calls(const std::vector<LweCall> &calls, One one, Many many) {
+    if (calls.size() == 1) {
+        one(calls[0].result, calls[0].x);
+        return;
+    }
+    std::vector<LweSample *> rs(calls.size());
+    std::vector<const LweSample *> xs(calls.size());
+    for (size_t i = 0; i < calls.size(); i++) {
+        rs[i] = calls[i].result;
+        xs[i] = calls[i].x;
+    }
+    many(rs.data(), xs.data(), (int)calls.size());
+}
 inline void tfhe_bootstrap_woKS_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x) {
-    TFHE_AMD_SHIM_GUARD();
-    Resident &R = attach(bk);
-    put_lwe(R, R.d_in, x, R.n);
-    check(tfhe_amd_bootstrap_woks(R.ctx, (int32_t *)R.d_out, mu, (const int32_t *)R.d_in, 1), R.ctx, "bootstrap_woks");
-    get_lwe(R, result, R.d_out, R.N);
+    lwe_coalescer(0, bk, mu).call(LweCall{result, x}, [&](const std::vector<LweCall> &calls) {
+        run_lwe_calls(calls,
+                      [&](LweSample *r, const LweSample *in) {
+                          TFHE_AMD_SHIM_GUARD();
+                          Resident &R = attach(bk);
+                          put_lwe(R, R.d_in, in, R.n);
+                          check(tfhe_amd_bootstrap_woks(R.ctx, (int32_t *)R.d_out, mu, (const int32_t *)R.d_in, 1), R.ctx, "bootstrap_woks");
+                          get_lwe(R, r, R.d_out, R.N);
+                      },
+                      [&](LweSample *const *rs, const LweSample *const *xs, int n) { ::tfhe_amd_compat::tfhe_bootstrap_woKS_FFT_array(rs, bk, mu, xs, n); });
+    });
 }
 inline void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x) {
-    TFHE_AMD_SHIM_GUARD();
-    Resident &R = attach(bk);
-    put_lwe(R, R.d_in, x, R.n);
-    check(tfhe_amd_bootstrap(R.ctx, (int32_t *)R.d_out, mu, (const int32_t *)R.d_in, 1), R.ctx, "bootstrap");
-    get_lwe(R, result, R.d_out, R.n);
+    lwe_coalescer(1, bk, mu).call(LweCall{result, x}, [&](const std::vector<LweCall> &calls) {
+        run_lwe_calls(calls,
+                      [&](LweSample *r, const LweSample *in) {
+                          TFHE_AMD_SHIM_GUARD();
+                          Resident &R = attach(bk);
+                          put_lwe(R, R.d_in, in, R.n);
+                          check(tfhe_amd_bootstrap(R.ctx, (int32_t *)R.d_out, mu, (const int32_t *)R.d_in, 1), R.ctx, "bootstrap");
+                          get_lwe(R, r, R.d_out, R.n);
+                      },
+                      [&](LweSample *const *rs, const LweSample *const *xs, int n) { ::tfhe_amd_compat::tfhe_bootstrap_FFT_array(rs, bk, mu, xs, n); });
+    });
 }
 inline void tfhe_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bkFFT, const int *bara, const int n,
                                  const TGswParams *bk_params) {
@@ -464,11 +573,17 @@ inline Resident &attach_ks(const LweKeySwitchKey *ks) {
     return it->second;
 }
 inline void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample) {
-    TFHE_AMD_SHIM_GUARD();
-    Resident &R = attach_ks(ks);
-    put_lwe(R, R.d_in, sample, R.N);
-    check(tfhe_amd_keyswitch(R.ctx, (int32_t *)R.d_out, (const int32_t *)R.d_in, 1), R.ctx, "keyswitch");
-    get_lwe(R, result, R.d_out, R.n);
+    lwe_coalescer(2, ks, 0).call(LweCall{result, sample}, [&](const std::vector<LweCall> &calls) {
+        run_lwe_calls(calls,
+                      [&](LweSample *r, const LweSample *in) {
+                          TFHE_AMD_SHIM_GUARD();
+                          Resident &R = attach_ks(ks);
+                          put_lwe(R, R.d_in, in, R.N);
+                          check(tfhe_amd_keyswitch(R.ctx, (int32_t *)R.d_out, (const int32_t *)R.d_in, 1), R.ctx, "keyswitch");
+                          get_lwe(R, r, R.d_out, R.n);
+                      },
+                      [&](LweSample *const *rs, const LweSample *const *xs, int n) { ::tfhe_amd_compat::lweKeySwitch_array(rs, ks, xs, n); });
+    });
 }
 
 // ---- array forms behind the reference names ----------------------------------------------------
@@ -677,8 +792,25 @@ class PocEngine {
         }
     }
     // tfhe_CircuitBootstrapFFT(TGswSample32* result, const LweSample32* sample, env)   poc:823-873
+    // Calls from several host threads are coalesced into one tfhe_CircuitBootstrapFFT_array launch (Coalescer above).
     template <class TGswSample32T, class LweSample32T>
     void tfhe_CircuitBootstrapFFT(TGswSample32T *result, const LweSample32T *sample) {
+        cb_calls_.call(std::make_pair((void *)result, (const void *)sample), [&](const std::vector<std::pair<void *, const void *>> &calls) {
+            if (calls.size() == 1) {
+                tfhe_CircuitBootstrapFFT_one((TGswSample32T *)calls[0].first, (const LweSample32T *)calls[0].second);
+                return;
+            }
+            std::vector<TGswSample32T *> rs(calls.size());
+            std::vector<const LweSample32T *> xs(calls.size());
+            for (size_t i = 0; i < calls.size(); i++) {
+                rs[i] = (TGswSample32T *)calls[i].first;
+                xs[i] = (const LweSample32T *)calls[i].second;
+            }
+            tfhe_CircuitBootstrapFFT_array(rs.data(), xs.data(), (int)calls.size());
+        });
+    }
+    template <class TGswSample32T, class LweSample32T>
+    void tfhe_CircuitBootstrapFFT_one(TGswSample32T *result, const LweSample32T *sample) {
         TFHE_AMD_SHIM_GUARD();
         check(tfhe_amd_memcpy_h2d(c2_, d_a_, sample->a, sizeof(int32_t) * (size_t)(p_.N1 + 1)), c2_, "h2d");
         die(tfhe_amd_circuit_bootstrap(cb_, (int32_t *)d_b_, (const int32_t *)d_a_, 1), "circuit_bootstrap");
@@ -862,6 +994,7 @@ class PocEngine {
     PocEngine(const PocEngine &);
     PocEngine &operator=(const PocEngine &);
     const GlobalsT *env_;
+    Coalescer<std::pair<void *, const void *> > cb_calls_;
     tfhe_amd_cb *cb_;
     tfhe_amd_cb_pool *pool_;
     std::vector<int> pool_devices_;

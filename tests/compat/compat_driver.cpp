@@ -305,18 +305,53 @@ static int run_arr(const char *inp, const char *outp) {
     const double t1 = now_s();
     for (int c = 0; c < count; c++) tfhe_bootstrap_FFT(&rl[c], &bk, mu, &x[c]);
     const double t_loop = now_s() - t1;
-    // the one-sample shim from several host threads at once (the shims take one lock: serialised, never corrupted)
-    const int tcount = count < 8 ? count : 8;
+    // The reference's OWN parallel construct -- `#pragma omp parallel for` over independent one-item calls
+    // (parallel/src/test_parallel_multiplications.cpp:62) -- on the unmodified one-sample entry point: the calls of the
+    // threads are coalesced by the shim into array launches (same results, a multiple of the serial loop's rate)
+    const int tcount = count;
     std::vector<Torus32> a_thr((size_t)tcount * n);
     std::vector<LweSample> rt((size_t)tcount);
     for (int c = 0; c < tcount; c++) rt[c] = LweSample{a_thr.data() + (size_t)c * n, 0, 0};
+    const int want_threads = getenv("TFHE_COMPAT_THREADS") ? atoi(getenv("TFHE_COMPAT_THREADS")) : 32;
+    const int nthreads = count < want_threads ? (count < 2 ? 2 : count) : want_threads;
+    const double t2 = now_s();
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+    for (int c = 0; c < tcount; c++) tfhe_bootstrap_FFT(&rt[c], &bk, mu, &x[c]);
+#else
     {
         std::vector<std::thread> pool;
-        for (int w = 0; w < 4; w++)
+        for (int w = 0; w < nthreads; w++)
             pool.emplace_back([&, w]() {
-                for (int c = w; c < tcount; c += 4) tfhe_bootstrap_FFT(&rt[c], &bk, mu, &x[c]);
+                for (int c = w; c < tcount; c += nthreads) tfhe_bootstrap_FFT(&rt[c], &bk, mu, &x[c]);
             });
         for (auto &th : pool) th.join();
+    }
+#endif
+    const double t_par = now_s() - t2;
+    // the other coalesced entry points from threads: woKS and the key switch on its outputs == the full bootstrap
+    std::vector<Torus32> a_thr_woks((size_t)tcount * N), a_thr_ks((size_t)tcount * n);
+    std::vector<LweSample> rtu((size_t)tcount), rtk((size_t)tcount);
+    for (int c = 0; c < tcount; c++) {
+        rtu[c] = LweSample{a_thr_woks.data() + (size_t)c * N, 0, 0};
+        rtk[c] = LweSample{a_thr_ks.data() + (size_t)c * n, 0, 0};
+    }
+    {
+        const int nt = tcount < 8 ? tcount : 8, upto = tcount < 64 ? tcount : 64;
+        std::vector<std::thread> pool;
+        for (int w = 0; w < nt; w++)
+            pool.emplace_back([&, w]() {
+                for (int c = w; c < upto; c += nt) {
+                    tfhe_bootstrap_woKS_FFT(&rtu[c], &bk, mu, &x[c]);
+                    lweKeySwitch(&rtk[c], &ksk, &rtu[c]);
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (int c = 0; c < upto; c++)
+            if (rtk[c].b != rl[c].b || memcmp(rtk[c].a, rl[c].a, 4 * (size_t)n) != 0) {
+                fprintf(stderr, "coalesced woKS + key switch differs from the loop at %d\n", c);
+                return 3;
+            }
     }
     bool same = a_arr == a_loop && a_ks == a_loop;
     // the array forms over SEVERAL devices: the same loop cut into contiguous slices, one pool member per device
@@ -374,9 +409,16 @@ static int run_arr(const char *inp, const char *outp) {
     out.save(outp);
     printf("{\"count\": %d, \"array_seconds\": %.6f, \"array_bootstraps_per_s\": %.1f, \"loop_seconds\": %.6f, "
            "\"loop_bootstraps_per_s\": %.1f, \"array_identical_to_loop\": %s, \"pool_devices\": %d, \"pool_seconds\": %.6f, "
-           "\"pool_identical_to_loop\": %s}\n",
+           "\"pool_identical_to_loop\": %s, \"parallel_for_threads\": %d, \"parallel_for_seconds\": %.6f, "
+           "\"parallel_for_bootstraps_per_s\": %.1f, \"openmp\": %s}\n",
            count, t_arr, count / t_arr, t_loop, count / t_loop, same ? "true" : "false", (int)devs.size(), t_pool,
-           devs.size() > 1 ? (pool_same ? "true" : "false") : "null");
+           devs.size() > 1 ? (pool_same ? "true" : "false") : "null", nthreads, t_par, count / t_par,
+#ifdef _OPENMP
+           "true"
+#else
+           "false"
+#endif
+    );
 #ifdef DROPIN
     tfhe_amd_dropin_release(nullptr);
 #else
@@ -513,6 +555,14 @@ static int run_poc(const char *inp, const char *outp) {
     }
     eng.tfhe_CircuitBootstrapFFT_array(agp.data(), axp.data(), count);
     bool same = arr_res == all_res;
+    // the one-sample call from several host threads at once: coalesced into array launches, same results
+    {
+        std::fill(arr_res.begin(), arr_res.end(), 0);
+        std::vector<std::thread> pool;
+        for (int c = 0; c < count; c++) pool.emplace_back([&, c]() { eng.tfhe_CircuitBootstrapFFT(agp[c], axp[c]); });
+        for (auto &th : pool) th.join();
+        same = same && arr_res == all_res;
+    }
     const std::vector<int> devs = env_devices();
     if (devs.size() > 1) {
         std::fill(arr_res.begin(), arr_res.end(), 0);

@@ -27,7 +27,7 @@ def build_driver(lib_path, tag):
     # same sources against libtfhe_amd_emu_san.so)
     if not b.linked_against(out, lib_path, [src, hdr, lib_path]):
         libdir, libname = os.path.dirname(lib_path), os.path.basename(lib_path)
-        subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+        subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fopenmp", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
                                "-L" + libdir, "-l:" + libname, "-Wl,-rpath," + libdir, "-lpthread"])
         b.record_engine(out, lib_path)
     return out
@@ -173,6 +173,7 @@ def run_array_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, coun
             return None
     stats = json.loads(open(fs).read())
     assert stats["count"] == count and stats["array_identical_to_loop"] is True
+    assert stats["openmp"] is True and stats["parallel_for_bootstraps_per_s"] > 0  # the reference's parallel construct, coalesced
     got = np.fromfile(fo, np.int32).reshape(count, n + 1)
     return stats, got, (bk, ks, x)
 
@@ -235,6 +236,16 @@ def prerun_gpu_drivers():
         os.remove(os.path.join(d, f))
     lk, bk, ks, x = RB._inputs()
     run_array_form(drv, d, n=RB.n, inputs=(bk, ks, x), phase="run", devices="0,0")  # + over a pool of two members, both on device 0
+    # the coalesced OpenMP loop with 256 threads (the default run above uses 32): stats only, kept beside the others
+    d2 = os.path.join(GPU_RUN_DIR, "arr256")
+    os.makedirs(d2, exist_ok=True)
+    for f in os.listdir(d2):
+        os.remove(os.path.join(d2, f))
+    os.environ["TFHE_COMPAT_THREADS"] = "256"
+    try:
+        run_array_form(drv, d2, n=RB.n, inputs=(bk, ks, x), phase="run")
+    finally:
+        del os.environ["TFHE_COMPAT_THREADS"]
 
 
 def _need(form):
@@ -276,6 +287,13 @@ def test_array_forms_gpu():
     assert stats["array_bootstraps_per_s"] > 50 * stats["loop_bootstraps_per_s"], stats
     # the same loop over a pool of two members sharing the one GPU (two host threads, two streams, two key copies): identical
     assert stats["pool_devices"] == 2 and stats["pool_identical_to_loop"] is True, stats
+    # the reference's `#pragma omp parallel for` over ONE-SAMPLE calls (32 threads), coalesced by the shim into array launches:
+    # a multiple of the serial loop's rate from an unmodified loop body
+    assert stats["parallel_for_bootstraps_per_s"] > 5 * stats["loop_bootstraps_per_s"], stats
+    import json
+    s256 = json.loads(open(os.path.join(GPU_RUN_DIR, "arr256", "arr_stats.json")).read())
+    assert s256["parallel_for_threads"] == 256 and s256["array_identical_to_loop"] is True
+    assert s256["parallel_for_bootstraps_per_s"] > stats["parallel_for_bootstraps_per_s"], (s256, stats)  # more callers, larger launches
 
 
 def _need_arr():

@@ -35,7 +35,7 @@ def build_lib_driver(engine_lib, tag):
     src = os.path.join(ROOT, "tests", "compat", "compat_driver.cpp")
     if not b.linked_against(out, engine_lib, [src, dropin, os.path.join(INC, "tfhe_amd_dropin.h")]):
         d = os.path.dirname(dropin)
-        subprocess.check_call(["g++", "-std=c++11", "-O1", "-DDROPIN", "-I" + INC, src, "-o", out, "-L" + d,
+        subprocess.check_call(["g++", "-std=c++11", "-O1", "-fopenmp", "-DDROPIN", "-I" + INC, src, "-o", out, "-L" + d,
                                "-l:" + os.path.basename(dropin), "-Wl,-rpath," + d, "-lpthread"])
         b.record_engine(out, engine_lib)
     return out
