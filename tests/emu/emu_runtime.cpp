@@ -520,6 +520,10 @@ hipError_t hipEventDestroy(hipEvent_t e) {
     return hipSuccess;
 }
 hipError_t emu_func_set_attribute(const void *fn, int bytes) {
+    if (emu::t_capture) {  // the host library's own rule (tfhe_amd_bootstrap_streamed): every kernel of a schedule is configured before its capture
+        fprintf(stderr, "emu: hipFuncSetAttribute inside a stream capture\n");
+        abort();
+    }
     std::lock_guard<std::mutex> lk(emu::g_dev_mu);
     emu::g_lds_attr[std::make_pair(fn, emu::t_device)] = bytes;
     return hipSuccess;

@@ -348,20 +348,26 @@ def check_streamed_graph(lib_path, N=1024, n=12, l=2, Bgbit=10, ks_t=8, ks_bb=2,
         s.close()
 
 
-def check_streamed_graph_batch_classes(lib_path, N=1024, n=6, l=2, Bgbit=10, ks_t=8, ks_bb=2, big=1031, small=8, seed=92):
+def check_streamed_graph_batch_classes(lib_path, N=1024, n=6, l=2, Bgbit=10, ks_t=8, ks_bb=2, big=1031, small=8, seed=92, br_split=None,
+                                       order=None):
     """graph mode with NO prior plain bootstrap on the context, at a batch served by the 8-wave kernel and then at one
     served by the latency-shaped kernel (another kernel class: its first launch sets an LDS attribute, which must not
-    happen inside the capture -- the warm-up is per class), each: warm-up call, capturing call, replay"""
+    happen inside the capture -- the warm-up is per class), each: warm-up call, capturing call, replay.
+    br_split / order: the latency-shaped kernel for EVERY batch, small batch first -- the schedule's two 0-step launches then
+    change kernel (4-wave -> 8-wave form) while the 1-step class stays: the warm-up is keyed on both (the emulator aborts on a
+    hipFuncSetAttribute inside a capture)"""
     s = GateSetup(lib_path, N, n, l, Bgbit, ks_t, ks_bb)
     rs = np.random.RandomState(seed)
     e = s.eng
     try:
+        if br_split is not None:
+            e.set_option(T.OPT_BR_SPLIT, br_split)
         e.set_option(T.OPT_STREAMED_GRAPH, 1)
         mu = 1 << 29
         x = rs.randint(-2 ** 31, 2 ** 31, size=(big, n + 1)).astype(np.int32)
         x_d, out_d = e.to_device(x), e.alloc(x.nbytes)
         got = {}
-        for B in (big, small):
+        for B in (order or (big, small)):
             for call in range(3):
                 e._chk(e.lib.tfhe_amd_bootstrap_streamed(e.ctx, out_d.ptr, mu, x_d.ptr, B))
                 got[(B, call)] = out_d.download(np.int32, x.shape)[:B].copy()

@@ -99,6 +99,12 @@ def test_streamed_graph_without_prior_plain_call_emu(emu_lib):
     P.check_streamed_graph_batch_classes(emu_lib, n=2, big=20, small=3)
 
 
+def test_streamed_graph_zero_step_class_emu(emu_lib):
+    """the latency-shaped kernel for every batch (split limit 2^30), a batch of 3 and then of 1030: the 1-step launches keep their
+    class, the 0-step launches move from the 4-wave to the 8-wave form, whose LDS attribute must be set outside the capture"""
+    P.check_streamed_graph_batch_classes(emu_lib, n=2, big=1030, small=3, br_split=1 << 30, order=(3, 1030))
+
+
 def test_gate_wide_batch_logic_emu(emu_lib):
     """the wide-batch check of the GPU suite (there: B = 1031, 8-wave workgroups) at a size the emulator finishes"""
     P.check_gate_wide_batch(emu_lib, l=3, Bgbit=7, B=30, n=2)

@@ -496,6 +496,7 @@ def test_two_contexts_on_two_host_threads(gpu_lib):
 
 def test_streamed_graph_across_kernel_classes(gpu_lib):
     P.check_streamed_graph_batch_classes(gpu_lib)
+    P.check_streamed_graph_batch_classes(gpu_lib, br_split=1 << 30, order=(8, 1031))  # the 0-step launches change kernel form
 
 
 def test_gate_path_latency_kernel_other_bgbit(gpu_lib):
