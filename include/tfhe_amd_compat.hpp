@@ -99,9 +99,8 @@ struct ResidentKey {
         return Bgbit < o.Bgbit;
     }
 };
-// Threading contract: like the reference (global scratch in fft_processor_spqlios.cpp:21-24,163-164, global RNG
-// numeric_functions.cpp:14) the shims are SINGLE-THREADED: the registry is an unguarded static map and every
-// resident engine has one set of staging buffers.  Concurrent callers use the batch C ABI with one context each.
+// (The reference itself is single-threaded here: global scratch in fft_processor_spqlios.cpp:21-24,163-164, global RNG
+// numeric_functions.cpp:14.  The registry and every resident engine's one set of staging buffers are protected by the lock below.)
 inline std::map<ResidentKey, Resident> &registry() {
     static std::map<ResidentKey, Resident> r;
     return r;
