@@ -50,6 +50,7 @@ ABI_SYMBOLS = [
     "tfhe_amd_pool_create", "tfhe_amd_pool_destroy", "tfhe_amd_pool_last_error", "tfhe_amd_pool_size", "tfhe_amd_pool_device",
     "tfhe_amd_pool_ctx", "tfhe_amd_pool_load_keys", "tfhe_amd_pool_load_keys_torus", "tfhe_amd_pool_bootstrap_host",
     "tfhe_amd_pool_bootstrap_woks_host", "tfhe_amd_pool_keyswitch_host", "tfhe_amd_pool_last_split", "tfhe_amd_pool_set_option",
+    "tfhe_amd_pool_bootstrap_rows", "tfhe_amd_pool_bootstrap_woks_rows", "tfhe_amd_pool_keyswitch_rows",
     "tfhe_amd_cb_pool_create", "tfhe_amd_cb_pool_destroy", "tfhe_amd_cb_pool_last_error", "tfhe_amd_cb_pool_size",
     "tfhe_amd_cb_pool_member", "tfhe_amd_cb_pool_load_preks", "tfhe_amd_cb_pool_load_bk_fft", "tfhe_amd_cb_pool_load_bk_torus",
     "tfhe_amd_cb_pool_load_privks_plane", "tfhe_amd_cb_pool_circuit_bootstrap_host",

@@ -177,8 +177,9 @@ struct Pipe {
         s_in = s_out = nullptr;
     }
 };
-template <class Launch>
-int pipelined_rows(tfhe_amd_ctx *c, Pipe &p, char *out, size_t out_row, const char *in, size_t in_row, size_t mid_row, int lo, int hi, int chunk,
+// rows_in(first, rows, dst) fills dst with rows first .. first + rows - 1; rows_out(first, rows, src) takes them back
+template <class RowsIn, class RowsOut, class Launch>
+int pipelined_rows(tfhe_amd_ctx *c, Pipe &p, RowsOut rows_out, size_t out_row, RowsIn rows_in, size_t in_row, size_t mid_row, int lo, int hi, int chunk,
                    Launch launch) {
     if (int rc = p.prepare(c, (size_t)chunk * in_row, (size_t)chunk * out_row, (size_t)chunk * mid_row)) return rc;
     int rows_of[SETS] = {0, 0, 0}, at_of[SETS] = {0, 0, 0};
@@ -190,7 +191,7 @@ int pipelined_rows(tfhe_amd_ctx *c, Pipe &p, char *out, size_t out_row, const ch
         double t0 = now_s();
         if (int rc = tfhe_amd_event_sync(c, p.ev_out[s])) return rc;
         double t1 = now_s();
-        memcpy(out + (size_t)at_of[s] * out_row, p.st[s].h_out, (size_t)rows_of[s] * out_row);
+        rows_out(at_of[s], rows_of[s], p.st[s].h_out);
         t_wait += t1 - t0;
         t_out += now_s() - t1;
         rows_of[s] = 0;
@@ -203,7 +204,7 @@ int pipelined_rows(tfhe_amd_ctx *c, Pipe &p, char *out, size_t out_row, const ch
         rc = drain(s);  // the set's previous chunk (k - 3): its buffers are reused now
         if (rc) break;
         double t0 = now_s();
-        memcpy(set.h_in, in + (size_t)at * in_row, (size_t)rows * in_row);
+        rows_in(at, rows, set.h_in);
         double t1 = now_s();
         t_in += t1 - t0;
         rc = tfhe_amd_set_stream(c, p.s_in);                                              // copy in
@@ -248,8 +249,8 @@ void slice_of(int total, int r, int m, int *lo, int *hi) {
 }
 
 // copy in -> launch -> copy out of rows [lo, hi) as one piece (in rounds of at most STAGE_BYTES per direction)
-template <class Launch>
-int staged_rows(tfhe_amd_ctx *c, Staging &st, char *out, size_t out_row, const char *in, size_t in_row, size_t mid_row, int lo, int hi, Launch launch) {
+template <class RowsIn, class RowsOut, class Launch>
+int staged_rows(tfhe_amd_ctx *c, Staging &st, RowsOut rows_out, size_t out_row, RowsIn rows_in, size_t in_row, size_t mid_row, int lo, int hi, Launch launch) {
     const size_t big = in_row > out_row ? in_row : out_row;
     int per_round = (int)(STAGE_BYTES / big);
     if (per_round < 1) per_round = 1;
@@ -259,11 +260,11 @@ int staged_rows(tfhe_amd_ctx *c, Staging &st, char *out, size_t out_row, const c
         if (int rc = st.ensure_mid(c, (size_t)per_round * mid_row)) return rc;
     for (int at = lo; at < hi; at += per_round) {
         const int rows = hi - at < per_round ? hi - at : per_round;
-        memcpy(st.h_in, in + (size_t)at * in_row, (size_t)rows * in_row);  // pageable -> pinned: the copy below then runs at the link's rate
+        rows_in(at, rows, st.h_in);  // into pinned memory: the copy below then runs at the link's rate
         if (int rc = tfhe_amd_memcpy_h2d(c, st.d_in, st.h_in, (size_t)rows * in_row)) return rc;
         if (int rc = launch(st.d_out, st.d_in, rows)) return rc;
         if (int rc = tfhe_amd_memcpy_d2h(c, st.h_out, st.d_out, (size_t)rows * out_row)) return rc;  // waits for the launch
-        memcpy(out + (size_t)at * out_row, st.h_out, (size_t)rows * out_row);
+        rows_out(at, rows, st.h_out);
     }
     return TFHE_AMD_OK;
 }
@@ -310,10 +311,12 @@ int member_status(tfhe_amd_pool::Member &mb, int rc) {
     return rc;
 }
 
-// launch(ctx, d_mid, d_out, d_in, rows): the operation on device buffers; d_mid (rows x mid_ints) is scratch owned by the caller
-template <class Launch>
-int pool_rows(tfhe_amd_pool *pool, int32_t *out, size_t out_ints, const int32_t *x, size_t in_ints, size_t mid_ints, int count, Launch launch) {
-    if (!pool || !out || !x || count < 0) return TFHE_AMD_ERR_PARAM;
+// launch(ctx, d_mid, d_out, d_in, rows): the operation on device buffers; d_mid (rows x mid_ints) is scratch owned by the caller.
+// rows_in / rows_out move rows between the caller's representation and the members' pinned staging buffers; they are called
+// on the members' threads, concurrently for DISJOINT row ranges.
+template <class RowsIn, class RowsOut, class Launch>
+int pool_rows_fn(tfhe_amd_pool *pool, RowsOut rows_out, size_t out_ints, RowsIn rows_in, size_t in_ints, size_t mid_ints, int count, Launch launch) {
+    if (!pool || count < 0) return TFHE_AMD_ERR_PARAM;
     std::lock_guard<std::mutex> lk(pool->call_mu);
     const int members = (int)pool->m.size();
     return on_every_member(pool, [=](int i) {
@@ -329,13 +332,13 @@ int pool_rows(tfhe_amd_pool *pool, int32_t *out, size_t out_ints, const int32_t 
         int rc;
         if (chunk > 0 && hi - lo >= 2 * chunk) {
             mb.last_chunks = (hi - lo + chunk - 1) / chunk;
-            rc = pipelined_rows(mb.ctx, mb.pipe, (char *)out, out_ints * 4, (const char *)x, in_ints * 4, mid_ints * 4, lo, hi, chunk,
+            rc = pipelined_rows(mb.ctx, mb.pipe, rows_out, out_ints * 4, rows_in, in_ints * 4, mid_ints * 4, lo, hi, chunk,
                                 [&](Staging &set, void *o, const void *in, int rows) {
                                     return launch(mb.ctx, (int32_t *)set.d_mid, (int32_t *)o, (const int32_t *)in, rows);
                                 });
         } else {
             mb.last_chunks = 1;
-            rc = staged_rows(mb.ctx, mb.st, (char *)out, out_ints * 4, (const char *)x, in_ints * 4, mid_ints * 4, lo, hi,
+            rc = staged_rows(mb.ctx, mb.st, rows_out, out_ints * 4, rows_in, in_ints * 4, mid_ints * 4, lo, hi,
                              [&](void *o, const void *in, int rows) {
                                  return launch(mb.ctx, (int32_t *)mb.st.d_mid, (int32_t *)o, (const int32_t *)in, rows);
                              });
@@ -343,6 +346,23 @@ int pool_rows(tfhe_amd_pool *pool, int32_t *out, size_t out_ints, const int32_t 
         mb.last_seconds = now_s() - t0;
         return member_status(mb, rc);
     });
+}
+// flat host arrays
+template <class Launch>
+int pool_rows(tfhe_amd_pool *pool, int32_t *out, size_t out_ints, const int32_t *x, size_t in_ints, size_t mid_ints, int count, Launch launch) {
+    if (!out || !x) return TFHE_AMD_ERR_PARAM;
+    return pool_rows_fn(
+        pool, [=](int first, int rows, const void *src) { memcpy(out + (size_t)first * out_ints, src, (size_t)rows * out_ints * 4); }, out_ints,
+        [=](int first, int rows, void *dst) { memcpy(dst, x + (size_t)first * in_ints, (size_t)rows * in_ints * 4); }, in_ints, mid_ints, count, launch);
+}
+// the caller's own representation, through its two callbacks
+template <class Launch>
+int pool_rows_cb(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, size_t out_ints, tfhe_amd_rows_in_fn get, size_t in_ints, size_t mid_ints, void *user,
+                 int count, Launch launch) {
+    if (!put || !get) return TFHE_AMD_ERR_PARAM;
+    return pool_rows_fn(
+        pool, [=](int first, int rows, const void *src) { put(user, first, rows, (const int32_t *)src); }, out_ints,
+        [=](int first, int rows, void *dst) { get(user, first, rows, (int32_t *)dst); }, in_ints, mid_ints, count, launch);
 }
 }  // namespace
 
@@ -446,6 +466,28 @@ int tfhe_amd_pool_keyswitch_host(tfhe_amd_pool *pool, int32_t *out, const int32_
     if (!pool) return TFHE_AMD_ERR_PARAM;
     return pool_rows(pool, out, (size_t)pool->p.ks_n_out + 1, x, (size_t)pool->p.N + 1, 0, count,
                      [](tfhe_amd_ctx *c, int32_t *, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_keyswitch(c, o, in, rows); });
+}
+// the same three operations on the CALLER's representation of the rows (e.g. an array of LweSample pointers): `get` fills a
+// member's pinned staging buffer with rows [first, first + rows), `put` takes the results; no flat intermediate array
+static int launch_bootstrap(tfhe_amd_ctx *c, int32_t mu, int32_t *mid, int32_t *o, const int32_t *in, int rows) {
+    const int rc = tfhe_amd_bootstrap_woks(c, mid, mu, in, rows);
+    return rc ? rc : tfhe_amd_keyswitch(c, o, mid, rows);
+}
+int tfhe_amd_pool_bootstrap_rows(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int32_t mu, int count) {
+    if (!pool) return TFHE_AMD_ERR_PARAM;
+    const size_t row = (size_t)pool->p.n + 1;
+    return pool_rows_cb(pool, put, row, get, row, (size_t)pool->p.N + 1, user, count,
+                        [mu](tfhe_amd_ctx *c, int32_t *mid, int32_t *o, const int32_t *in, int rows) { return launch_bootstrap(c, mu, mid, o, in, rows); });
+}
+int tfhe_amd_pool_bootstrap_woks_rows(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int32_t mu, int count) {
+    if (!pool) return TFHE_AMD_ERR_PARAM;
+    return pool_rows_cb(pool, put, (size_t)pool->p.N + 1, get, (size_t)pool->p.n + 1, 0, user, count,
+                        [mu](tfhe_amd_ctx *c, int32_t *, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_bootstrap_woks(c, o, mu, in, rows); });
+}
+int tfhe_amd_pool_keyswitch_rows(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int count) {
+    if (!pool) return TFHE_AMD_ERR_PARAM;
+    return pool_rows_cb(pool, put, (size_t)pool->p.ks_n_out + 1, get, (size_t)pool->p.N + 1, 0, user, count,
+                        [](tfhe_amd_ctx *c, int32_t *, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_keyswitch(c, o, in, rows); });
 }
 int tfhe_amd_pool_set_option(tfhe_amd_pool *pool, int option, int value) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
@@ -571,7 +613,10 @@ int tfhe_amd_cb_pool_circuit_bootstrap_host(tfhe_amd_cb_pool *pool, int32_t *out
         int lo, hi;
         slice_of(count, i, members, &lo, &hi);
         if (hi == lo) return (int)TFHE_AMD_OK;
-        const int rc = staged_rows(mb.ctx, mb.st, (char *)out, out_row, (const char *)x, in_row, 0, lo, hi, [&](void *o, const void *in, int rows) {
+        const int rc = staged_rows(
+            mb.ctx, mb.st, [=](int first, int rows, const void *src) { memcpy((char *)out + (size_t)first * out_row, src, (size_t)rows * out_row); }, out_row,
+            [=](int first, int rows, void *dst) { memcpy(dst, (const char *)x + (size_t)first * in_row, (size_t)rows * in_row); }, in_row, 0, lo, hi,
+            [&](void *o, const void *in, int rows) {
             return tfhe_amd_circuit_bootstrap(mb.cb, (int32_t *)o, (const int32_t *)in, rows);
         });
         if (rc) {  // the pipeline's message, or the level-2 context's when a copy failed

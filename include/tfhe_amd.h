@@ -345,6 +345,15 @@ int tfhe_amd_pool_load_keys_torus(tfhe_amd_pool *pool, const void *bk_torus, con
 int tfhe_amd_pool_bootstrap_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count);
 int tfhe_amd_pool_bootstrap_woks_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count);
 int tfhe_amd_pool_keyswitch_host(tfhe_amd_pool *pool, int32_t *out, const int32_t *x, int count);
+/* The same three operations on the CALLER'S OWN representation of the samples (e.g. an array of LweSample pointers): `get`
+ * fills a member's pinned staging buffer with rows [first, first + rows) in the flat layout above, `put` takes the result
+ * rows; no intermediate flat array, and in the pipelined form the gather of chunk k + 1 and the scatter of chunk k - 1 run while
+ * chunk k computes.  Both are called on the members' threads, concurrently for DISJOINT row ranges. */
+typedef void (*tfhe_amd_rows_in_fn)(void *user, int first, int rows, int32_t *dst);
+typedef void (*tfhe_amd_rows_out_fn)(void *user, int first, int rows, const int32_t *src);
+int tfhe_amd_pool_bootstrap_rows(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int32_t mu, int count);
+int tfhe_amd_pool_bootstrap_woks_rows(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int32_t mu, int count);
+int tfhe_amd_pool_keyswitch_rows(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int count);
 /* Inside a member a slice of at least 2 x CHUNK_ROWS samples is PIPELINED: chunks of CHUNK_ROWS whose kernels run back to
  * back on the member's stream while a second stream copies the next chunk in and a third copies the previous one out (three
  * sets of pinned staging buffers; shorter slices go as one piece).  TFHE_AMD_POOL_OPT_CHUNK_ROWS: default 2048 -- the blind

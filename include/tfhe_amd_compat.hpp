@@ -277,7 +277,6 @@ struct PoolResident {
     std::vector<int> devices;
     uint64_t fingerprint = 0;
     int n = 0, N = 0;
-    std::vector<int32_t> in, out;  // gathered rows (the pool stages them through its own pinned buffers)
 };
 inline std::map<ResidentKey, PoolResident> &pool_registry() {
     static std::map<ResidentKey, PoolResident> r;
@@ -295,15 +294,16 @@ inline PoolResident &attach_pool(const GswT *bkFFT, int n, int N, int l, int Bgb
     const ResidentKey key{bkFFT ? (const void *)bkFFT : (const void *)ks, (const void *)ks, n, N, l, Bgbit};
     const uint64_t fp = key_fingerprint(bkFFT, bkFFT ? n : 0, N, l, ks);
     auto it = reg.find(key);
+    const std::vector<int> want = device_list().empty() ? std::vector<int>(1, device_ordinal()) : device_list();
     if (it != reg.end()) {
-        if (it->second.fingerprint == fp && it->second.devices == device_list()) return it->second;
+        if (it->second.fingerprint == fp && it->second.devices == want) return it->second;
         tfhe_amd_pool_destroy(it->second.pool);  // the key was rebuilt in place, or the device list changed
         reg.erase(it);
     }
     PoolResident R;
     R.owner = owner;
     R.fingerprint = fp;
-    R.devices = device_list();
+    R.devices = want;
     R.n = n;
     R.N = N;
     tfhe_amd_params p;
@@ -615,28 +615,47 @@ inline void lwe_array_call(Resident &R, LweSample *const *results, int n_out, co
     check(tfhe_amd_memcpy_d2h(R.ctx, R.h_out, R.da_out, out_bytes), R.ctx, "d2h");
     scatter_lwe(results, (const int32_t *)R.h_out, count, n_out);
 }
-// the same call through a pool (more than one device named by set_devices): gather, ONE sharded call, scatter
+// the same call through a pool: the members gather the caller's samples straight into their pinned staging buffers and scatter
+// the results from them (tfhe_amd_pool_*_rows) -- no flat intermediate array, and for a long loop the gather of chunk k + 1 and
+// the scatter of chunk k - 1 run while chunk k computes
+struct LweRows {
+    LweSample *const *results;
+    const LweSample *const *xs;
+    int n_in, n_out;
+};
+inline void lwe_rows_in(void *user, int first, int rows, int32_t *dst) {
+    const LweRows *r = static_cast<const LweRows *>(user);
+    gather_lwe(dst, r->xs + first, rows, r->n_in);
+}
+inline void lwe_rows_out(void *user, int first, int rows, const int32_t *src) {
+    const LweRows *r = static_cast<const LweRows *>(user);
+    scatter_lwe(r->results + first, src, rows, r->n_out);
+}
 template <class Call>
 inline void lwe_array_pool_call(PoolResident &R, LweSample *const *results, int n_out, const LweSample *const *xs, int n_in, int count,
                                 Call call, const char *what) {
-    R.in.resize((size_t)count * (n_in + 1));
-    R.out.resize((size_t)count * (n_out + 1));
-    gather_lwe(R.in.data(), xs, count, n_in);
-    pool_check(call(R.out.data(), R.in.data()), R.pool, what);
-    scatter_lwe(results, R.out.data(), count, n_out);
+    LweRows rows{results, xs, n_in, n_out};
+    pool_check(call(&rows), R.pool, what);
 }
 inline PoolResident &attach_pool(const LweBootstrappingKeyFFT *bk) {
     return attach_pool(bk->bkFFT, bk->in_out_params->n, bk->accum_params->N, bk->bk_params->l, bk->bk_params->Bgbit, bk->ks, bk);
 }
-inline bool use_pool() { return device_list().size() > 1; }
+// Which array calls go through a pool: all of them once several devices are named; on ONE device those long enough for the pool's
+// pipelined form (>= 4096 samples: copies, gather and scatter hidden behind the kernels) -- shorter ones keep the resident
+// engine's one-piece path (no second key copy on the device for callers that never hand over long loops)
+#ifndef TFHE_AMD_COMPAT_POOL_MIN
+#define TFHE_AMD_COMPAT_POOL_MIN 4096
+#endif
+constexpr int POOL_MIN_COUNT = TFHE_AMD_COMPAT_POOL_MIN;
+inline bool use_pool(int count = 0) { return device_list().size() > 1 || count >= POOL_MIN_COUNT; }
 inline void tfhe_bootstrap_FFT_array(LweSample *const *results, const LweBootstrappingKeyFFT *bk, Torus32 mu,
                                      const LweSample *const *xs, int count) {
     TFHE_AMD_SHIM_GUARD();
     if (count <= 0) return;
-    if (use_pool()) {
+    if (use_pool(count)) {
         PoolResident &P = attach_pool(bk);
         lwe_array_pool_call(P, results, P.n, xs, P.n, count,
-                            [&](int32_t *o, const int32_t *i) { return tfhe_amd_pool_bootstrap_host(P.pool, o, mu, i, count); }, "bootstrap (array, pool)");
+                            [&](LweRows *r) { return tfhe_amd_pool_bootstrap_rows(P.pool, lwe_rows_out, lwe_rows_in, r, mu, count); }, "bootstrap (array, pool)");
         return;
     }
     Resident &R = attach(bk);
@@ -647,10 +666,11 @@ inline void tfhe_bootstrap_woKS_FFT_array(LweSample *const *results, const LweBo
                                           const LweSample *const *xs, int count) {
     TFHE_AMD_SHIM_GUARD();
     if (count <= 0) return;
-    if (use_pool()) {
+    if (use_pool(count)) {
         PoolResident &P = attach_pool(bk);
         lwe_array_pool_call(P, results, P.N, xs, P.n, count,
-                            [&](int32_t *o, const int32_t *i) { return tfhe_amd_pool_bootstrap_woks_host(P.pool, o, mu, i, count); }, "bootstrap_woks (array, pool)");
+                            [&](LweRows *r) { return tfhe_amd_pool_bootstrap_woks_rows(P.pool, lwe_rows_out, lwe_rows_in, r, mu, count); },
+                            "bootstrap_woks (array, pool)");
         return;
     }
     Resident &R = attach(bk);
@@ -660,10 +680,10 @@ inline void tfhe_bootstrap_woKS_FFT_array(LweSample *const *results, const LweBo
 inline void lweKeySwitch_array(LweSample *const *results, const LweKeySwitchKey *ks, const LweSample *const *samples, int count) {
     TFHE_AMD_SHIM_GUARD();
     if (count <= 0) return;
-    if (use_pool()) {  // a key-switch key on its own: a pool of contexts that hold nothing else (gadget unused: l = Bgbit = 1)
+    if (use_pool(count)) {  // a key-switch key on its own: a pool of contexts that hold nothing else (gadget unused: l = Bgbit = 1)
         PoolResident &P = attach_pool((const TGswSampleFFT *)nullptr, ks->out_params->n, ks->n, 1, 1, ks, ks);
         lwe_array_pool_call(P, results, P.n, samples, P.N, count,
-                            [&](int32_t *o, const int32_t *i) { return tfhe_amd_pool_keyswitch_host(P.pool, o, i, count); }, "keyswitch (array, pool)");
+                            [&](LweRows *r) { return tfhe_amd_pool_keyswitch_rows(P.pool, lwe_rows_out, lwe_rows_in, r, count); }, "keyswitch (array, pool)");
         return;
     }
     Resident &R = attach_ks(ks);

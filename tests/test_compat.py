@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEED = 0x5446484500000001
 
 
-def build_driver(lib_path, tag):
+def build_driver(lib_path, tag, defines=()):
     out = os.path.join(ROOT, "tests", "emu", "_build", f"compat_driver_{tag}")
     src = os.path.join(ROOT, "tests", "compat", "compat_driver.cpp")
     hdr = os.path.join(ROOT, "include", "tfhe_amd_compat.hpp")
@@ -27,7 +27,7 @@ def build_driver(lib_path, tag):
     # same sources against libtfhe_amd_emu_san.so)
     if not b.linked_against(out, lib_path, [src, hdr, lib_path]):
         libdir, libname = os.path.dirname(lib_path), os.path.basename(lib_path)
-        subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fopenmp", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+        subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fopenmp"] + ["-D" + d for d in defines] + ["-I" + os.path.join(ROOT, "include"), src, "-o", out,
                                "-L" + libdir, "-l:" + libname, "-Wl,-rpath," + libdir, "-lpthread"])
         b.record_engine(out, lib_path)
     return out
@@ -182,6 +182,16 @@ def test_array_forms_emu(emu_lib, tmp_path):
     stats, got, (bk, ks, x) = run_array_form(build_driver(emu_lib, "emu"), tmp_path)
     want = np.stack([O.bootstrap32(1024, bk, ks, 1 << 29, x[c], 2, 10, 8, 2) for c in range(x.shape[0])])
     assert np.array_equal(got, want), "tfhe_bootstrap_FFT_array"
+
+
+def test_long_array_calls_take_the_pool_route_on_one_device_emu(emu_lib, tmp_path):
+    """on ONE device an array call of >= 4096 samples goes through a one-member pool (pipelined gather / copy / compute / copy /
+    scatter straight from and to the caller's LweSample objects: tfhe_amd_pool_*_rows); the driver built with the threshold
+    lowered to 5 takes that route with 6 samples -- identical to the one-by-one loop and the oracle"""
+    drv = build_driver(emu_lib, "emu_poolmin5", defines=("TFHE_AMD_COMPAT_POOL_MIN=5",))
+    stats, got, (bk, ks, x) = run_array_form(drv, tmp_path)
+    want = np.stack([O.bootstrap32(1024, bk, ks, 1 << 29, x[c], 2, 10, 8, 2) for c in range(x.shape[0])])
+    assert np.array_equal(got, want)
 
 
 def test_array_forms_over_a_pool_emu(emu_lib, tmp_path):

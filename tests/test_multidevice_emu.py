@@ -168,6 +168,45 @@ def test_pool_pipelined_chunks(emu_lib, devices, count, chunk):
         s.close()
 
 
+def test_pool_rows_callbacks(emu_lib):
+    """tfhe_amd_pool_*_rows: the members fetch and deliver rows through the caller's two callbacks (here: rows kept in REVERSE order
+    in the caller's arrays), on their own threads, for disjoint ranges; pipelined chunks of 2 over two devices"""
+    import ctypes as C
+    N, n, l, Bgbit, t, bb = 1024, 2, 2, 10, 8, 2
+    s = P.GateSetup(emu_lib, N, n, l, Bgbit, t, bb)
+    pool = T.Pool([2, 5], torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=t, ks_basebit=bb, lib_path=emu_lib)
+    try:
+        pool.load_keys(s.bk, s.ks)
+        pool.set_chunk_rows(2)
+        count = 9
+        x = np.random.RandomState(9).randint(-2 ** 31, 2 ** 31, size=(count, n + 1)).astype(np.int32)
+        xr = np.ascontiguousarray(x[::-1])          # the caller's storage: row r of the call lives at index count - 1 - r
+        outr = np.zeros((count, n + 1), np.int32)
+        seen = []
+        IN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32))
+        OUT = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32))
+
+        def get(user, first, rows, dst):
+            seen.append((first, rows))
+            for r in range(rows):
+                C.memmove(C.addressof(dst.contents) + r * (n + 1) * 4, xr[count - 1 - (first + r)].ctypes.data, (n + 1) * 4)
+
+        def put(user, first, rows, src):
+            for r in range(rows):
+                C.memmove(outr[count - 1 - (first + r)].ctypes.data, C.addressof(src.contents) + r * (n + 1) * 4, (n + 1) * 4)
+
+        lib = pool.lib
+        lib.tfhe_amd_pool_bootstrap_rows.argtypes = [C.c_void_p, OUT, IN, C.c_void_p, C.c_int32, C.c_int]
+        g, p = IN(get), OUT(put)
+        assert lib.tfhe_amd_pool_bootstrap_rows(pool.pool, p, g, None, 1 << 29, count) == T.OK
+        assert np.array_equal(outr[::-1], s.eng.bootstrap(1 << 29, x))
+        assert sorted(seen) == [(0, 2), (2, 2), (4, 1), (5, 2), (7, 2)]  # member 0: rows 0-4 in chunks of 2, member 1: rows 5-8
+        assert lib.tfhe_amd_pool_bootstrap_rows(pool.pool, C.cast(None, OUT), g, None, 1 << 29, count) == T.ERR_PARAM  # a null callback
+    finally:
+        pool.close()
+        s.close()
+
+
 def test_pool_calls_from_several_host_threads_are_serialised(emu_lib):
     """a pool is not re-entrant: calls from several host threads take its one lock and run one after the other, each with the
     right answer (the shims' array forms rely on it)"""
