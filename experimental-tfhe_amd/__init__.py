@@ -53,7 +53,8 @@ ABI_SYMBOLS = [
     "tfhe_amd_pool_bootstrap_rows", "tfhe_amd_pool_bootstrap_woks_rows", "tfhe_amd_pool_keyswitch_rows",
     "tfhe_amd_cb_pool_create", "tfhe_amd_cb_pool_destroy", "tfhe_amd_cb_pool_last_error", "tfhe_amd_cb_pool_size",
     "tfhe_amd_cb_pool_member", "tfhe_amd_cb_pool_load_preks", "tfhe_amd_cb_pool_load_bk_fft", "tfhe_amd_cb_pool_load_bk_torus",
-    "tfhe_amd_cb_pool_load_privks_plane", "tfhe_amd_cb_pool_circuit_bootstrap_host",
+    "tfhe_amd_cb_pool_load_privks_plane", "tfhe_amd_cb_pool_circuit_bootstrap_host", "tfhe_amd_cb_pool_circuit_bootstrap_rows",
+    "tfhe_amd_cb_pool_set_option",
 ]
 
 
@@ -213,6 +214,7 @@ def load_library(path=None):
     lib.tfhe_amd_cb_pool_load_bk_torus.argtypes = [vp, i64p]
     lib.tfhe_amd_cb_pool_load_privks_plane.argtypes = [vp, C.c_int, i32p]
     lib.tfhe_amd_cb_pool_circuit_bootstrap_host.argtypes = [vp, i32p, i32p, C.c_int]
+    lib.tfhe_amd_cb_pool_set_option.argtypes = [vp, C.c_int, C.c_int]
     _libs[path] = lib
     return lib
 
@@ -766,6 +768,9 @@ class CircuitBootstrapPool:
         a = np.ascontiguousarray(privks, np.int32).reshape(2, -1)
         for u in range(2):
             self._chk(self.lib.tfhe_amd_cb_pool_load_privks_plane(self.pool, u, _np_ptr(a[u])))
+
+    def set_chunk_rows(self, rows):
+        self._chk(self.lib.tfhe_amd_cb_pool_set_option(self.pool, POOL_OPT_CHUNK_ROWS, int(rows)))
 
     def circuit_bootstrap(self, x):
         x = np.ascontiguousarray(x, np.int32).reshape(-1, self.p.N1 + 1)

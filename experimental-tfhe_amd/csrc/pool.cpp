@@ -519,14 +519,16 @@ struct tfhe_amd_cb_pool {
     struct Member {
         int device = 0;
         tfhe_amd_cb *cb = nullptr;
-        tfhe_amd_ctx *ctx = nullptr;  // the member's level-2 context (memory helpers)
-        Staging st;
+        tfhe_amd_ctx *ctx = nullptr;  // the member's level-2 context (memory helpers, streams, events)
+        Staging st;  // one-piece form
+        Pipe pipe;   // pipelined form (the pipeline's kernels all run on the handle's one stream, in order: its internal workspaces are safe)
         Worker *worker = nullptr;
         std::string err;
     };
     std::vector<Member> m;
     std::mutex call_mu;
     std::string err;
+    int chunk_rows = 1024;  // one Torus64 / N2 = 2048 ciphertext per wave on every SIMD: the blind rotation's full-rate batch
 };
 
 namespace {
@@ -575,6 +577,7 @@ void tfhe_amd_cb_pool_destroy(tfhe_amd_cb_pool *pool) {
         tfhe_amd_cb_pool::Member &mb = pool->m[i];
         if (mb.cb) {
             mb.st.release(mb.ctx);
+            mb.pipe.release(mb.ctx);
             tfhe_amd_cb_destroy(mb.cb);
         }
         mb.cb = nullptr;
@@ -603,8 +606,12 @@ int tfhe_amd_cb_pool_load_privks_plane(tfhe_amd_cb_pool *pool, int u_plane, cons
     return cb_pool_load(pool, plane, [u_plane, plane](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_privks_plane(cb, u_plane, plane); });
 }
 
-int tfhe_amd_cb_pool_circuit_bootstrap_host(tfhe_amd_cb_pool *pool, int32_t *out, const int32_t *x, int count) {
-    if (!pool || !out || !x || count < 0) return TFHE_AMD_ERR_PARAM;
+}  // extern "C"
+
+namespace {
+template <class RowsIn, class RowsOut>
+int cb_pool_rows_fn(tfhe_amd_cb_pool *pool, RowsOut rows_out, RowsIn rows_in, int count) {
+    if (!pool || count < 0) return TFHE_AMD_ERR_PARAM;
     std::lock_guard<std::mutex> lk(pool->call_mu);
     const int members = (int)pool->m.size();
     const size_t in_row = ((size_t)pool->p.N1 + 1) * 4, out_row = (size_t)2 * pool->p.l1 * 2 * pool->p.N1 * 4;
@@ -613,18 +620,45 @@ int tfhe_amd_cb_pool_circuit_bootstrap_host(tfhe_amd_cb_pool *pool, int32_t *out
         int lo, hi;
         slice_of(count, i, members, &lo, &hi);
         if (hi == lo) return (int)TFHE_AMD_OK;
-        const int rc = staged_rows(
-            mb.ctx, mb.st, [=](int first, int rows, const void *src) { memcpy((char *)out + (size_t)first * out_row, src, (size_t)rows * out_row); }, out_row,
-            [=](int first, int rows, void *dst) { memcpy(dst, (const char *)x + (size_t)first * in_row, (size_t)rows * in_row); }, in_row, 0, lo, hi,
-            [&](void *o, const void *in, int rows) {
-            return tfhe_amd_circuit_bootstrap(mb.cb, (int32_t *)o, (const int32_t *)in, rows);
-        });
+        const int chunk = pool->chunk_rows;
+        int rc;
+        if (chunk > 0 && hi - lo >= 2 * chunk)
+            rc = pipelined_rows(mb.ctx, mb.pipe, rows_out, out_row, rows_in, in_row, 0, lo, hi, chunk, [&](Staging &, void *o, const void *in, int rows) {
+                return tfhe_amd_circuit_bootstrap(mb.cb, (int32_t *)o, (const int32_t *)in, rows);
+            });
+        else
+            rc = staged_rows(mb.ctx, mb.st, rows_out, out_row, rows_in, in_row, 0, lo, hi, [&](void *o, const void *in, int rows) {
+                return tfhe_amd_circuit_bootstrap(mb.cb, (int32_t *)o, (const int32_t *)in, rows);
+            });
         if (rc) {  // the pipeline's message, or the level-2 context's when a copy failed
             const char *e = tfhe_amd_cb_last_error(mb.cb);
             mb.err = (e && *e) ? e : tfhe_amd_last_error(mb.ctx);
         }
         return rc;
     });
+}
+}  // namespace
+
+extern "C" {
+
+int tfhe_amd_cb_pool_circuit_bootstrap_host(tfhe_amd_cb_pool *pool, int32_t *out, const int32_t *x, int count) {
+    if (!pool || !out || !x) return TFHE_AMD_ERR_PARAM;
+    const size_t in_row = ((size_t)pool->p.N1 + 1) * 4, out_row = (size_t)2 * pool->p.l1 * 2 * pool->p.N1 * 4;
+    return cb_pool_rows_fn(
+        pool, [=](int first, int rows, const void *src) { memcpy((char *)out + (size_t)first * out_row, src, (size_t)rows * out_row); },
+        [=](int first, int rows, void *dst) { memcpy(dst, (const char *)x + (size_t)first * in_row, (size_t)rows * in_row); }, count);
+}
+int tfhe_amd_cb_pool_circuit_bootstrap_rows(tfhe_amd_cb_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int count) {
+    if (!pool || !put || !get) return TFHE_AMD_ERR_PARAM;
+    return cb_pool_rows_fn(
+        pool, [=](int first, int rows, const void *src) { put(user, first, rows, (const int32_t *)src); },
+        [=](int first, int rows, void *dst) { get(user, first, rows, (int32_t *)dst); }, count);
+}
+int tfhe_amd_cb_pool_set_option(tfhe_amd_cb_pool *pool, int option, int value) {
+    if (!pool || option != TFHE_AMD_POOL_OPT_CHUNK_ROWS || value < 0) return TFHE_AMD_ERR_PARAM;
+    std::lock_guard<std::mutex> lk(pool->call_mu);
+    pool->chunk_rows = value;
+    return TFHE_AMD_OK;
 }
 
 }  // extern "C"

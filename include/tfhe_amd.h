@@ -375,8 +375,12 @@ int tfhe_amd_cb_pool_load_preks(tfhe_amd_cb_pool *pool, const int32_t *preks);
 int tfhe_amd_cb_pool_load_bk_fft(tfhe_amd_cb_pool *pool, const double *bkfft);
 int tfhe_amd_cb_pool_load_bk_torus(tfhe_amd_cb_pool *pool, const int64_t *bk);
 int tfhe_amd_cb_pool_load_privks_plane(tfhe_amd_cb_pool *pool, int u_plane, const int32_t *plane);
-/* x [count][N1+1] LWE32 (host) -> out [count][2][l1][2][N1] int32 (host) */
+/* x [count][N1+1] LWE32 (host) -> out [count][2][l1][2][N1] int32 (host); _rows: through the caller's callbacks (rows in the
+ * flat layouts just named).  A member pipelines a slice of >= 2 x CHUNK_ROWS inputs (default 1024: one Torus64 ciphertext per wave
+ * on every SIMD) like the gate pool; tfhe_amd_cb_pool_set_option(pool, TFHE_AMD_POOL_OPT_CHUNK_ROWS, rows) changes it. */
 int tfhe_amd_cb_pool_circuit_bootstrap_host(tfhe_amd_cb_pool *pool, int32_t *out, const int32_t *x, int count);
+int tfhe_amd_cb_pool_circuit_bootstrap_rows(tfhe_amd_cb_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int count);
+int tfhe_amd_cb_pool_set_option(tfhe_amd_cb_pool *pool, int option, int value);
 
 /* ---- harness: synthetic keys and samples (the reference's keygen/encrypt/phase,
  *      poc:88-134,191-227,342-423; PRNG spec in DESIGN.md) -- host side ------------------ */

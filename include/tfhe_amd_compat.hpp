@@ -765,7 +765,7 @@ template <class GlobalsT>
 class PocEngine {
    public:
     explicit PocEngine(const GlobalsT *env, int device = 0)
-        : env_(env), cb_(nullptr), pool_(nullptr), h_in_(nullptr), h_out_(nullptr), da_in_(nullptr), da_out_(nullptr), arr_in_bytes_(0), arr_out_bytes_(0) {
+        : env_(env), cb_(nullptr), own_pool_(nullptr), pool_(nullptr) {
         tfhe_amd_cb_params p;
         p.n0 = env->n_lvl0;
         p.N1 = env->n_lvl1;
@@ -779,19 +779,11 @@ class PocEngine {
         p.t21 = env->kslength_lvl21;
         p.bb21 = env->ksbasebit_lvl21;
         p_ = p;
-        die(tfhe_amd_cb_create(&p, device, &cb_), "tfhe_amd_cb_create");
-        {
-            const std::vector<int32_t> f = flat_preks();
-            die(tfhe_amd_cb_load_preks(cb_, f.data()), "load preKS");
-        }
-        {
-            const std::vector<double> f = flat_bkfft();
-            die(tfhe_amd_cb_load_bk_fft(cb_, f.data()), "load bkFFT");
-        }
-        for (int u = 0; u < 2; u++) {
-            const std::vector<int32_t> f = flat_privks(u);
-            die(tfhe_amd_cb_load_privks_plane(cb_, u, f.data()), "load privKS");
-        }
+        // the engine's own handle is the one member of a pool of its own: the one-sample entry points use the member's handle
+        // directly (under the shims' lock), the array form goes through the pool and gets its pipelined member -- one copy of the
+        // 2.7 GB of keys serves both
+        own_pool_ = make_pool(std::vector<int>(1, device));
+        cb_ = tfhe_amd_cb_pool_member(own_pool_, 0);
         c2_ = tfhe_amd_cb_ctx_lvl2(cb_);
         c10_ = tfhe_amd_cb_ctx_lvl10(cb_);
         const size_t big = sizeof(int32_t) * (size_t)2 * p.l1 * 2 * p.N1 + sizeof(int64_t) * (size_t)(p.N2 + 1);
@@ -801,14 +793,10 @@ class PocEngine {
     ~PocEngine() {
         if (pool_) tfhe_amd_cb_pool_destroy(pool_);
         if (cb_) {
-            if (h_in_) tfhe_amd_host_free(c2_, h_in_);
-            if (h_out_) tfhe_amd_host_free(c2_, h_out_);
-            if (da_in_) tfhe_amd_free(c2_, da_in_);
-            if (da_out_) tfhe_amd_free(c2_, da_out_);
             tfhe_amd_free(c2_, d_a_);
             tfhe_amd_free(c2_, d_b_);
-            tfhe_amd_cb_destroy(cb_);
         }
+        if (own_pool_) tfhe_amd_cb_pool_destroy(own_pool_);  // destroys cb_, its member
     }
     // tfhe_CircuitBootstrapFFT(TGswSample32* result, const LweSample32* sample, env)   poc:823-873
     // Calls from several host threads are coalesced into one tfhe_CircuitBootstrapFFT_array launch (Coalescer above).
@@ -841,34 +829,25 @@ class PocEngine {
                     std::memcpy(result->samples[u][w].a[q].coefs, &f[(((size_t)u * p_.l1 + w) * 2 + q) * p_.N1],
                                 sizeof(int32_t) * (size_t)p_.N1);
     }
-    // The driver loop of poc:1009-1013 over `count` samples as ONE launch: gather into pinned staging, one copy in,
-    // tfhe_amd_circuit_bootstrap on the batch, one copy out, scatter into the caller's TGswSample32 objects.
+    // The driver loop of poc:1009-1013 over `count` samples as ONE call: the pool's member(s) gather the inputs from the caller's
+    // LweSample32 objects into pinned staging, run tfhe_amd_circuit_bootstrap on the batch (in pipelined chunks of 1024 when it is
+    // long) and scatter the results into the caller's TGswSample32 objects.  With several devices named (set_devices) the pool
+    // spans them; otherwise it is the engine's own one-member pool.
     template <class TGswSample32T, class LweSample32T>
     void tfhe_CircuitBootstrapFFT_array(TGswSample32T *const *results, const LweSample32T *const *samples, int count) {
         TFHE_AMD_SHIM_GUARD();
         if (count <= 0) return;
-        const size_t rin = (size_t)p_.N1 + 1, rout = (size_t)2 * p_.l1 * 2 * p_.N1;
-        if (use_pool()) {  // several devices (set_devices): contiguous slices of the loop over a tfhe_amd_cb_pool
+        tfhe_amd_cb_pool *pool = own_pool_;
+        if (use_pool()) {
             ensure_pool();
-            pool_in_.resize(rin * count);
-            pool_out_.resize(rout * count);
-            for (int c = 0; c < count; c++) std::memcpy(&pool_in_[(size_t)c * rin], samples[c]->a, sizeof(int32_t) * rin);
-            const int rc = tfhe_amd_cb_pool_circuit_bootstrap_host(pool_, pool_out_.data(), pool_in_.data(), count);
-            if (rc != TFHE_AMD_OK) {
-                std::fprintf(stderr, "tfhe_amd: circuit_bootstrap (array, pool) failed (%d): %s\n", rc, tfhe_amd_cb_pool_last_error(pool_));
-                std::abort();
-            }
-            scatter_tgsw(results, pool_out_.data(), count);
-            return;
+            pool = pool_;
         }
-        array_staging(c2_, h_in_, da_in_, arr_in_bytes_, sizeof(int32_t) * rin * count, h_out_, da_out_, arr_out_bytes_,
-                      sizeof(int32_t) * rout * count);
-        int32_t *hi = (int32_t *)h_in_;
-        for (int c = 0; c < count; c++) std::memcpy(hi + (size_t)c * rin, samples[c]->a, sizeof(int32_t) * rin);
-        check(tfhe_amd_memcpy_h2d(c2_, da_in_, h_in_, sizeof(int32_t) * rin * count), c2_, "h2d");
-        die(tfhe_amd_circuit_bootstrap(cb_, (int32_t *)da_out_, (const int32_t *)da_in_, count), "circuit_bootstrap (array)");
-        check(tfhe_amd_memcpy_d2h(c2_, h_out_, da_out_, sizeof(int32_t) * rout * count), c2_, "d2h");
-        scatter_tgsw(results, (const int32_t *)h_out_, count);
+        CbRows<TGswSample32T, LweSample32T> rows = {this, results, samples};
+        const int rc = tfhe_amd_cb_pool_circuit_bootstrap_rows(pool, &CbRows<TGswSample32T, LweSample32T>::put, &CbRows<TGswSample32T, LweSample32T>::get, &rows, count);
+        if (rc != TFHE_AMD_OK) {
+            std::fprintf(stderr, "tfhe_amd: circuit_bootstrap (array) failed (%d): %s\n", rc, tfhe_amd_cb_pool_last_error(pool));
+            std::abort();
+        }
     }
     // circuitBootstrapWoKS(LweSample64* result, Torus64 mu, const int* abar, env)   poc:530-659
     template <class LweSample64T>
@@ -984,45 +963,62 @@ class PocEngine {
                         std::memcpy(&f[o], env_->privKS[u][i][j][d].a[q].coefs, sizeof(int32_t) * (size_t)p.N1);
         return f;
     }
-    // the pool behind the array form: built for the current device list, rebuilt when that list changes
+    // rows of the array form between the caller's objects and a member's pinned staging buffer (called on the members' threads)
+    template <class TGswSample32T, class LweSample32T>
+    struct CbRows {
+        PocEngine *self;
+        TGswSample32T *const *results;
+        const LweSample32T *const *samples;
+        static void get(void *user, int first, int rows, int32_t *dst) {
+            const CbRows *r = static_cast<const CbRows *>(user);
+            const size_t rin = (size_t)r->self->p_.N1 + 1;
+            for (int c = 0; c < rows; c++) std::memcpy(dst + (size_t)c * rin, r->samples[first + c]->a, sizeof(int32_t) * rin);
+        }
+        static void put(void *user, int first, int rows, const int32_t *src) {
+            const CbRows *r = static_cast<const CbRows *>(user);
+            r->self->scatter_tgsw(r->results + first, src, rows);
+        }
+    };
+    // a pool over `devices` with this engine's keys (Globals::preKS, bkFFT, privKS flattened and uploaded once per member)
+    tfhe_amd_cb_pool *make_pool(const std::vector<int> &devices) {
+        tfhe_amd_cb_pool *pool = nullptr;
+        auto pdie = [&](int rc, const char *what) {
+            if (rc != TFHE_AMD_OK) {
+                std::fprintf(stderr, "tfhe_amd: %s failed (%d): %s\n", what, rc, pool ? tfhe_amd_cb_pool_last_error(pool) : "");
+                std::abort();
+            }
+        };
+        pdie(tfhe_amd_cb_pool_create(&p_, devices.data(), (int)devices.size(), &pool), "tfhe_amd_cb_pool_create");
+        {
+            const std::vector<int32_t> f = flat_preks();
+            pdie(tfhe_amd_cb_pool_load_preks(pool, f.data()), "load preKS");
+        }
+        {
+            const std::vector<double> f = flat_bkfft();
+            pdie(tfhe_amd_cb_pool_load_bk_fft(pool, f.data()), "load bkFFT");
+        }
+        for (int u = 0; u < 2; u++) {
+            const std::vector<int32_t> f = flat_privks(u);
+            pdie(tfhe_amd_cb_pool_load_privks_plane(pool, u, f.data()), "load privKS");
+        }
+        return pool;
+    }
+    // the multi-device pool behind the array form: built for the current device list, rebuilt when that list changes
     void ensure_pool() {
         if (pool_ && pool_devices_ == device_list()) return;
         if (pool_) tfhe_amd_cb_pool_destroy(pool_);
         pool_ = nullptr;
         pool_devices_ = device_list();
-        auto pdie = [&](int rc, const char *what) {
-            if (rc != TFHE_AMD_OK) {
-                std::fprintf(stderr, "tfhe_amd: %s failed (%d): %s\n", what, rc, pool_ ? tfhe_amd_cb_pool_last_error(pool_) : "");
-                std::abort();
-            }
-        };
-        pdie(tfhe_amd_cb_pool_create(&p_, pool_devices_.data(), (int)pool_devices_.size(), &pool_), "tfhe_amd_cb_pool_create");
-        {
-            const std::vector<int32_t> f = flat_preks();
-            pdie(tfhe_amd_cb_pool_load_preks(pool_, f.data()), "pool: load preKS");
-        }
-        {
-            const std::vector<double> f = flat_bkfft();
-            pdie(tfhe_amd_cb_pool_load_bk_fft(pool_, f.data()), "pool: load bkFFT");
-        }
-        for (int u = 0; u < 2; u++) {
-            const std::vector<int32_t> f = flat_privks(u);
-            pdie(tfhe_amd_cb_pool_load_privks_plane(pool_, u, f.data()), "pool: load privKS");
-        }
+        pool_ = make_pool(pool_devices_);
     }
-    PocEngine(const PocEngine &);
-    PocEngine &operator=(const PocEngine &);
     const GlobalsT *env_;
     Coalescer<std::pair<void *, const void *> > cb_calls_;
-    tfhe_amd_cb *cb_;
-    tfhe_amd_cb_pool *pool_;
+    tfhe_amd_cb *cb_;                  // = the one member of own_pool_
+    tfhe_amd_cb_pool *own_pool_, *pool_;  // this engine's device; the devices named by set_devices (array form only)
     std::vector<int> pool_devices_;
-    std::vector<int32_t> pool_in_, pool_out_;
     tfhe_amd_cb_params p_;
     tfhe_amd_ctx *c2_, *c10_;
     void *d_a_, *d_b_;
-    void *h_in_, *h_out_, *da_in_, *da_out_;  // array form: pinned host staging + device buffers
-    size_t arr_in_bytes_, arr_out_bytes_;
 };
 
 }  // namespace tfhe_amd_compat

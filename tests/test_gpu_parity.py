@@ -254,6 +254,9 @@ def test_circuit_bootstrap_pool_two_members_on_device_0(gpu_lib):
         for b in (0, 18, 19, 36):
             want = O.circuit_bootstrap(x[b], preks, bk, privks, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21)
             assert np.array_equal(got[b], want), b
+        pool.set_chunk_rows(4)  # the pipelined member: 19 = 4 + 4 + 4 + 4 + 3 on three streams, in both members at once
+        for rep in range(2):
+            assert np.array_equal(pool.circuit_bootstrap(x), got), rep
     finally:
         pool.close()
 

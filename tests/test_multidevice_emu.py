@@ -266,6 +266,8 @@ def test_circuit_bootstrap_pool(emu_lib):
         x = np.random.RandomState(9).randint(-2 ** 31, 2 ** 31, size=(3, N1 + 1)).astype(np.int32)
         want = np.stack([O.circuit_bootstrap(x[b], preks, bk, privks, n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21) for b in range(3)])
         assert np.array_equal(pool.circuit_bootstrap(x), want)
+        pool.set_chunk_rows(1)  # member 0's two inputs as two pipelined chunks (copy-in / compute / copy-out streams), member 1's one as one piece
+        assert np.array_equal(pool.circuit_bootstrap(x), want)
     finally:
         pool.close()
 
