@@ -504,6 +504,7 @@ int tfhe_amd_pool_set_option(tfhe_amd_pool *pool, int option, int value) {
 }
 int tfhe_amd_pool_last_split(const tfhe_amd_pool *pool, int *counts, double *seconds) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
+    std::lock_guard<std::mutex> lk(const_cast<tfhe_amd_pool *>(pool)->call_mu);  // (the members write these during a call)
     for (size_t i = 0; i < pool->m.size(); i++) {
         if (counts) counts[i] = pool->m[i].last_count;
         if (seconds) seconds[i] = pool->m[i].last_seconds;

@@ -1,0 +1,58 @@
+// coalescer_test.cpp -- tfhe_amd_compat::Coalescer (include/tfhe_amd_compat.hpp) on its own, no engine behind it: many host
+// threads call at once; every request must be carried by exactly one batch, batches must never overlap, a call must return only
+// after its own request ran, and the lead must be handed over (no caller leads more than one batch per call).
+// Built twice by tests/test_coalescer.py: plain, and with -fsanitize=thread (the class is all mutex / condition-variable code).
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+#include <vector>
+
+#include "tfhe_amd_compat.hpp"
+
+struct Item {
+    int id;
+    int *slot;  // where the "result" of this request goes
+};
+
+int main(int argc, char **argv) {
+    const int threads = argc > 1 ? atoi(argv[1]) : 32, calls = argc > 2 ? atoi(argv[2]) : 300;
+    tfhe_amd_compat::Coalescer<Item> co;
+    std::atomic<int> running(0), overlaps(0), batches(0), carried(0), max_batch(0);
+    std::vector<int> results((size_t)threads * calls, -1);
+    std::vector<int> led((size_t)threads, 0);
+    auto worker = [&](int t) {
+        for (int c = 0; c < calls; c++) {
+            const int id = t * calls + c;
+            int batches_led = 0;
+            co.call(Item{id, &results[(size_t)id]}, [&](const std::vector<Item> &items) {
+                if (running.fetch_add(1) != 0) overlaps++;
+                batches++;
+                batches_led++;
+                int m = max_batch.load();
+                while ((int)items.size() > m && !max_batch.compare_exchange_weak(m, (int)items.size())) {
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(20 + (id % 7) * 10));  // the "launch"
+                for (const Item &it : items) {
+                    *it.slot = it.id * 3 + 1;
+                    carried++;
+                }
+                running.fetch_sub(1);
+            });
+            if (results[(size_t)id] != id * 3 + 1) {
+                fprintf(stderr, "call %d returned before its request ran\n", id);
+                return;
+            }
+            if (batches_led > 1) led[(size_t)t]++;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) pool.emplace_back(worker, t);
+    for (auto &th : pool) th.join();
+    int bad = 0, multi = 0;
+    for (size_t i = 0; i < results.size(); i++) bad += results[i] != (int)i * 3 + 1;
+    for (int v : led) multi += v;
+    printf("{\"threads\": %d, \"calls\": %d, \"batches\": %d, \"carried\": %d, \"max_batch\": %d, \"overlaps\": %d, \"wrong\": %d, \"led_more_than_one\": %d}\n",
+           threads, threads * calls, batches.load(), carried.load(), max_batch.load(), overlaps.load(), bad, multi);
+    return (bad || overlaps.load() || multi || carried.load() != threads * calls) ? 1 : 0;
+}

@@ -1,0 +1,46 @@
+"""Host-side concurrency code on its own, plain and under ThreadSanitizer (the kernel emulator's fibers cannot run under it).
+
+tfhe_amd_compat::Coalescer (the shims' coalescing of one-sample calls from several host threads) on its own: a plain build
+and a ThreadSanitizer build of tests/compat/coalescer_test.cpp -- every request carried exactly once, batches never overlap, no
+call returns before its request ran, the lead is handed over, and no data race."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tsan", [False, True])
+def test_coalescer(tmp_path, tsan):
+    exe = str(tmp_path / ("coalescer_tsan" if tsan else "coalescer"))
+    cmd = ["g++", "-std=c++11", "-O1", "-g", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "compat", "coalescer_test.cpp"), "-o", exe]
+    if tsan:
+        cmd[3:3] = ["-fsanitize=thread"]
+    subprocess.check_call(cmd)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}  # (a sanitizer run of the suite preloads libasan: not into this one)
+    out = subprocess.run([exe, "24" if tsan else "48", "150" if tsan else "400"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr[-3000:]
+    assert "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["carried"] == d["calls"] and d["wrong"] == 0 and d["overlaps"] == 0 and d["led_more_than_one"] == 0
+    assert d["batches"] < d["calls"] and d["max_batch"] > 1  # calls did share batches
+
+
+@pytest.mark.parametrize("tsan", [False, True])
+def test_pool_threading_on_a_mock_engine(tmp_path, tsan):
+    """experimental-tfhe_amd/csrc/pool.cpp linked against a host-memory stand-in for the C ABI it is written on
+    (tests/compat/pool_mock_engine.cpp; it aborts when two threads are inside one context at once): six host threads on one pool
+    of four members -- sharded, pipelined and callback calls of ragged sizes, option changes and key reloads in between"""
+    exe = str(tmp_path / ("pool_tsan" if tsan else "pool_plain"))
+    srcs = [os.path.join(ROOT, "experimental-tfhe_amd", "csrc", "pool.cpp"), os.path.join(ROOT, "tests", "compat", "pool_mock_engine.cpp"),
+            os.path.join(ROOT, "tests", "compat", "pool_tsan_test.cpp")]
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-pthread", "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", exe]
+    if tsan:
+        cmd[3:3] = ["-fsanitize=thread"]
+    subprocess.check_call(cmd)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "pool_tsan_test: ok" in out.stdout, out.stdout + out.stderr[-3000:]
+    assert "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
