@@ -48,7 +48,27 @@
 #define TFHE_TWD_SPLIT 4
 #endif
 
+// Workgroup barrier every K CMux steps of the blind rotation, by workgroup width (0 = none).  The 8 (or 4) waves of a workgroup
+// stream the SAME key row per step (64 KB at N = 1024, l = 2) from L2, each for itself -- 9 TB/s of L2 -> L1 traffic per launch, and
+// the chip, power-limited under this fp64 load, pays for it in clock.  Re-aligned by a barrier the waves run close enough for the
+// CU's 32 KB L1 to serve the followers; they drift apart again within a few steps, and a barrier costs the wait for the slowest
+// wave.  Round 5, MI355X, batch 4096 (profiles/r05_br_sync.txt): K = 16 -> L2 requests -32 %, cycles per CMux +2.0 %, shader clock
+// 2.22 -> 2.28 GHz, kernel time -1.1 % on a box that holds 2.2 GHz and -2.2 % on one that holds 2.05; K = 1 / 2: slower (the
+// barrier waits outweigh a -67 % in L2 requests); K = 4 .. 32: the same within noise.  Bit-identical (the barrier orders nothing
+// the results depend on).
+#ifndef TFHE_BR_SYNC8
+#define TFHE_BR_SYNC8 16
+#endif
+#ifndef TFHE_BR_SYNC4
+#define TFHE_BR_SYNC4 0
+#endif
+
 namespace tfhe {
+
+template <int WAVES>
+struct BR_SYNC_EVERY {
+    static constexpr int value = (WAVES == 8) ? TFHE_BR_SYNC8 : (WAVES == 4 ? TFHE_BR_SYNC4 : 0);
+};
 
 // ------------------------------------------------------------------ geometry
 template <int LOGN>
@@ -1143,6 +1163,11 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
     int a_next = ((A.flags & BR_NO_ROTATE) || A.n_steps <= 0) ? 0 : tfhe_uniform_load32(rot, 0);
 #pragma unroll 1
     for (int i = 0; i < A.n_steps; i++) {
+        // every wave of a workgroup reads the same bootstrapping-key row in the same order: re-aligned every few steps, the waves
+        // behind find the row's lines in the CU's L1 (see TFHE_BR_SYNC8 at the top of this file)
+        if constexpr (WAVES > 1 && BR_SYNC_EVERY<WAVES>::value > 0) {
+            if ((i % BR_SYNC_EVERY<WAVES>::value) == 0) __syncthreads();
+        }
         const double2 *bkrow = bk0 + (size_t)i * A.bk_step_stride;
         int a = 0;
         const bool rotate = !(A.flags & BR_NO_ROTATE);

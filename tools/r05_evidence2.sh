@@ -1,0 +1,12 @@
+set -u
+O=gpurun_out
+timeout 900 python -m pytest tests -m gpu -q > $O/r05_pytest_gpu.log 2>&1; echo "rc=$?" >> $O/r05_pytest_gpu.log
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r05_bench_final.json 2> $O/r05_bench_final.err; echo "rc=$?" >> $O/r05_bench_final.err
+cp $O/bench_detail_1gpu.json $O/r05_bench_final_detail.json
+bash tools/prof_trace.sh r05 > $O/r05_prof_trace.txt 2>&1
+bash tools/prof_pmc.sh r05 fetch FETCH_SIZE > $O/r05_pmc_fetch.txt 2>&1
+bash tools/prof_pmc.sh r05 write WRITE_SIZE > $O/r05_pmc_write.txt 2>&1
+bash tools/prof_pmc.sh r05 sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS > $O/r05_pmc_sq1.txt 2>&1
+bash tools/prof_pmc.sh r05 sq2 GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE > $O/r05_pmc_sq2.txt 2>&1
+bash tools/prof_pmc.sh r05 sq3 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL > $O/r05_pmc_sq3.txt 2>&1
+bash tools/prof_pmc.sh r05 tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum > $O/r05_pmc_tcc.txt 2>&1
