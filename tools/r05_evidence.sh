@@ -1,3 +1,5 @@
+# The GPU-box command list behind profiles/r05_* (run as ONE gpurun call: gpurun --timeout 3000 -- bash tools/r05_evidence.sh);
+# afterwards, here: python tools/make_traffic.py gpurun_out/prof_r05 and copy the summaries named in profiles/README.md.
 set -u
 O=gpurun_out
 timeout 900 python -m pytest tests -m gpu -q > $O/r05_pytest_gpu.log 2>&1; echo "rc=$?" >> $O/r05_pytest_gpu.log
