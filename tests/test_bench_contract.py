@@ -181,6 +181,22 @@ def test_bench_post_region_sections_on_emulator(emu_lib):
     assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # never inside `value`
 
 
+def test_pool_over_every_visible_device_on_emulator(emu_lib):
+    """`bench.py --pool-devices all`: ONE process driving every device the engine library shows (here the emulator's 8) through
+    tfhe_amd_pool_* -- keys uploaded from host arrays to all eight, the batch cut into eight slices, outputs identical to the
+    headline's; what a maintainer runs on an 8-GPU node beside `--gpus 8`"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", emu_lib, "--batch", "5", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--lwe-n", "6", "--headline-only", "--pool-devices", "all"], capture_output=True, text=True,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    rows = d["pool_check"]["[devices, samples per call, bootstraps/s]"]
+    assert rows[-1][0] == list(range(8)) and rows[-1][1] == 20 and rows[-1][2] > 0 and d["pool_check"]["identical_to_headline"] is True
+    f = json.load(open(os.path.join(ROOT, d["detail"])))
+    last = f["pool_check"]["pools"][-1]
+    assert last["split"] == [3, 3, 3, 3, 2, 2, 2, 2] and len(set(last["pci"])) == 8
+
+
 def test_two_ranks_on_one_device_are_reported_as_such(emu_lib):
     """two gloo ranks that share ONE (emulated) device: the line says n_gpus 2 (ranks) but n_devices 1 and shows the same PCI
     bus id twice -- under RCCL the same situation exits non-zero (bench.py refuses to call two ranks on one chip two GPUs)"""
