@@ -45,6 +45,18 @@ uint64_t env_fingerprint(const Globals *env) {
                 std::memcpy(&bits, &env->bkFFT[is[a]].allsamples[r].a[1].values[pos[b]], 8);
                 h = tfhe_amd_compat::fp_mix(h, bits);
             }
+    // ... and, as key_fingerprint, one value of EVERY TGSW sample of the bootstrapping key and one word of every input
+    // coefficient's block of the pre-key-switch key (the 2.69 GB private key-switch table: one row per 64 coefficients)
+    for (int i = 0; i < n0; i++) {
+        uint64_t bits;
+        std::memcpy(&bits, &env->bkFFT[i].allsamples[i % rows2].a[(i / rows2) & 1].values[(int)(((long long)i * 37 + 5) % N2)], 8);
+        h = tfhe_amd_compat::fp_mix(h, bits);
+    }
+    for (int i = 0; i < env->n_lvl1; i++)
+        h = tfhe_amd_compat::fp_mix(h, (uint32_t)env->preKS[i][i % env->kslength_lvl10][1].a[(int)(((long long)i * 29 + 3) % (n0 + 1))]);
+    for (int u = 0; u < 2; u++)
+        for (int i = 0; i <= N2; i += 64)
+            h = tfhe_amd_compat::fp_mix(h, (uint32_t)env->privKS[u][i][(i / 64) % env->kslength_lvl21][1].a[(i / 64) & 1].coefs[i % env->n_lvl1]);
     h = tfhe_amd_compat::fp_mix(h, (uint32_t)env->preKS[0][0][1].a[0]);
     h = tfhe_amd_compat::fp_mix(h, (uint32_t)env->preKS[env->n_lvl1 - 1][env->kslength_lvl10 - 1][1].a[n0]);
     for (int u = 0; u < 2; u++) {

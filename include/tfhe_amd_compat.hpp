@@ -213,10 +213,15 @@ inline void staging(Resident &R, size_t bytes) {
 
 // Resident copies are found by the ADDRESS of the caller's key object.  The CONTRACT is release(): call it whenever a key
 // object's contents change or its memory is reused.  As a guard against the commonest mistake -- a key freed and rebuilt at
-// the same address without a release() in between -- every lookup re-reads a SAMPLE of the host key (the bit patterns of a few
-// values of its first, middle and last polynomials and key-switch rows: ~50 loads) and compares it with the sample taken at
-// upload time; a difference drops the resident copy and uploads the key again.  The detection is probabilistic: a change
-// elsewhere than at the sampled positions is NOT seen and the stale GPU copy is served ("Caveat").
+// the same address without a release() in between, or one TGSW sample / key-switch row re-encrypted in place -- every lookup
+// re-reads a SAMPLE of the host key and compares it with the sample taken at upload time; a difference drops the resident copy
+// and uploads the key again.  The sample touches EVERY TGSW sample of the bootstrapping key (one value each: TLWE row, polynomial
+// and position walk with the sample index, so all 2l rows, both polynomials and ~n positions are covered across the key; four
+// values of the first, middle and last samples besides) and EVERY input coefficient's block of the key-switch key (one mask
+// word and the body of one of its t x (base-1) rows): ~n + N loads, 14 us at the gate shape once they sit in the host's caches
+// (0.6 % of a one-sample call).
+// The detection stays probabilistic: a change elsewhere than at the sampled positions is NOT seen and the stale GPU copy is
+// served ("Caveat").
 inline uint64_t fp_mix(uint64_t h, uint64_t v) {
     h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
     return h;
@@ -224,15 +229,17 @@ inline uint64_t fp_mix(uint64_t h, uint64_t v) {
 template <class GswT>
 inline uint64_t key_fingerprint(const GswT *bkFFT, int n, int N, int l, const LweKeySwitchKey *ks) {
     uint64_t h = 0x5446484500000001ull;
+    auto value_bits = [&](int i, int r, int q, int pos) {
+        uint64_t bits;
+        std::memcpy(&bits, &bkFFT[i].all_samples[r].a[q].values[pos], 8);
+        return bits;
+    };
     const int rows[3] = {0, n / 2, n - 1}, pos[4] = {0, 1, N / 2, N - 1};
     for (int a = 0; a < 3 && bkFFT && n > 0; a++)
         for (int r = 0; r < 2 * l; r += (2 * l - 1 > 0 ? 2 * l - 1 : 1))
             for (int q = 0; q < 2; q++)
-                for (int b = 0; b < 4; b++) {
-                    uint64_t bits;
-                    std::memcpy(&bits, &bkFFT[rows[a]].all_samples[r].a[q].values[pos[b]], 8);
-                    h = fp_mix(h, bits);
-                }
+                for (int b = 0; b < 4; b++) h = fp_mix(h, value_bits(rows[a], r, q, pos[b]));
+    for (int i = 0; bkFFT && i < n; i++) h = fp_mix(h, value_bits(i, i % (2 * l), (i / (2 * l)) & 1, (int)(((long long)i * 37 + 5) % N)));
     if (ks) {
         const int is[3] = {0, ks->n / 2, ks->n - 1};
         for (int a = 0; a < 3; a++)
@@ -242,6 +249,11 @@ inline uint64_t key_fingerprint(const GswT *bkFFT, int n, int N, int l, const Lw
                 h = fp_mix(h, (uint32_t)row.a[ks->out_params->n - 1]);
                 h = fp_mix(h, (uint32_t)row.b);
             }
+        const int nout = ks->out_params->n;
+        for (int i = 0; i < ks->n; i++) {
+            const LweSample &row = ks->ks[i][i % ks->t][ks->base > 1 ? 1 + i % (ks->base - 1) : 0];
+            h = fp_mix(h, ((uint64_t)(uint32_t)row.a[(int)(((long long)i * 29 + 3) % nout)] << 32) | (uint32_t)row.b);
+        }
     }
     return h;
 }

@@ -190,6 +190,21 @@ static int run_lib(const char *inp, const char *outp) {
         out.put(r.a, 4 * (size_t)n);
         out.put(&r.b, 4);
     }
+    // ONE interior TGSW sample replaced in place (sample 1 now points at sample 2's polynomials), again without a release: the
+    // content sample touches every TGSW sample of the key, so this too must be served from a fresh upload -- and the original
+    // put back the same way for what follows
+    if (n >= 5) {
+        for (int pass = 0; pass < 2; pass++) {
+            for (int r = 0; r < kpl; r++)
+                for (int q = 0; q < 2; q++)
+                    polys[((size_t)1 * kpl + r) * 2 + q].values = (double *)bkflat + (((size_t)(pass == 0 ? 2 : 1) * kpl + r) * 2 + q) * N;
+            LweSample x{(Torus32 *)xs, xs[n], 0};
+            LweSample r{rb.data(), 0, 0};
+            tfhe_bootstrap_FFT(&r, &bk, mu, &x);
+            out.put(r.a, 4 * (size_t)n);
+            out.put(&r.b, 4);
+        }
+    }
 #ifdef DROPIN
     tfhe_amd_dropin_release(nullptr);
     out.save(outp);

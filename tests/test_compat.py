@@ -79,6 +79,11 @@ def run_lib_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=
     assert np.array_equal(take(np.int32, n + 1), O.bootstrap32(N, bkr, ks, mu, x[0], l, Bgbit, t, bb)), "release(bk) + rebuilt key"
     # the original key put back in place WITHOUT a release: noticed through the content sample
     assert np.array_equal(take(np.int32, n + 1), O.bootstrap32(N, bk, ks, mu, x[0], l, Bgbit, t, bb)), "key rebuilt in place, no release"
+    if n >= 5:  # one interior TGSW sample replaced in place (1 := 2), no release; then the original put back the same way
+        bk1 = bk.copy()
+        bk1[1] = bk[2]
+        assert np.array_equal(take(np.int32, n + 1), O.bootstrap32(N, bk1, ks, mu, x[0], l, Bgbit, t, bb)), "one TGSW sample replaced in place"
+        assert np.array_equal(take(np.int32, n + 1), O.bootstrap32(N, bk, ks, mu, x[0], l, Bgbit, t, bb)), "... and put back"
     if not plugin:  # the literal drop-in driver (tests/test_dropin.py) has no FFT-plugin section
         assert pos == len(raw)
         return
