@@ -38,9 +38,11 @@
 #ifndef TFHE_AMD_COMPAT_HPP
 #define TFHE_AMD_COMPAT_HPP
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -118,6 +120,13 @@ inline std::recursive_mutex &shim_mutex() {
 // takes everything pending (its own request included), runs it as one batch, marks those requests done and -- if more have
 // arrived meanwhile -- hands the lead to one of the waiting callers before it returns (no caller serves more than one batch: a
 // call waits for at most the batch in flight plus its own).  A lone caller is a batch of one at the one-sample path's latency.
+//
+// LINGER.  A tight loop of T threads would otherwise settle into two alternating groups of T/2: the callers of the batch in
+// flight come back microseconds AFTER the next leader has taken what was pending.  The coalescer keeps an estimate of the
+// callers around (the last batch + what was pending when it finished); a leader that holds fewer requests than that waits for
+// the stragglers -- at most a tenth of the last launch's duration, 300 us at most -- and goes as soon as they are all there.
+// A lone caller never waits (estimate 1).  When the wait runs out without the crowd arriving (callers with work of their own
+// between calls) the next waits are halved, down to 1/16 of that bound, and the full wait is tried again every 16th batch.
 template <class Item>
 class Coalescer {
    public:
@@ -129,19 +138,39 @@ class Coalescer {
         std::unique_lock<std::mutex> lk(mu_);
         pending_.push_back(&me);
         if (busy_) {
+            if (lingering_ && pending_.size() >= crowd_) gather_cv_.notify_one();  // the leader waits for exactly this
             cv_.wait(lk, [&] { return me.done || me.lead; });
             if (me.done) return;  // another caller's batch carried this request
         }
         busy_ = true;  // (already true when the lead was handed over)
+        if (pending_.size() < crowd_ && linger_bound_.count() > 0) {
+            const int shift = (batches_ % 16 == 15) ? 0 : shift_;
+            lingering_ = true;
+#if defined(__SANITIZE_THREAD__)
+            // (gcc 11's ThreadSanitizer runtime does not intercept pthread_cond_clockwait, what a wait on the steady clock
+            // becomes, and then reports the mutex as held throughout the wait: its build waits on the system clock)
+            const bool all_here = gather_cv_.wait_until(lk, std::chrono::system_clock::now() + linger_bound_ / (1 << shift),
+                                                        [&] { return pending_.size() >= crowd_; });
+#else
+            const bool all_here = gather_cv_.wait_for(lk, linger_bound_ / (1 << shift), [&] { return pending_.size() >= crowd_; });
+#endif
+            lingering_ = false;
+            shift_ = all_here ? 0 : (shift_ < 4 ? shift_ + 1 : 4);
+        }
         std::vector<Req *> batch;
         batch.swap(pending_);
         lk.unlock();
         std::vector<Item> items;
         items.reserve(batch.size());
         for (Req *r : batch) items.push_back(r->item);
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         run(items);
+        const std::chrono::nanoseconds took = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0);
         lk.lock();
         for (Req *r : batch) r->done = true;  // (a waiter's Req lives on its stack until it wakes under this lock)
+        crowd_ = batch.size() + pending_.size();
+        linger_bound_ = std::min(took / 10, std::chrono::nanoseconds(300000));
+        batches_++;
         if (!pending_.empty())
             pending_.front()->lead = true;
         else
@@ -156,9 +185,13 @@ class Coalescer {
         bool done = false, lead = false;
     };
     std::mutex mu_;
-    std::condition_variable cv_;
+    std::condition_variable cv_, gather_cv_;
     std::vector<Req *> pending_;
-    bool busy_ = false;
+    bool busy_ = false, lingering_ = false;
+    size_t crowd_ = 1;                        // callers around: size of the last batch + what was pending when it finished
+    std::chrono::nanoseconds linger_bound_{0};  // a tenth of the last launch, 300 us at most
+    int shift_ = 0;                           // the bound is halved `shift_` times after waits that ran out
+    unsigned batches_ = 0;
 };
 struct LweCall {
     LweSample *result;

@@ -17,6 +17,10 @@ struct Item {
 
 int main(int argc, char **argv) {
     const int threads = argc > 1 ? atoi(argv[1]) : 32, calls = argc > 2 ? atoi(argv[2]) : 300;
+    // rate mode (argv[3] > 0): a fixed "launch" of argv[3] microseconds and argv[4] microseconds of caller work between calls --
+    // what share of the callers one launch carries (a tight loop of T threads should fill batches of T, not alternate in halves)
+    const int launch_us = argc > 3 ? atoi(argv[3]) : 0, think_us = argc > 4 ? atoi(argv[4]) : 0;
+    const auto wall0 = std::chrono::steady_clock::now();
     tfhe_amd_compat::Coalescer<Item> co;
     std::atomic<int> running(0), overlaps(0), batches(0), carried(0), max_batch(0);
     std::vector<int> results((size_t)threads * calls, -1);
@@ -32,7 +36,7 @@ int main(int argc, char **argv) {
                 int m = max_batch.load();
                 while ((int)items.size() > m && !max_batch.compare_exchange_weak(m, (int)items.size())) {
                 }
-                std::this_thread::sleep_for(std::chrono::microseconds(20 + (id % 7) * 10));  // the "launch"
+                std::this_thread::sleep_for(std::chrono::microseconds(launch_us > 0 ? launch_us : 20 + (id % 7) * 10));  // the "launch"
                 for (const Item &it : items) {
                     *it.slot = it.id * 3 + 1;
                     carried++;
@@ -44,6 +48,11 @@ int main(int argc, char **argv) {
                 return;
             }
             if (batches_led > 1) led[(size_t)t]++;
+            if (think_us > 0) {  // the caller's own work between two calls (busy: a sleeping thread would not model it)
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(think_us);
+                while (std::chrono::steady_clock::now() < until) {
+                }
+            }
         }
     };
     std::vector<std::thread> pool;
@@ -52,6 +61,10 @@ int main(int argc, char **argv) {
     int bad = 0, multi = 0;
     for (size_t i = 0; i < results.size(); i++) bad += results[i] != (int)i * 3 + 1;
     for (int v : led) multi += v;
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+    if (launch_us > 0)
+        printf("{\"launch_us\": %d, \"think_us\": %d, \"calls_per_s\": %.0f, \"mean_batch\": %.1f, \"ideal_calls_per_s\": %.0f}\n", launch_us, think_us,
+               threads * calls / wall, (double)(threads * calls) / batches.load(), threads / ((launch_us + think_us) * 1e-6));
     printf("{\"threads\": %d, \"calls\": %d, \"batches\": %d, \"carried\": %d, \"max_batch\": %d, \"overlaps\": %d, \"wrong\": %d, \"led_more_than_one\": %d}\n",
            threads, threads * calls, batches.load(), carried.load(), max_batch.load(), overlaps.load(), bad, multi);
     return (bad || overlaps.load() || multi || carried.load() != threads * calls) ? 1 : 0;

@@ -26,6 +26,17 @@ def test_coalescer(tmp_path, tsan):
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["carried"] == d["calls"] and d["wrong"] == 0 and d["overlaps"] == 0 and d["led_more_than_one"] == 0
     assert d["batches"] < d["calls"] and d["max_batch"] > 1  # calls did share batches
+    if not tsan:
+        # a tight loop of 8 threads on a 2 ms "launch": the leader waits for the callers of the batch that just finished, so a
+        # launch carries (nearly) all 8 -- without that wait the loop settles into two alternating groups (mean batch 5.3 measured)
+        out = subprocess.run([exe, "8", "60", "2000", "0"], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr[-3000:]
+        r = json.loads(out.stdout.strip().splitlines()[0])
+        assert r["mean_batch"] >= 6.5, r
+        # a lone caller never waits: one call per launch, at the launch's own rate
+        out = subprocess.run([exe, "1", "100", "2000", "0"], capture_output=True, text=True, timeout=600, env=env)
+        r = json.loads(out.stdout.strip().splitlines()[0])
+        assert r["mean_batch"] == 1.0 and r["calls_per_s"] > 0.9 * r["ideal_calls_per_s"], r
 
 
 @pytest.mark.parametrize("tsan", [False, True])
