@@ -139,8 +139,14 @@ class Coalescer {
         pending_.push_back(&me);
         if (busy_) {
             if (lingering_ && pending_.size() >= crowd_) gather_cv_.notify_one();  // the leader waits for exactly this
-            cv_.wait(lk, [&] { return me.done || me.lead; });
+            lk.unlock();
+            // every request sleeps on its OWN mutex and condition variable: the callers of a finished batch wake side by side
+            // instead of queueing, one after the other, for the one lock a shared condition variable would hand them
+            std::unique_lock<std::mutex> mine(me.m);
+            me.cv.wait(mine, [&] { return me.done || me.lead; });
             if (me.done) return;  // another caller's batch carried this request
+            mine.unlock();
+            lk.lock();
         }
         busy_ = true;  // (already true when the lead was handed over)
         if (pending_.size() < crowd_ && linger_bound_.count() > 0) {
@@ -167,25 +173,33 @@ class Coalescer {
         run(items);
         const std::chrono::nanoseconds took = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0);
         lk.lock();
-        for (Req *r : batch) r->done = true;  // (a waiter's Req lives on its stack until it wakes under this lock)
         crowd_ = batch.size() + pending_.size();
         linger_bound_ = std::min(took / 10, std::chrono::nanoseconds(300000));
         batches_++;
-        if (!pending_.empty())
-            pending_.front()->lead = true;
-        else
-            busy_ = false;
+        Req *next = pending_.empty() ? nullptr : pending_.front();  // (stays in pending_: its own request rides in its batch)
+        if (!next) busy_ = false;
         lk.unlock();
-        cv_.notify_all();
+        // the lead goes out first -- the next leader gathers while this one is still waking its batch; a flag is set and its
+        // owner notified under the REQUEST's mutex (the Req lives on its owner's stack until the owner has seen the flag)
+        if (next) wake(next, &Req::lead);
+        for (Req *r : batch)
+            if (r != &me) wake(r, &Req::done);
     }
 
    private:
     struct Req {
         Item item;
         bool done = false, lead = false;
+        std::mutex m;
+        std::condition_variable cv;
     };
+    static void wake(Req *r, bool Req::*flag) {
+        std::lock_guard<std::mutex> g(r->m);
+        r->*flag = true;
+        r->cv.notify_one();
+    }
     std::mutex mu_;
-    std::condition_variable cv_, gather_cv_;
+    std::condition_variable gather_cv_;
     std::vector<Req *> pending_;
     bool busy_ = false, lingering_ = false;
     size_t crowd_ = 1;                        // callers around: size of the last batch + what was pending when it finished
