@@ -691,7 +691,7 @@ inline void lwe_rows_out(void *user, int first, int rows, const int32_t *src) {
     scatter_lwe(r->results + first, src, rows, r->n_out);
 }
 template <class Call>
-inline void lwe_array_pool_call(PoolResident &R, LweSample *const *results, int n_out, const LweSample *const *xs, int n_in, int count,
+inline void lwe_array_pool_call(PoolResident &R, LweSample *const *results, int n_out, const LweSample *const *xs, int n_in, int /*count*/,
                                 Call call, const char *what) {
     LweRows rows{results, xs, n_in, n_out};
     pool_check(call(&rows), R.pool, what);

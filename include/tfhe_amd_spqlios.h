@@ -12,7 +12,7 @@
  *              fft_model, ifft_model                          CB/spqlios/spqlios-fft.h:46-53
  *
  * so the reference's UNMODIFIED objects (poc_CircuitBootstrapping.o and its callers at poc:248-283) link against it:
- * replace `spqlios/*.o` on the link line by `-ltfhe_amd_spqlios`.  A caller that includes
+ * replace the `spqlios/` objects on the link line by `-ltfhe_amd_spqlios`.  A caller that includes
  * the reference's own lagrangehalfc_impl.h / spqlios-fft.h needs nothing from this file; it exists so that code
  * without the reference tree can compile against the same declarations.
  *

@@ -27,6 +27,20 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(tfhe_amd_[a-z0-9_]+)\s*\(", text)))
 
 
+def test_headers_compile_under_the_reference_flags(tmp_path):
+    """the reference builds with `-Wall -Werror` (circuit-bootstrapping/src/Makefile): every public header must survive that
+    (and -Wextra) in a translation unit of its own; tfhe_amd.h, the C ABI, also as C99"""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    for h in sorted(f for f in os.listdir(inc) if f.endswith((".h", ".hpp"))):
+        tu = tmp_path / (h + ".cpp")
+        tu.write_text('#include "%s"\n' % h)
+        subprocess.check_call(["g++", "-std=gnu++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + inc, str(tu)])
+    tu = tmp_path / "abi.c"
+    tu.write_text('#include "tfhe_amd.h"\nint main(void) { return tfhe_amd_version() == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + inc, str(tu)])
+
+
 def test_exports_every_declared_symbol(hip_lib):
     syms = header_symbols()
     assert len(syms) >= 35
