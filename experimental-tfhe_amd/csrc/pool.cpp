@@ -289,6 +289,9 @@ struct tfhe_amd_pool {
     std::mutex call_mu;  // one sharded call at a time
     std::string err;
     int chunk_rows = DEFAULT_CHUNK_ROWS;
+    // a key load that failed on SOME members leaves the members with different keys: the operations refuse to run (their
+    // outputs would depend on the slice a sample fell into) until a load of that key has succeeded on every member
+    bool bk_mixed = false, ks_mixed = false;
 };
 
 namespace {
@@ -318,6 +321,10 @@ template <class RowsIn, class RowsOut, class Launch>
 int pool_rows_fn(tfhe_amd_pool *pool, RowsOut rows_out, size_t out_ints, RowsIn rows_in, size_t in_ints, size_t mid_ints, int count, Launch launch) {
     if (!pool || count < 0) return TFHE_AMD_ERR_PARAM;
     std::lock_guard<std::mutex> lk(pool->call_mu);
+    if (pool->bk_mixed || pool->ks_mixed) {
+        pool->err = "the last key load failed on some members: the members hold different keys, load the keys again";
+        return TFHE_AMD_ERR_STATE;
+    }
     const int members = (int)pool->m.size();
     return on_every_member(pool, [=](int i) {
         tfhe_amd_pool::Member &mb = pool->m[i];
@@ -423,7 +430,7 @@ tfhe_amd_ctx *tfhe_amd_pool_ctx(tfhe_amd_pool *pool, int member) {
 static int pool_load(tfhe_amd_pool *pool, const void *bk, bool bk_is_fft, const int32_t *ks) {
     if (!pool || (!bk && !ks)) return TFHE_AMD_ERR_PARAM;
     std::lock_guard<std::mutex> lk(pool->call_mu);
-    return on_every_member(pool, [=](int i) {
+    const int status = on_every_member(pool, [=](int i) {
         tfhe_amd_pool::Member &mb = pool->m[i];
         if (bk) {
             tfhe_amd_gsw *g = nullptr;
@@ -441,6 +448,10 @@ static int pool_load(tfhe_amd_pool *pool, const void *bk, bool bk_is_fft, const 
             if (int rc = tfhe_amd_load_keyswitch_key(mb.ctx, ks)) return member_status(mb, rc);
         return (int)TFHE_AMD_OK;
     });
+    const bool several = pool->m.size() > 1;  // (one member: a failed load leaves its previous key, as on a bare context)
+    if (bk) pool->bk_mixed = status != TFHE_AMD_OK && several;
+    if (ks) pool->ks_mixed = status != TFHE_AMD_OK && several;
+    return status;
 }
 int tfhe_amd_pool_load_keys(tfhe_amd_pool *pool, const double *bkfft, const int32_t *ks) { return pool_load(pool, bkfft, true, ks); }
 int tfhe_amd_pool_load_keys_torus(tfhe_amd_pool *pool, const void *bk_torus, const int32_t *ks) {
@@ -530,6 +541,7 @@ struct tfhe_amd_cb_pool {
     std::mutex call_mu;
     std::string err;
     int chunk_rows = 1024;  // one Torus64 / N2 = 2048 ciphertext per wave on every SIMD: the blind rotation's full-rate batch
+    unsigned mixed = 0;     // bit per key component (0 preKS, 1 bk, 2 + u private key-switch plane u) whose last load failed on SOME members
 };
 
 namespace {
@@ -538,10 +550,15 @@ int cb_member_status(tfhe_amd_cb_pool::Member &mb, int rc) {
     return rc;
 }
 template <class Load>
-int cb_pool_load(tfhe_amd_cb_pool *pool, const void *key, Load load) {
-    if (!pool || !key) return TFHE_AMD_ERR_PARAM;
+int cb_pool_load(tfhe_amd_cb_pool *pool, const void *key, int component, Load load) {
+    if (!pool || !key || component < 0 || component > 31) return TFHE_AMD_ERR_PARAM;
     std::lock_guard<std::mutex> lk(pool->call_mu);
-    return on_every_member(pool, [=](int i) { return cb_member_status(pool->m[i], load(pool->m[i].cb)); });
+    const int status = on_every_member(pool, [=](int i) { return cb_member_status(pool->m[i], load(pool->m[i].cb)); });
+    if (status != TFHE_AMD_OK && pool->m.size() > 1)
+        pool->mixed |= 1u << component;
+    else if (status == TFHE_AMD_OK)
+        pool->mixed &= ~(1u << component);
+    return status;
 }
 }  // namespace
 
@@ -595,16 +612,16 @@ tfhe_amd_cb *tfhe_amd_cb_pool_member(tfhe_amd_cb_pool *pool, int member) {
     return pool && member >= 0 && member < (int)pool->m.size() ? pool->m[member].cb : nullptr;
 }
 int tfhe_amd_cb_pool_load_preks(tfhe_amd_cb_pool *pool, const int32_t *preks) {
-    return cb_pool_load(pool, preks, [preks](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_preks(cb, preks); });
+    return cb_pool_load(pool, preks, 0, [preks](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_preks(cb, preks); });
 }
 int tfhe_amd_cb_pool_load_bk_fft(tfhe_amd_cb_pool *pool, const double *bkfft) {
-    return cb_pool_load(pool, bkfft, [bkfft](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_bk_fft(cb, bkfft); });
+    return cb_pool_load(pool, bkfft, 1, [bkfft](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_bk_fft(cb, bkfft); });
 }
 int tfhe_amd_cb_pool_load_bk_torus(tfhe_amd_cb_pool *pool, const int64_t *bk) {
-    return cb_pool_load(pool, bk, [bk](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_bk_torus(cb, bk); });
+    return cb_pool_load(pool, bk, 1, [bk](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_bk_torus(cb, bk); });
 }
 int tfhe_amd_cb_pool_load_privks_plane(tfhe_amd_cb_pool *pool, int u_plane, const int32_t *plane) {
-    return cb_pool_load(pool, plane, [u_plane, plane](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_privks_plane(cb, u_plane, plane); });
+    return cb_pool_load(pool, plane, 2 + (u_plane & 15), [u_plane, plane](tfhe_amd_cb *cb) { return tfhe_amd_cb_load_privks_plane(cb, u_plane, plane); });
 }
 
 }  // extern "C"
@@ -614,6 +631,10 @@ template <class RowsIn, class RowsOut>
 int cb_pool_rows_fn(tfhe_amd_cb_pool *pool, RowsOut rows_out, RowsIn rows_in, int count) {
     if (!pool || count < 0) return TFHE_AMD_ERR_PARAM;
     std::lock_guard<std::mutex> lk(pool->call_mu);
+    if (pool->mixed) {
+        pool->err = "the last load of a key failed on some members: the members hold different keys, load it again";
+        return TFHE_AMD_ERR_STATE;
+    }
     const int members = (int)pool->m.size();
     const size_t in_row = ((size_t)pool->p.N1 + 1) * 4, out_row = (size_t)2 * pool->p.l1 * 2 * pool->p.N1 * 4;
     return on_every_member(pool, [=](int i) {

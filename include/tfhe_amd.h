@@ -336,7 +336,10 @@ int tfhe_amd_pool_device(const tfhe_amd_pool *pool, int member);
 /* member's context (borrowed; for options, events, the device-pointer entry points) */
 tfhe_amd_ctx *tfhe_amd_pool_ctx(tfhe_amd_pool *pool, int member);
 /* one upload per member, in parallel: bkfft = LweBootstrappingKeyFFT::bkFFT flattened, [n][(k+1)l][k+1][N] doubles (as
- * tfhe_amd_gsw_from_fft); ks = LweKeySwitchKey::ks flattened (as tfhe_amd_load_keyswitch_key); either may be NULL */
+ * tfhe_amd_gsw_from_fft); ks = LweKeySwitchKey::ks flattened (as tfhe_amd_load_keyswitch_key); either may be NULL.
+ * A load that fails on SOME members (the status and tfhe_amd_pool_last_error name the first: "member i (device d): ...")
+ * leaves the members with different keys: every operation of the pool then returns TFHE_AMD_ERR_STATE without running
+ * until a load of that key has succeeded on all members (tfhe_amd_cb_pool_load_*: the same, per key component). */
 int tfhe_amd_pool_load_keys(tfhe_amd_pool *pool, const double *bkfft, const int32_t *ks);
 /* the same with the bootstrapping key in coefficient form (converted on every device, tGswToFFTConvert) */
 int tfhe_amd_pool_load_keys_torus(tfhe_amd_pool *pool, const void *bk_torus, const int32_t *ks);

@@ -22,6 +22,9 @@ struct tfhe_amd_ctx {
 struct tfhe_amd_gsw {
     tfhe_amd_ctx *ctx;
 };
+// failure injection: key loads fail on contexts of this device (-1: never)
+extern "C" int pool_mock_fail_key_load_on_device;
+int pool_mock_fail_key_load_on_device = -1;
 namespace {
 struct Enter {
     tfhe_amd_ctx *c;
@@ -60,7 +63,12 @@ int tfhe_amd_event_record(tfhe_amd_ctx *c, void *) { Enter e(c); return TFHE_AMD
 int tfhe_amd_event_sync(tfhe_amd_ctx *c, void *) { Enter e(c); return TFHE_AMD_OK; }
 int tfhe_amd_stream_wait_event(tfhe_amd_ctx *c, void *) { Enter e(c); return TFHE_AMD_OK; }
 int tfhe_amd_event_destroy(tfhe_amd_ctx *c, void *ev) { Enter e(c); free(ev); return TFHE_AMD_OK; }
-int tfhe_amd_gsw_from_fft(tfhe_amd_ctx *c, const double *, int, tfhe_amd_gsw **out) { Enter e(c); *out = new tfhe_amd_gsw{c}; return TFHE_AMD_OK; }
+int tfhe_amd_gsw_from_fft(tfhe_amd_ctx *c, const double *, int, tfhe_amd_gsw **out) {
+    Enter e(c);
+    if (c->device == pool_mock_fail_key_load_on_device) { c->err = "injected key-load failure"; return TFHE_AMD_ERR_DEVICE; }
+    *out = new tfhe_amd_gsw{c};
+    return TFHE_AMD_OK;
+}
 int tfhe_amd_gsw_from_torus(tfhe_amd_ctx *c, const void *, int, tfhe_amd_gsw **out) { Enter e(c); *out = new tfhe_amd_gsw{c}; return TFHE_AMD_OK; }
 void tfhe_amd_gsw_free(tfhe_amd_gsw *g) { delete g; }
 int tfhe_amd_set_bootstrap_key(tfhe_amd_ctx *c, const tfhe_amd_gsw *g) { Enter e(c); c->has_bk = g != nullptr; return TFHE_AMD_OK; }

@@ -11,6 +11,8 @@
 
 #include "tfhe_amd.h"
 
+extern "C" int pool_mock_fail_key_load_on_device;  // tests/compat/pool_mock_engine.cpp: key loads fail on this device
+
 static const int n = 6, N = 20, MU = 77;
 static int32_t expect(int32_t x0, const int32_t *row, int j) { (void)x0; return (int32_t)((3u * (uint32_t)row[j % (n + 1)] + (uint32_t)j + (uint32_t)MU)) ^ 0x5a5a5a5a; }
 struct Rows {
@@ -65,6 +67,24 @@ int main() {
     std::vector<std::thread> th;
     for (int t = 0; t < 6; t++) th.emplace_back(work, t);
     for (auto &x : th) x.join();
+    // a key load that fails on ONE member (device 5 = member 3): reported with the member and its device, and the pool then
+    // refuses to run -- its members hold different keys -- until a load has succeeded everywhere
+    {
+        pool_mock_fail_key_load_on_device = 5;
+        if (tfhe_amd_pool_load_keys(pool, &bk, &ks) != TFHE_AMD_ERR_DEVICE) bad++;
+        if (!strstr(tfhe_amd_pool_last_error(pool), "member 3 (device 5)")) bad++;
+        std::vector<int32_t> x((size_t)8 * (n + 1), 1), out((size_t)8 * (n + 1), -1);
+        if (tfhe_amd_pool_bootstrap_host(pool, out.data(), MU, x.data(), 8) != TFHE_AMD_ERR_STATE) bad++;
+        if (!strstr(tfhe_amd_pool_last_error(pool), "different keys")) bad++;
+        if (out[0] != -1) bad++;  // nothing ran
+        if (tfhe_amd_pool_load_keys(pool, nullptr, &ks) != TFHE_AMD_OK) bad++;  // the other key loads, the failed one is still owed
+        if (tfhe_amd_pool_bootstrap_host(pool, out.data(), MU, x.data(), 8) != TFHE_AMD_ERR_STATE) bad++;
+        pool_mock_fail_key_load_on_device = -1;
+        if (tfhe_amd_pool_load_keys(pool, &bk, nullptr) != TFHE_AMD_OK) bad++;
+        if (tfhe_amd_pool_bootstrap_host(pool, out.data(), MU, x.data(), 8) != TFHE_AMD_OK) bad++;
+        for (int j = 0; j <= n; j++)
+            if (out[(size_t)7 * (n + 1) + j] != expect(0, &x[(size_t)7 * (n + 1)], j)) bad++;
+    }
     tfhe_amd_pool_destroy(pool);
     printf("pool_tsan_test: %s (%d mismatches)\n", bad ? "FAILED" : "ok", bad);
     return bad ? 1 : 0;
