@@ -174,6 +174,7 @@ class Coalescer {
         const std::chrono::nanoseconds took = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0);
         lk.lock();
         crowd_ = batch.size() + pending_.size();
+        requests_ += batch.size();
         linger_bound_ = std::min(took / 10, std::chrono::nanoseconds(300000));
         batches_++;
         Req *next = pending_.empty() ? nullptr : pending_.front();  // (stays in pending_: its own request rides in its batch)
@@ -184,6 +185,13 @@ class Coalescer {
         if (next) wake(next, &Req::lead);
         for (Req *r : batch)
             if (r != &me) wake(r, &Req::done);
+    }
+
+    // launches issued and requests carried so far (diagnostics: requests / batches = the mean launch size)
+    void stats(unsigned long *batches, unsigned long *requests) {
+        std::lock_guard<std::mutex> lk(mu_);
+        *batches = batches_;
+        *requests = requests_;
     }
 
    private:
@@ -205,7 +213,7 @@ class Coalescer {
     size_t crowd_ = 1;                        // callers around: size of the last batch + what was pending when it finished
     std::chrono::nanoseconds linger_bound_{0};  // a tenth of the last launch, 300 us at most
     int shift_ = 0;                           // the bound is halved `shift_` times after waits that ran out
-    unsigned batches_ = 0;
+    unsigned long batches_ = 0, requests_ = 0;
 };
 struct LweCall {
     LweSample *result;
@@ -222,13 +230,32 @@ struct CoalesceKey {
         return mu < o.mu;
     }
 };
+struct LweCoalescers {
+    std::mutex m;
+    std::map<CoalesceKey, Coalescer<LweCall> *> reg;  // entries live for the process (a few hundred bytes per key and mu)
+};
+inline LweCoalescers &lwe_coalescers() {
+    static LweCoalescers r;
+    return r;
+}
 inline Coalescer<LweCall> &lwe_coalescer(int kind, const void *key, int32_t mu) {
-    static std::mutex m;
-    static std::map<CoalesceKey, Coalescer<LweCall> *> reg;  // entries live for the process (a few dozen bytes per key and mu)
-    std::lock_guard<std::mutex> lk(m);
-    Coalescer<LweCall> *&c = reg[CoalesceKey{kind, key, mu}];
+    LweCoalescers &r = lwe_coalescers();
+    std::lock_guard<std::mutex> lk(r.m);
+    Coalescer<LweCall> *&c = r.reg[CoalesceKey{kind, key, mu}];
     if (!c) c = new Coalescer<LweCall>();
     return *c;
+}
+// launches and one-sample requests of the coalesced gate entry points so far, all keys (diagnostics)
+inline void lwe_coalescer_totals(unsigned long *batches, unsigned long *requests) {
+    LweCoalescers &r = lwe_coalescers();
+    std::lock_guard<std::mutex> lk(r.m);
+    *batches = *requests = 0;
+    for (auto &e : r.reg) {
+        unsigned long b, q;
+        e.second->stats(&b, &q);
+        *batches += b;
+        *requests += q;
+    }
 }
 
 inline int &device_ordinal() {

@@ -329,6 +329,10 @@ static int run_arr(const char *inp, const char *outp) {
     for (int c = 0; c < tcount; c++) rt[c] = LweSample{a_thr.data() + (size_t)c * n, 0, 0};
     const int want_threads = getenv("TFHE_COMPAT_THREADS") ? atoi(getenv("TFHE_COMPAT_THREADS")) : 32;
     const int nthreads = count < want_threads ? (count < 2 ? 2 : count) : want_threads;
+    unsigned long co_b0 = 0, co_q0 = 0, co_b1 = 0, co_q1 = 0;  // launches / requests of the coalescer around the loop
+#ifndef DROPIN
+    lwe_coalescer_totals(&co_b0, &co_q0);
+#endif
     const double t2 = now_s();
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(nthreads) schedule(static, 1)
@@ -344,6 +348,9 @@ static int run_arr(const char *inp, const char *outp) {
     }
 #endif
     const double t_par = now_s() - t2;
+#ifndef DROPIN
+    lwe_coalescer_totals(&co_b1, &co_q1);
+#endif
     // the other coalesced entry points from threads: woKS and the key switch on its outputs == the full bootstrap
     std::vector<Torus32> a_thr_woks((size_t)tcount * N), a_thr_ks((size_t)tcount * n);
     std::vector<LweSample> rtu((size_t)tcount), rtk((size_t)tcount);
@@ -425,9 +432,10 @@ static int run_arr(const char *inp, const char *outp) {
     printf("{\"count\": %d, \"array_seconds\": %.6f, \"array_bootstraps_per_s\": %.1f, \"loop_seconds\": %.6f, "
            "\"loop_bootstraps_per_s\": %.1f, \"array_identical_to_loop\": %s, \"pool_devices\": %d, \"pool_seconds\": %.6f, "
            "\"pool_identical_to_loop\": %s, \"parallel_for_threads\": %d, \"parallel_for_seconds\": %.6f, "
-           "\"parallel_for_bootstraps_per_s\": %.1f, \"openmp\": %s}\n",
+           "\"parallel_for_bootstraps_per_s\": %.1f, \"parallel_for_launches\": %lu, \"parallel_for_mean_launch\": %.1f, \"openmp\": %s}\n",
            count, t_arr, count / t_arr, t_loop, count / t_loop, same ? "true" : "false", (int)devs.size(), t_pool,
-           devs.size() > 1 ? (pool_same ? "true" : "false") : "null", nthreads, t_par, count / t_par,
+           devs.size() > 1 ? (pool_same ? "true" : "false") : "null", nthreads, t_par, count / t_par, co_b1 - co_b0,
+           co_b1 > co_b0 ? (double)(co_q1 - co_q0) / (double)(co_b1 - co_b0) : 0.0,
 #ifdef _OPENMP
            "true"
 #else
