@@ -85,8 +85,15 @@ struct Staging {
     void *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
     void *d_mid = nullptr;  // intermediate of a two-kernel operation (blind rotation -> key switch), owned here so that two sets can be in flight
     size_t in_bytes = 0, out_bytes = 0, mid_bytes = 0;
+    // buffers grow geometrically (at least 1 MiB, at least twice the previous size): calls of varying size -- the shims' coalesced
+    // one-sample calls -- must not pay a pinned + device reallocation (milliseconds; the frees synchronise) at every new maximum
+    static size_t grown(size_t have, size_t need) {
+        const size_t want = have * 2 > need ? have * 2 : need;
+        return want > ((size_t)1 << 20) ? want : ((size_t)1 << 20);
+    }
     int ensure_mid(tfhe_amd_ctx *c, size_t need) {
         if (mid_bytes >= need) return TFHE_AMD_OK;
+        need = grown(mid_bytes, need);
         if (d_mid) tfhe_amd_free(c, d_mid);
         d_mid = nullptr;
         mid_bytes = 0;
@@ -96,6 +103,7 @@ struct Staging {
     }
     int ensure(tfhe_amd_ctx *c, size_t in_need, size_t out_need) {
         if (in_bytes < in_need) {
+            in_need = grown(in_bytes, in_need);
             if (h_in) tfhe_amd_host_free(c, h_in);
             if (d_in) tfhe_amd_free(c, d_in);
             h_in = d_in = nullptr;
@@ -105,6 +113,7 @@ struct Staging {
             in_bytes = in_need;
         }
         if (out_bytes < out_need) {
+            out_need = grown(out_bytes, out_need);
             if (h_out) tfhe_amd_host_free(c, h_out);
             if (d_out) tfhe_amd_free(c, d_out);
             h_out = d_out = nullptr;

@@ -46,6 +46,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -124,9 +125,13 @@ inline std::recursive_mutex &shim_mutex() {
 // LINGER.  A tight loop of T threads would otherwise settle into two alternating groups of T/2: the callers of the batch in
 // flight come back microseconds AFTER the next leader has taken what was pending.  The coalescer keeps an estimate of the
 // callers around (the last batch + what was pending when it finished); a leader that holds fewer requests than that waits for
-// the stragglers -- at most a tenth of the last launch's duration, 300 us at most -- and goes as soon as they are all there.
-// A lone caller never waits (estimate 1).  When the wait runs out without the crowd arriving (callers with work of their own
-// between calls) the next waits are halved, down to 1/16 of that bound, and the full wait is tried again every 16th batch.
+// the stragglers -- at most an eighth of the last launch's duration, 0.5 ms at most -- and goes as soon as they are all there
+// (32 callers are back within ~0.1 ms: 6.5 -> 12 k bootstraps/s on one MI355X; with 256 callers the host's turnaround is as long
+// as the launch itself, waiting for everyone only idles the GPU, and launches of about half the callers, alternating, are as
+// fast: 36-47 k/s with any bound, profiles/r05_array_form_stats.jsonl).  A lone caller never waits (estimate 1).  A wait that
+// ran out while callers were still arriving lengthens the next one, a wait during which nobody came halves it (down to 1/16 of
+// the bound; the full wait is tried again every 16th batch).  TFHE_AMD_COALESCE_LINGER_US in the environment fixes the bound
+// (0: never wait).
 template <class Item>
 class Coalescer {
    public:
@@ -144,13 +149,23 @@ class Coalescer {
             // instead of queueing, one after the other, for the one lock a shared condition variable would hand them
             std::unique_lock<std::mutex> mine(me.m);
             me.cv.wait(mine, [&] { return me.done || me.lead; });
-            if (me.done) return;  // another caller's batch carried this request
+            if (me.done) {  // another caller's batch carried this request
+                if (me.wake_list) {  // ... and its leader made this caller a captain: pass the news on to a share of the batch
+                    const std::shared_ptr<std::vector<Req *>> list = std::move(me.wake_list);
+                    const size_t lo = me.wake_lo, hi = me.wake_hi;
+                    mine.unlock();
+                    for (size_t i = lo; i < hi; i++) wake((*list)[i], &Req::done);
+                }
+                return;
+            }
             mine.unlock();
             lk.lock();
         }
         busy_ = true;  // (already true when the lead was handed over)
         if (pending_.size() < crowd_ && linger_bound_.count() > 0) {
-            const int shift = (batches_ % 16 == 15) ? 0 : shift_;
+            const int shift = (linger_fixed_us() >= 0 || batches_ % 16 == 15) ? 0 : shift_;
+            const size_t had = pending_.size();
+            lingers_++;
             lingering_ = true;
 #if defined(__SANITIZE_THREAD__)
             // (gcc 11's ThreadSanitizer runtime does not intercept pthread_cond_clockwait, what a wait on the steady clock
@@ -161,7 +176,15 @@ class Coalescer {
             const bool all_here = gather_cv_.wait_for(lk, linger_bound_ / (1 << shift), [&] { return pending_.size() >= crowd_; });
 #endif
             lingering_ = false;
-            shift_ = all_here ? 0 : (shift_ < 4 ? shift_ + 1 : 4);
+            // all there: full waits from now on.  Ran out while callers were still arriving: they are on their way, wait longer
+            // next time.  Ran out and nobody came: the callers have work of their own, halve the wait.
+            if (all_here)
+                shift_ = 0;
+            else if (pending_.size() > had)
+                shift_ = shift_ > 0 ? shift_ - 1 : 0;
+            else
+                shift_ = shift_ < 4 ? shift_ + 1 : 4;
+            if (!all_here) linger_timeouts_++;
         }
         std::vector<Req *> batch;
         batch.swap(pending_);
@@ -175,7 +198,8 @@ class Coalescer {
         lk.lock();
         crowd_ = batch.size() + pending_.size();
         requests_ += batch.size();
-        linger_bound_ = std::min(took / 10, std::chrono::nanoseconds(300000));
+        linger_bound_ = linger_fixed_us() >= 0 ? std::chrono::nanoseconds(1000LL * linger_fixed_us())
+                                                : std::min(took / 8, std::chrono::nanoseconds(500000));
         batches_++;
         Req *next = pending_.empty() ? nullptr : pending_.front();  // (stays in pending_: its own request rides in its batch)
         if (!next) busy_ = false;
@@ -183,15 +207,48 @@ class Coalescer {
         // the lead goes out first -- the next leader gathers while this one is still waking its batch; a flag is set and its
         // owner notified under the REQUEST's mutex (the Req lives on its owner's stack until the owner has seen the flag)
         if (next) wake(next, &Req::lead);
+        // a large batch is woken in two levels -- ~sqrt(n) captains by this thread, a contiguous share of the rest by each
+        // captain -- so that the last caller of 256 hears of it after ~30 wake-ups, not 255
+        std::shared_ptr<std::vector<Req *>> others = std::make_shared<std::vector<Req *>>();
+        others->reserve(batch.size());
         for (Req *r : batch)
-            if (r != &me) wake(r, &Req::done);
+            if (r != &me) others->push_back(r);
+        const size_t n = others->size();
+        size_t captains = n;
+        if (n > 16) {
+            captains = 4;
+            while (captains * captains < n) captains++;
+        }
+        const size_t rest = n - captains, share = captains ? (rest + captains - 1) / captains : 0;
+        for (size_t j = 0; j < captains; j++) {
+            Req *r = (*others)[j];
+            std::lock_guard<std::mutex> g(r->m);
+            const size_t lo = captains + j * share, hi = lo + share < n ? lo + share : n;
+            if (rest && lo < hi) {
+                r->wake_list = others;
+                r->wake_lo = lo;
+                r->wake_hi = hi;
+            }
+            r->done = true;
+            r->cv.notify_one();
+        }
     }
 
     // launches issued and requests carried so far (diagnostics: requests / batches = the mean launch size)
-    void stats(unsigned long *batches, unsigned long *requests) {
+    void stats(unsigned long *batches, unsigned long *requests, unsigned long *lingers = nullptr, unsigned long *linger_timeouts = nullptr) {
         std::lock_guard<std::mutex> lk(mu_);
         *batches = batches_;
         *requests = requests_;
+        if (lingers) *lingers = lingers_;
+        if (linger_timeouts) *linger_timeouts = linger_timeouts_;
+    }
+    // TFHE_AMD_COALESCE_LINGER_US in the environment: a FIXED wait bound in microseconds (0: leaders never wait), read once
+    static long linger_fixed_us() {
+        static const long v = [] {
+            const char *e = std::getenv("TFHE_AMD_COALESCE_LINGER_US");
+            return e && *e ? std::atol(e) : -1L;
+        }();
+        return v;
     }
 
    private:
@@ -200,6 +257,8 @@ class Coalescer {
         bool done = false, lead = false;
         std::mutex m;
         std::condition_variable cv;
+        std::shared_ptr<std::vector<Req *>> wake_list;  // captain duty (set with `done`): wake [wake_lo, wake_hi) of this list
+        size_t wake_lo = 0, wake_hi = 0;
     };
     static void wake(Req *r, bool Req::*flag) {
         std::lock_guard<std::mutex> g(r->m);
@@ -211,9 +270,9 @@ class Coalescer {
     std::vector<Req *> pending_;
     bool busy_ = false, lingering_ = false;
     size_t crowd_ = 1;                        // callers around: size of the last batch + what was pending when it finished
-    std::chrono::nanoseconds linger_bound_{0};  // a tenth of the last launch, 300 us at most
+    std::chrono::nanoseconds linger_bound_{0};  // an eighth of the last launch, 0.5 ms at most
     int shift_ = 0;                           // the bound is halved `shift_` times after waits that ran out
-    unsigned long batches_ = 0, requests_ = 0;
+    unsigned long batches_ = 0, requests_ = 0, lingers_ = 0, linger_timeouts_ = 0;
 };
 struct LweCall {
     LweSample *result;
@@ -246,15 +305,20 @@ inline Coalescer<LweCall> &lwe_coalescer(int kind, const void *key, int32_t mu) 
     return *c;
 }
 // launches and one-sample requests of the coalesced gate entry points so far, all keys (diagnostics)
-inline void lwe_coalescer_totals(unsigned long *batches, unsigned long *requests) {
+inline void lwe_coalescer_totals(unsigned long *batches, unsigned long *requests, unsigned long *lingers = nullptr,
+                                 unsigned long *linger_timeouts = nullptr) {
     LweCoalescers &r = lwe_coalescers();
     std::lock_guard<std::mutex> lk(r.m);
     *batches = *requests = 0;
+    if (lingers) *lingers = 0;
+    if (linger_timeouts) *linger_timeouts = 0;
     for (auto &e : r.reg) {
-        unsigned long b, q;
-        e.second->stats(&b, &q);
+        unsigned long b, q, w, t;
+        e.second->stats(&b, &q, &w, &t);
         *batches += b;
         *requests += q;
+        if (lingers) *lingers += w;
+        if (linger_timeouts) *linger_timeouts += t;
     }
 }
 
@@ -462,19 +526,27 @@ inline Resident &attach_gsw(const GswT *bkFFT, int n, int N, int l, int Bgbit, c
 // staging of the array forms: one gather into PINNED host memory, one copy each way
 inline void array_staging(tfhe_amd_ctx *ctx, void *&h_in, void *&da_in, size_t &have_in, size_t in_bytes, void *&h_out,
                           void *&da_out, size_t &have_out, size_t out_bytes) {
+    // grown GEOMETRICALLY (at least 1 MiB, at least twice the previous size): the coalesced one-sample calls arrive in launches
+    // of varying size, and a pinned + device reallocation at every new maximum costs milliseconds each (the frees synchronise)
+    auto grown = [](size_t have, size_t need) {
+        size_t want = have * 2 > need ? have * 2 : need;
+        return want > ((size_t)1 << 20) ? want : ((size_t)1 << 20);
+    };
     if (have_in < in_bytes) {
+        const size_t want = grown(have_in, in_bytes);
         if (h_in) tfhe_amd_host_free(ctx, h_in);
         if (da_in) tfhe_amd_free(ctx, da_in);
-        check(tfhe_amd_host_alloc(ctx, &h_in, in_bytes), ctx, "host_alloc");
-        check(tfhe_amd_malloc(ctx, &da_in, in_bytes), ctx, "malloc");
-        have_in = in_bytes;
+        check(tfhe_amd_host_alloc(ctx, &h_in, want), ctx, "host_alloc");
+        check(tfhe_amd_malloc(ctx, &da_in, want), ctx, "malloc");
+        have_in = want;
     }
     if (have_out < out_bytes) {
+        const size_t want = grown(have_out, out_bytes);
         if (h_out) tfhe_amd_host_free(ctx, h_out);
         if (da_out) tfhe_amd_free(ctx, da_out);
-        check(tfhe_amd_host_alloc(ctx, &h_out, out_bytes), ctx, "host_alloc");
-        check(tfhe_amd_malloc(ctx, &da_out, out_bytes), ctx, "malloc");
-        have_out = out_bytes;
+        check(tfhe_amd_host_alloc(ctx, &h_out, want), ctx, "host_alloc");
+        check(tfhe_amd_malloc(ctx, &da_out, want), ctx, "malloc");
+        have_out = want;
     }
 }
 inline void array_staging(Resident &R, size_t in_bytes, size_t out_bytes) {

@@ -329,9 +329,9 @@ static int run_arr(const char *inp, const char *outp) {
     for (int c = 0; c < tcount; c++) rt[c] = LweSample{a_thr.data() + (size_t)c * n, 0, 0};
     const int want_threads = getenv("TFHE_COMPAT_THREADS") ? atoi(getenv("TFHE_COMPAT_THREADS")) : 32;
     const int nthreads = count < want_threads ? (count < 2 ? 2 : count) : want_threads;
-    unsigned long co_b0 = 0, co_q0 = 0, co_b1 = 0, co_q1 = 0;  // launches / requests of the coalescer around the loop
+    unsigned long co_b0 = 0, co_q0 = 0, co_b1 = 0, co_q1 = 0, co_w0 = 0, co_t0 = 0, co_w1 = 0, co_t1 = 0;  // launches / requests of the coalescer around the loop
 #ifndef DROPIN
-    lwe_coalescer_totals(&co_b0, &co_q0);
+    lwe_coalescer_totals(&co_b0, &co_q0, &co_w0, &co_t0);
 #endif
     const double t2 = now_s();
 #ifdef _OPENMP
@@ -349,7 +349,7 @@ static int run_arr(const char *inp, const char *outp) {
 #endif
     const double t_par = now_s() - t2;
 #ifndef DROPIN
-    lwe_coalescer_totals(&co_b1, &co_q1);
+    lwe_coalescer_totals(&co_b1, &co_q1, &co_w1, &co_t1);
 #endif
     // the other coalesced entry points from threads: woKS and the key switch on its outputs == the full bootstrap
     std::vector<Torus32> a_thr_woks((size_t)tcount * N), a_thr_ks((size_t)tcount * n);
@@ -432,10 +432,10 @@ static int run_arr(const char *inp, const char *outp) {
     printf("{\"count\": %d, \"array_seconds\": %.6f, \"array_bootstraps_per_s\": %.1f, \"loop_seconds\": %.6f, "
            "\"loop_bootstraps_per_s\": %.1f, \"array_identical_to_loop\": %s, \"pool_devices\": %d, \"pool_seconds\": %.6f, "
            "\"pool_identical_to_loop\": %s, \"parallel_for_threads\": %d, \"parallel_for_seconds\": %.6f, "
-           "\"parallel_for_bootstraps_per_s\": %.1f, \"parallel_for_launches\": %lu, \"parallel_for_mean_launch\": %.1f, \"openmp\": %s}\n",
+           "\"parallel_for_bootstraps_per_s\": %.1f, \"parallel_for_launches\": %lu, \"parallel_for_mean_launch\": %.1f, \"parallel_for_leader_waits\": %lu, \"parallel_for_waits_run_out\": %lu, \"openmp\": %s}\n",
            count, t_arr, count / t_arr, t_loop, count / t_loop, same ? "true" : "false", (int)devs.size(), t_pool,
            devs.size() > 1 ? (pool_same ? "true" : "false") : "null", nthreads, t_par, count / t_par, co_b1 - co_b0,
-           co_b1 > co_b0 ? (double)(co_q1 - co_q0) / (double)(co_b1 - co_b0) : 0.0,
+           co_b1 > co_b0 ? (double)(co_q1 - co_q0) / (double)(co_b1 - co_b0) : 0.0, co_w1 - co_w0, co_t1 - co_t0,
 #ifdef _OPENMP
            "true"
 #else
