@@ -26,6 +26,10 @@ void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Tor
 void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, const TGswParams *params) {
     tfhe_amd_compat::tGswFFTExternMulToTLwe(accum, gsw, params);
 }
+void tfhe_MuxRotate_FFT(TLweSample *result, const TLweSample *accum, const TGswSampleFFT *bki, const int barai,
+                        const TGswParams *bk_params) {
+    tfhe_amd_compat::tfhe_MuxRotate_FFT(result, accum, bki, barai, bk_params);
+}
 void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample) {
     tfhe_amd_compat::lweKeySwitch(result, ks, sample);
 }

@@ -694,6 +694,18 @@ inline void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, 
     check(tfhe_amd_extern_mul(R.ctx, R.d_in, R.gsw, 0, 1), R.ctx, "extern_mul");
     get_tlwe(R, accum, R.d_in, R.N);
 }
+// tfhe_MuxRotate_FFT (CB/lwe_functions.cpp:328-333): result = bki (x) ((X^barai - 1) accum) + accum -- one CMux step of the blind
+// rotation on its own; result and accum may be the same object (the reference's callers ping-pong two samples)
+inline void tfhe_MuxRotate_FFT(TLweSample *result, const TLweSample *accum, const TGswSampleFFT *bki, const int barai,
+                               const TGswParams *bk_params) {
+    TFHE_AMD_SHIM_GUARD();
+    Resident &R = attach_gsw(bki, 1, bk_params->tlwe_params->N, bk_params->l, bk_params->Bgbit);
+    put_tlwe(R, R.d_in, accum, R.N);
+    const int32_t a = (int32_t)barai;
+    check(tfhe_amd_memcpy_h2d(R.ctx, R.d_aux, &a, sizeof(a)), R.ctx, "h2d");
+    check(tfhe_amd_mux_rotate(R.ctx, R.d_in, R.gsw, 0, (const int32_t *)R.d_aux, 1), R.ctx, "mux_rotate");
+    get_tlwe(R, result, R.d_in, R.N);
+}
 // lweKeySwitch(result, ks, sample): a key-switch key seen on its own gets its own resident engine
 // (input dimension ks->n must be a ring degree the engine supports: 1024 or 2048)
 inline Resident &attach_ks(const LweKeySwitchKey *ks) {

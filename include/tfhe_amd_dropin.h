@@ -8,6 +8,7 @@
 //     tfhe_bootstrap_woKS_FFT         CB/lwe_functions.cpp:399-402
 //     tfhe_bootstrap_FFT              CB/lwe_functions.cpp:434-437
 //     tGswFFTExternMulToTLwe          CB/tgsw_functions.cpp:424
+//     tfhe_MuxRotate_FFT              CB/lwe_functions.cpp:328
 //     lweKeySwitch                    CB/lwe_functions.cpp:163
 //   The struct definitions below carry the fields those files use; a driver that has the
 //   upstream headers defines TFHE_AMD_DROPIN_NO_LIBRARY_TYPES before including this file.
@@ -38,6 +39,8 @@ void tfhe_blindRotateAndExtract_FFT(LweSample *result, const TorusPolynomial *v,
 void tfhe_bootstrap_woKS_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x);
 void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x);
 void tGswFFTExternMulToTLwe(TLweSample *accum, const TGswSampleFFT *gsw, const TGswParams *params);
+void tfhe_MuxRotate_FFT(TLweSample *result, const TLweSample *accum, const TGswSampleFFT *bki, const int barai,
+                        const TGswParams *bk_params);
 void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample);
 /* ARRAY FORMS: the caller's loop over `count` independent samples (the reference's drivers loop over one-sample calls,
  * poc:1009-1013; parallel/src/test_parallel_multiplications.cpp:62) as one gather, ONE launch, one scatter.

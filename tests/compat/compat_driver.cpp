@@ -155,6 +155,15 @@ static int run_lib(const char *inp, const char *outp) {
         TLweSample as2{ap2, ap2 + 1, 0, 1};
         tGswFFTExternMulToTLwe(&as2, &gsw[n - 1], &gp);
         out.put(acc2.data(), 4 * (size_t)2 * N);
+        // one CMux step on its own (tfhe_MuxRotate_FFT, CB/lwe_functions.cpp:328-333): into a second sample, then in place;
+        // rotation amounts from the sample's own rotation list (any of [0, 2N): 0 must give the accumulator back)
+        std::vector<Torus32> acc3(accs + (size_t)c * 2 * N, accs + (size_t)(c + 1) * 2 * N), res3((size_t)2 * N, 0);
+        TorusPolynomial ap3[2] = {{N, acc3.data()}, {N, acc3.data() + N}}, rp3[2] = {{N, res3.data()}, {N, res3.data() + N}};
+        TLweSample as3{ap3, ap3 + 1, 0, 1}, rs3{rp3, rp3 + 1, 0, 1};
+        tfhe_MuxRotate_FFT(&rs3, &as3, &gsw[0], rt[0], &gp);
+        out.put(res3.data(), 4 * (size_t)2 * N);
+        tfhe_MuxRotate_FFT(&as3, &as3, &gsw[n - 1], c == 0 ? 0 : rt[n - 1], &gp);
+        out.put(acc3.data(), 4 * (size_t)2 * N);
     }
     // release(bk), then a DIFFERENT key rebuilt at the same addresses (the TGSW samples in reverse order: same
     // structs, other polynomial pointers): the next call must upload it again, not reuse the stale GPU copy

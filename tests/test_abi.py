@@ -59,7 +59,7 @@ def test_dropin_library_exports_the_reference_names(hip_lib):
     block = text[text.index('extern "C" {'):text.index("#else")]
     names = sorted(set(re.findall(r"\bvoid\s+([A-Za-z_0-9]+)\s*\(", block)))
     assert names == sorted(["tfhe_blindRotate_FFT", "tfhe_blindRotateAndExtract_FFT", "tfhe_bootstrap_woKS_FFT", "tfhe_bootstrap_FFT",
-                            "tGswFFTExternMulToTLwe", "lweKeySwitch", "tfhe_amd_dropin_release", "tfhe_amd_dropin_set_device", "tfhe_amd_dropin_set_devices",
+                            "tGswFFTExternMulToTLwe", "tfhe_MuxRotate_FFT", "lweKeySwitch", "tfhe_amd_dropin_release", "tfhe_amd_dropin_set_device", "tfhe_amd_dropin_set_devices",
                             "tfhe_bootstrap_woKS_FFT_array", "tfhe_bootstrap_FFT_array", "lweKeySwitch_array"])
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/tfhe_amd_dropin.h but not exported"

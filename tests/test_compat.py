@@ -73,6 +73,9 @@ def run_lib_form(driver, tmp_path, N=1024, n=5, l=2, Bgbit=10, t=8, bb=2, count=
                               O.blind_rotate_extract32(N, v, bk, rot[c, n], rot[c, :n], l, Bgbit)), "blindRotateAndExtract"
         assert np.array_equal(take(np.int32, 2 * N), O.blind_rotate32(N, acc[c], bk, rot[c, :n], l, Bgbit).ravel()), "blindRotate"
         assert np.array_equal(take(np.int32, 2 * N), O.extprod32(N, acc[c], bk[n - 1], l, Bgbit).ravel()), "tGswFFTExternMulToTLwe"
+        assert np.array_equal(take(np.int32, 2 * N), O.mux_rotate32(N, acc[c], bk[0], rot[c, 0], l, Bgbit).ravel()), "tfhe_MuxRotate_FFT"
+        a_last = 0 if c == 0 else rot[c, n - 1]
+        assert np.array_equal(take(np.int32, 2 * N), O.mux_rotate32(N, acc[c], bk[n - 1], a_last, l, Bgbit).ravel()), "tfhe_MuxRotate_FFT in place"
     # after release(bk): the key rebuilt at the same addresses with its TGSW samples in reverse order
     bkr = np.ascontiguousarray(bk[::-1])
     assert np.array_equal(take(np.int32, N + 1), O.bootstrap_woks32(N, bkr, mu, x[0], l, Bgbit)), "release(bk) + rebuilt key, woKS"
