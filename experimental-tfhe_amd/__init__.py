@@ -799,8 +799,10 @@ def device_pci_bus_id(device=0, lib_path=None):
 def build_tables(N, lib_path=None):
     """the reference-layout twiddle tables (fft, ifft) from the host-only builder: no context, no device"""
     lib = load_library(lib_path)
-    f, r = np.empty(2 * N - 8), np.empty(2 * N - 8)
-    assert lib.tfhe_amd_build_tables(int(N), _np_ptr(f), _np_ptr(r)) == OK
+    f, r = np.empty(max(2 * N - 8, 1)), np.empty(max(2 * N - 8, 1))
+    rc = lib.tfhe_amd_build_tables(int(N), _np_ptr(f), _np_ptr(r))
+    if rc != OK:
+        raise TfheAmdError(f"status {rc}: tfhe_amd_build_tables({N}): the ring degree must be a power of two, 16 <= N <= 2^20")
     return f, r
 
 

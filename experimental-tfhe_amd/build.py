@@ -21,7 +21,7 @@ OUT_SPQLIOS = os.path.join(HERE, "libtfhe_amd_spqlios.so")  # the reference's FF
 OUT_PROBE = os.path.join(HERE, "libtfhe_amd_probe.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SOURCES = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp"), os.path.join(CSRC, "hp_twiddles.cpp"), os.path.join(CSRC, "pool.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "devport.h"), os.path.join(CSRC, "probe_hooks.h"),
+DEPS = SOURCES + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "tfhe_kernels_generic.h"), os.path.join(CSRC, "devport.h"), os.path.join(CSRC, "probe_hooks.h"),
                   os.path.join(os.path.dirname(HERE), "include", "tfhe_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]

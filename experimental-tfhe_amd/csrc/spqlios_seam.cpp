@@ -35,15 +35,18 @@ void chk(int rc, Engine *e, const char *what) {
     if (rc != TFHE_AMD_OK) die(what, rc, e ? e->ctx : nullptr);
 }
 
+// every ring degree the reference's plugin accepts: a power of two >= 16 (require() in new_fft_table / new_ifft_table,
+// spqlios-fft-impl.cpp:157-160,400-403); like the reference, anything else aborts with a message
+bool served(int N) { return N >= 16 && N <= (1 << 20) && (N & (N - 1)) == 0; }
 Engine *engine(int N) {
-    static Engine *slots[2] = {nullptr, nullptr};
+    static Engine *slots[32] = {nullptr};  // by log2(N)
     static std::mutex create_mu;
-    if (N != 1024 && N != 2048) {
-        std::fprintf(stderr, "tfhe_amd_spqlios: ring degree %d is not served (1024 and 2048 are)\n", N);
+    if (!served(N)) {
+        std::fprintf(stderr, "tfhe_amd_spqlios: ring degree %d is not served (n must be a power of 2, 16 <= n <= 2^20)\n", N);
         std::abort();
     }
     std::lock_guard<std::mutex> guard(create_mu);
-    Engine *&e = slots[N == 2048];
+    Engine *&e = slots[__builtin_ctz((unsigned)N)];
     if (e) return e;
     const char *dev = std::getenv("TFHE_AMD_DEVICE");
     tfhe_amd_params p;
@@ -84,8 +87,8 @@ struct Table {
     int inverse;
 };
 Table *new_table(int nn, int inverse) {
-    if (nn != 1024 && nn != 2048) {
-        std::fprintf(stderr, "tfhe_amd_spqlios: new_%sfft_table(%d): 1024 and 2048 are served\n", inverse ? "i" : "", nn);
+    if (!served(nn)) {  // the reference: require(nn >= 16), require(power of 2) -> abort
+        std::fprintf(stderr, "tfhe_amd_spqlios: new_%sfft_table(%d): n must be a power of 2, 16 <= n <= 2^20\n", inverse ? "i" : "", nn);
         std::abort();
     }
     Table *t = new Table();

@@ -2,6 +2,7 @@
 // key upload, kernel dispatch.  Built by hipcc for gfx950 (build.sh).  There is no CPU
 // path in this library: without a device, context creation fails.
 #include "tfhe_kernels.h"
+#include "tfhe_kernels_generic.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -28,6 +29,7 @@ struct tfhe_amd_ctx {
     tfhe_amd_params p;
     int device;
     int logn;
+    bool generic;  // N is neither 1024 nor 2048: the team-per-polynomial kernels of tfhe_kernels_generic.h
     hipStream_t stream;  // the stream work is issued on: `own`, or the caller's (tfhe_amd_set_stream)
     hipStream_t own;     // created with the context, alive until it is destroyed (switching streams costs nothing)
     std::string err;
@@ -42,6 +44,8 @@ struct tfhe_amd_ctx {
     size_t ws_lwe_bytes;
     void *ws_acc;
     size_t ws_acc_bytes;
+    void *ws_gen;  // generic-N kernels: transform / accumulator areas that do not fit the LDS
+    size_t ws_gen_bytes;
     int32_t *vp_rot_d;  // rotation constants of tfhe_amd_lut_eval
     void *hp_tw_d;      // Real96 twiddles: powomega [2N] then powombar [2N] (HpCplx), lazily built
     hipStream_t probe_stream;  // tfhe_amd_clock_probe: a second stream, so that the probe runs BESIDE the work queued on `stream`
@@ -228,7 +232,10 @@ int br32_class(const tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
     if (br_split_applies(c, a)) return 0;
     return (c->logn == 10 && a.batch <= BR_LONE_WAVE_MAX) ? 1 : 2;
 }
+template <typename T>
+int launch_br_gen(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a);
 int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
+    if (c->generic) return launch_br_gen<int32_t>(c, a);
     if (br_split_applies(c, a)) {
         if (c->p.Bgbit == 10) return launch_br_split<10>(c, a);
         if (c->p.Bgbit == 8) return launch_br_split<8>(c, a);
@@ -254,6 +261,7 @@ int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
     return launch_br_t<int32_t, 10, 8, 2>(c, a);
 }
 int launch_br64(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) {
+    if (c->generic) return launch_br_gen<int64_t>(c, a);
     // N=2048: accumulator in registers, 4 waves per workgroup (one per SIMD); tfhe_kernels.h, BlindRotateLds::ACCREG.
     // (Two waves per ciphertext -- 128 lanes x 8 points, everything in 256 registers, 8 waves per CU -- was built and
     // measured in round 3: bit-identical, 1.35 instead of 1.57 vector instructions per fp64 instruction, but 10-20 % SLOWER:
@@ -317,6 +325,98 @@ int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
     return launch_fft_w<TOUT, LOGN, FFT_WAVES>(c, out_d, in_d, batch);
 }
 
+// ---- ring degrees other than 1024 / 2048 (tfhe_kernels_generic.h) -------------------------------------------
+// dynamic LDS the generic kernels may ask for; their per-function limit is always raised to this (a process may hold
+// contexts of several ring degrees, and the attribute is per function, not per context)
+constexpr size_t GEN_LDS_MAX = (size_t)160 * 1024;
+constexpr size_t GEN_WORK_MAX = (size_t)256 << 20;  // global scratch of one launch when the LDS is too small
+int grow(tfhe_amd_ctx *c, void **buf, size_t *have, size_t need);
+// transforms: grid and work area of a launch over `batch` polynomials
+struct GenFftPlan {
+    int grid;
+    size_t lds;
+    double *work;
+};
+template <typename KernelT>
+int gen_fft_plan(tfhe_amd_ctx *c, KernelT kernel, int batch, GenFftPlan *pl) {
+    const int N = c->p.N, teams = GEN_BLOCK / gen_team_size(N / 2);
+    const size_t bytes = (size_t)teams * N * sizeof(double);
+    const int needed = (batch + teams - 1) / teams;
+    if (int rc = set_lds(c, kernel, GEN_LDS_MAX)) return rc;
+    if (bytes <= GEN_LDS_MAX) {
+        pl->lds = bytes;
+        pl->work = nullptr;
+        return persistent_grid(c, kernel, GEN_BLOCK, bytes, needed, &pl->grid);
+    }
+    long long g = (long long)(GEN_WORK_MAX / bytes);
+    if (g < 1) g = 1;
+    pl->grid = (int)(needed < g ? needed : g);
+    pl->lds = 0;
+    if (int rc = grow(c, &c->ws_gen, &c->ws_gen_bytes, (size_t)pl->grid * bytes)) return rc;
+    pl->work = (double *)c->ws_gen;
+    return TFHE_AMD_OK;
+}
+template <typename TIN, bool PACK>
+int launch_gen_ifft(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
+    GenFftPlan pl;
+    if (int rc = gen_fft_plan(c, kg_ifft_batch<TIN, PACK>, batch, &pl)) return rc;
+    TFHE_LAUNCH((kg_ifft_batch<TIN, PACK>), dim3(pl.grid), dim3(GEN_BLOCK), pl.lds, c->stream, out_d, in_d,
+                (const double2 *)c->tw_d, batch, c->logn, pl.work);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+template <typename TOUT>
+int launch_gen_fft(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
+    GenFftPlan pl;
+    if (int rc = gen_fft_plan(c, kg_fft_batch<TOUT>, batch, &pl)) return rc;
+    TFHE_LAUNCH((kg_fft_batch<TOUT>), dim3(pl.grid), dim3(GEN_BLOCK), pl.lds, c->stream, out_d, in_d,
+                (const double2 *)c->tw_d, batch, c->logn, pl.work);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+// blind rotation: accumulator, digit and Fourier-accumulator areas in LDS while they fit (all three; else the two
+// transform areas; else none), the rest in a per-workgroup slice of global scratch
+template <typename T>
+int launch_br_gen(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
+    const size_t N = (size_t)c->p.N;
+    const size_t acc_b = sizeof(T) * 2 * N, dig_b = sizeof(double) * N, fac_b = sizeof(double) * 2 * N;
+    GenBrPlace g;
+    memset(&g, 0, sizeof(g));
+    g.logn = c->logn;
+    size_t lds = 0, glob = 0;
+    if (acc_b + dig_b + fac_b <= GEN_LDS_MAX) {
+        g.acc_lds = 0;
+        g.dig_lds = (long long)acc_b;
+        g.fac_lds = (long long)(acc_b + dig_b);
+        lds = acc_b + dig_b + fac_b;
+    } else if (dig_b + fac_b <= GEN_LDS_MAX) {
+        g.acc_lds = -1;
+        g.dig_lds = 0;
+        g.fac_lds = (long long)dig_b;
+        lds = dig_b + fac_b;
+        glob = acc_b;
+    } else {
+        g.acc_lds = g.dig_lds = g.fac_lds = -1;
+        glob = acc_b + dig_b + fac_b;
+    }
+    int block = (int)(N / 4);  // NC/2 butterflies per layer
+    block = block < 64 ? 64 : (block > GEN_BLOCK ? GEN_BLOCK : block);
+    auto kernel = kg_blind_rotate<T>;
+    if (int rc = set_lds(c, kernel, GEN_LDS_MAX)) return rc;
+    int grid = 0;
+    if (int rc = persistent_grid(c, kernel, block, lds, a.batch, &grid)) return rc;
+    if (glob) {
+        const long long cap = (long long)(GEN_WORK_MAX / glob);
+        if (grid > cap) grid = cap < 1 ? 1 : (int)cap;
+        if (int rc = grow(c, &c->ws_gen, &c->ws_gen_bytes, (size_t)grid * glob)) return rc;
+        g.work = (unsigned char *)c->ws_gen;
+        g.work_stride = (long long)glob;
+    }
+    TFHE_LAUNCH((kg_blind_rotate<T>), dim3(grid), dim3(block), lds, c->stream, a, g);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+
 void drop_streamed_graph(tfhe_amd_ctx *c) {
     if (c->sg.exec) (void)hipGraphExecDestroy((hipGraphExec_t)c->sg.exec);
     c->sg.exec = nullptr;
@@ -342,7 +442,9 @@ size_t torus_bytes(const tfhe_amd_ctx *c) { return (size_t)c->p.torus_bits / 8; 
 int pack_rows(tfhe_amd_ctx *c, double2 *dst_d, const double *src_d, long long rows) {
     const long long total = rows * (c->p.N / 2);
     const int blocks = (int)((total + 255) / 256);
-    if (c->logn == 10)
+    if (c->generic)
+        TFHE_LAUNCH_FLAT(kg_pack_gsw, dim3(blocks), dim3(256), c->stream, dst_d, src_d, rows, c->logn);
+    else if (c->logn == 10)
         TFHE_LAUNCH_FLAT((k_pack_gsw<10>), dim3(blocks), dim3(256), c->stream, dst_d, src_d, rows);
     else
         TFHE_LAUNCH_FLAT((k_pack_gsw<11>), dim3(blocks), dim3(256), c->stream, dst_d, src_d, rows);
@@ -420,6 +522,18 @@ int launch_exact_t(tfhe_amd_ctx *c, void *acc_d, const void *gsw_torus_d, int ba
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
+template <typename T>
+int launch_exact_gen(tfhe_amd_ctx *c, void *acc_d, const void *gsw_torus_d, int batch) {
+    const size_t N = (size_t)c->p.N;
+    const size_t lds = sizeof(int32_t) * 2 * c->p.l * N + sizeof(T) * 4 * N;  // digits, [g | -g], results
+    if (lds > GEN_LDS_MAX) return fail(c, TFHE_AMD_ERR_PARAM, "exact external product: the digits of this gadget do not fit the LDS");
+    auto kernel = kg_extprod_exact<T>;
+    if (int rc = set_lds(c, kernel, GEN_LDS_MAX)) return rc;
+    TFHE_LAUNCH((kg_extprod_exact<T>), dim3(batch), dim3(256), lds, c->stream, (T *)acc_d, (const T *)gsw_torus_d, c->gd, batch,
+                c->logn);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
 int launch_br(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) { return launch_br32(c, a); }
 int launch_br(tfhe_amd_ctx *c, const BlindRotateArgs<int64_t> &a) { return launch_br64(c, a); }
 
@@ -443,6 +557,8 @@ int cmux_t(tfhe_amd_ctx *c, void *out_d, const tfhe_amd_gsw *g, const int32_t *s
 //           level 0 reads the shared plaintext table, later levels the previous level's TLWE samples
 //   rotate: acc <- CMux(bit i, acc, X^{-2^i} acc), i < min(d, logN)  == a blind rotation whose "key" is
 //           the item's own TGSW samples and whose rotations are the constants 2N - 2^i; extraction fused
+constexpr int MAX_LOGN = 20;  // ring degrees 16 .. 2^20
+constexpr int VP_ROT_STRIDE = 32, VP_ROT_ROWS = MAX_LOGN + 1;
 template <typename T>
 int lut_eval_t(tfhe_amd_ctx *c, void *lwe_out_d, const tfhe_amd_gsw *bits, int d, const void *lut_d, int batch) {
     const int N = c->p.N, logn = c->logn;
@@ -450,9 +566,9 @@ int lut_eval_t(tfhe_amd_ctx *c, void *lwe_out_d, const tfhe_amd_gsw *bits, int d
     if (!c->vp_rot_d) {
         // row r = the rotations of an r-bit selection, (2N - 2^i)_{i<r}, then 0 in the slot the
         // test-vector initialisation reads as "barb"
-        int32_t rot[12 * 16] = {0};
+        int32_t rot[VP_ROT_ROWS * VP_ROT_STRIDE] = {0};
         for (int r = 0; r <= logn; r++)
-            for (int i = 0; i < r; i++) rot[r * 16 + i] = 2 * N - (1 << i);
+            for (int i = 0; i < r; i++) rot[r * VP_ROT_STRIDE + i] = 2 * N - (1 << i);
         HIPCHECK(c, hipMalloc((void **)&c->vp_rot_d, sizeof(rot)));
         HIPCHECK(c, hipMemcpyAsync(c->vp_rot_d, rot, sizeof(rot), hipMemcpyHostToDevice, c->stream));
         HIPCHECK(c, hipStreamSynchronize(c->stream));  // `rot` is a stack array
@@ -493,7 +609,7 @@ int lut_eval_t(tfhe_amd_ctx *c, void *lwe_out_d, const tfhe_amd_gsw *bits, int d
     a.gsw_sample_stride = (long long)bits->sample_complex;
     a.sel_div = 1;
     a.sel_mul = d;
-    a.rot = c->vp_rot_d + low * 16;
+    a.rot = c->vp_rot_d + low * VP_ROT_STRIDE;
     a.rot_stride = 0;
     a.lwe_out = (T *)lwe_out_d;
     a.flags = BR_EXTRACT;
@@ -547,7 +663,8 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     if (!p || !out) return TFHE_AMD_ERR_PARAM;
     *out = nullptr;
     if (p->k != 1) return TFHE_AMD_ERR_PARAM;
-    if (p->N != 1024 && p->N != 2048) return TFHE_AMD_ERR_PARAM;
+    // every ring degree the reference's plugin accepts (new_fft_table: a power of two >= 16, spqlios-fft-impl.cpp:157-160)
+    if (p->N < 16 || p->N > (1 << MAX_LOGN) || (p->N & (p->N - 1))) return TFHE_AMD_ERR_PARAM;
     if (p->torus_bits != 32 && p->torus_bits != 64) return TFHE_AMD_ERR_PARAM;
     if (p->l < 1 || p->l > 8 || p->Bgbit < 1 || p->l * p->Bgbit > p->torus_bits - 1) return TFHE_AMD_ERR_PARAM;
     if (p->n < 1) return TFHE_AMD_ERR_PARAM;
@@ -560,6 +677,9 @@ int tfhe_amd_ctx_create(const tfhe_amd_params *p, int device, tfhe_amd_ctx **out
     c->p = *p;
     c->device = device;
     c->logn = ilog2(p->N);
+    c->generic = p->N != 1024 && p->N != 2048;
+    c->ws_gen = nullptr;
+    c->ws_gen_bytes = 0;
     c->stream = nullptr;
     c->own = nullptr;
     c->tw_d = nullptr;
@@ -627,6 +747,7 @@ void tfhe_amd_ctx_destroy(tfhe_amd_ctx *c) {
     if (c->ksm_d) (void)hipFree(c->ksm_d);
     if (c->ws_lwe) (void)hipFree(c->ws_lwe);
     if (c->ws_acc) (void)hipFree(c->ws_acc);
+    if (c->ws_gen) (void)hipFree(c->ws_gen);
     if (c->vp_rot_d) (void)hipFree(c->vp_rot_d);
     if (c->hp_tw_d) (void)hipFree(c->hp_tw_d);
     if (c->probe_d) (void)hipFree(c->probe_d);
@@ -717,7 +838,7 @@ int tfhe_amd_event_destroy(tfhe_amd_ctx *c, void *event) {
 }
 
 int tfhe_amd_build_tables(int N, double *fft_trig, double *ifft_trig) {  // host only: no context, no device
-    if (N != 1024 && N != 2048) return TFHE_AMD_ERR_PARAM;
+    if (N < 16 || N > (1 << MAX_LOGN) || (N & (N - 1))) return TFHE_AMD_ERR_PARAM;
     std::vector<double> f, r;
     std::vector<double2> tw;
     if (!build_tables(N, f, r, tw)) return TFHE_AMD_ERR_PARAM;
@@ -867,7 +988,10 @@ int tfhe_amd_gsw_from_torus_d(tfhe_amd_ctx *c, const void *gsw_torus_d, int coun
     int rc = gsw_alloc(c, count, &g);
     if (rc) return rc;
     double *dst = reinterpret_cast<double *>(g->data_d);
-    if (c->p.torus_bits == 32)
+    if (c->generic)
+        rc = c->p.torus_bits == 32 ? launch_gen_ifft<int32_t, true>(c, dst, (const int32_t *)gsw_torus_d, (int)rows)
+                                   : launch_gen_ifft<int64_t, true>(c, dst, (const int64_t *)gsw_torus_d, (int)rows);
+    else if (c->p.torus_bits == 32)
         rc = c->logn == 10 ? launch_ifft_t<int32_t, 10, true>(c, dst, (const int32_t *)gsw_torus_d, (int)rows)
                            : launch_ifft_t<int32_t, 11, true>(c, dst, (const int32_t *)gsw_torus_d, (int)rows);
     else
@@ -913,13 +1037,22 @@ void tfhe_amd_gsw_free(tfhe_amd_gsw *g) {
 int tfhe_amd_gsw_export_fft(tfhe_amd_ctx *c, const tfhe_amd_gsw *g, int index, double *out) {
     if (!c || !g || !out || index < 0 || index >= g->count) return TFHE_AMD_ERR_PARAM;
     ENTER(c);
-    const int N = c->p.N, NC = N / 2, PPL = NC / 64;
+    const int N = c->p.N, NC = N / 2, PPL = NC >= 64 ? NC / 64 : 1;
     std::vector<double2> h(g->sample_complex);
     HIPCHECK(c, hipMemcpyAsync(h.data(), g->data_d + (size_t)index * g->sample_complex,
                                g->sample_complex * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     const double unscale = (double)N / 2.0;  // exact: power of two
     const int rows = 2 * c->p.l * 2;
+    if (c->generic) {  // [row][NC] complex in the reference's order
+        for (int r = 0; r < rows; r++)
+            for (int j = 0; j < NC; j++) {
+                const double2 v = h[(size_t)r * NC + j];
+                out[(size_t)r * N + j] = v.x * unscale;
+                out[(size_t)r * N + NC + j] = v.y * unscale;
+            }
+        return TFHE_AMD_OK;
+    }
     for (int r = 0; r < rows; r++)
         for (int m = 0; m < PPL; m++)
             for (int t = 0; t < 64; t++) {
@@ -1053,12 +1186,14 @@ int tfhe_amd_ifft_int32(tfhe_amd_ctx *c, double *out_d, const int32_t *in_d, int
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
     ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
+    if (c->generic) return launch_gen_ifft<int32_t, false>(c, out_d, in_d, batch);
     return c->logn == 10 ? launch_ifft_t<int32_t, 10>(c, out_d, in_d, batch) : launch_ifft_t<int32_t, 11>(c, out_d, in_d, batch);
 }
 int tfhe_amd_ifft_torus64(tfhe_amd_ctx *c, double *out_d, const int64_t *in_d, int batch) {
     if (!c || !out_d || !in_d || batch < 0) return TFHE_AMD_ERR_PARAM;
     ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
+    if (c->generic) return launch_gen_ifft<int64_t, false>(c, out_d, in_d, batch);
     return c->logn == 10 ? launch_ifft_t<int64_t, 10>(c, out_d, in_d, batch) : launch_ifft_t<int64_t, 11>(c, out_d, in_d, batch);
 }
 // k_fft_batch reads its input with 16-byte loads (tfhe_kernels.h): Lagrange-domain inputs must be 16-byte aligned
@@ -1068,6 +1203,7 @@ int tfhe_amd_fft_torus32(tfhe_amd_ctx *c, int32_t *out_d, const double *in_d, in
     ENTER(c);
     REQUIRE_ALIGNED16(c, in_d);
     if (batch == 0) return TFHE_AMD_OK;
+    if (c->generic) return launch_gen_fft<int32_t>(c, out_d, in_d, batch);
     return c->logn == 10 ? launch_fft_t<int32_t, 10>(c, out_d, in_d, batch) : launch_fft_t<int32_t, 11>(c, out_d, in_d, batch);
 }
 int tfhe_amd_fft_torus64(tfhe_amd_ctx *c, int64_t *out_d, const double *in_d, int batch) {
@@ -1075,6 +1211,7 @@ int tfhe_amd_fft_torus64(tfhe_amd_ctx *c, int64_t *out_d, const double *in_d, in
     ENTER(c);
     REQUIRE_ALIGNED16(c, in_d);
     if (batch == 0) return TFHE_AMD_OK;
+    if (c->generic) return launch_gen_fft<int64_t>(c, out_d, in_d, batch);
     return c->logn == 10 ? launch_fft_t<int64_t, 10>(c, out_d, in_d, batch) : launch_fft_t<int64_t, 11>(c, out_d, in_d, batch);
 }
 // the bare core transforms of spqlios-fft.h:52-53 (`ifft`, `fft`): N doubles -> N doubles, no conversion, no scale.
@@ -1090,6 +1227,7 @@ int tfhe_amd_ifft_f64(tfhe_amd_ctx *c, double *out_d, const double *in_d, int ba
     ENTER(c);
     REQUIRE(c, !ranges_overlap(out_d, in_d, (size_t)batch * c->p.N * sizeof(double)), "the transforms are out of place on the device: the two ranges overlap");
     if (batch == 0) return TFHE_AMD_OK;
+    if (c->generic) return launch_gen_ifft<double, false>(c, out_d, in_d, batch);
     return c->logn == 10 ? launch_ifft_t<double, 10>(c, out_d, in_d, batch) : launch_ifft_t<double, 11>(c, out_d, in_d, batch);
 }
 int tfhe_amd_fft_f64(tfhe_amd_ctx *c, double *out_d, const double *in_d, int batch) {
@@ -1098,6 +1236,7 @@ int tfhe_amd_fft_f64(tfhe_amd_ctx *c, double *out_d, const double *in_d, int bat
     REQUIRE_ALIGNED16(c, in_d);
     REQUIRE(c, !ranges_overlap(out_d, in_d, (size_t)batch * c->p.N * sizeof(double)), "the transforms are out of place on the device: the two ranges overlap");
     if (batch == 0) return TFHE_AMD_OK;
+    if (c->generic) return launch_gen_fft<double>(c, out_d, in_d, batch);
     return c->logn == 10 ? launch_fft_t<double, 10>(c, out_d, in_d, batch) : launch_fft_t<double, 11>(c, out_d, in_d, batch);
 }
 int tfhe_amd_lagrange_addmul(tfhe_amd_ctx *c, double *res_d, const double *a_d, const double *b_d, int batch, int b_shared) {
@@ -1402,7 +1541,9 @@ int tfhe_amd_modswitch(tfhe_amd_ctx *c, int32_t *out_d, const int32_t *x_d, int 
     if (batch == 0) return TFHE_AMD_OK;
     const long long total = (long long)batch * (c->p.n + 1);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (c->logn == 10)
+    if (c->generic)
+        TFHE_LAUNCH_FLAT(kg_modswitch, dim3(blocks), dim3(256), c->stream, out_d, x_d, total, c->logn);
+    else if (c->logn == 10)
         TFHE_LAUNCH_FLAT((k_modswitch<10>), dim3(blocks), dim3(256), c->stream, out_d, x_d, total);
     else
         TFHE_LAUNCH_FLAT((k_modswitch<11>), dim3(blocks), dim3(256), c->stream, out_d, x_d, total);
@@ -1415,6 +1556,9 @@ int tfhe_amd_extern_mul_exact(tfhe_amd_ctx *c, void *acc_d, const void *gsw_toru
     if (!c || !acc_d || !gsw_torus_d || batch < 0) return TFHE_AMD_ERR_PARAM;
     ENTER(c);
     if (batch == 0) return TFHE_AMD_OK;
+    if (c->generic)
+        return c->p.torus_bits == 32 ? launch_exact_gen<int32_t>(c, acc_d, gsw_torus_d, batch)
+                                     : launch_exact_gen<int64_t>(c, acc_d, gsw_torus_d, batch);
     if (c->p.torus_bits == 32)
         return c->logn == 10 ? launch_exact_t<int32_t, 10>(c, acc_d, gsw_torus_d, batch)
                              : launch_exact_t<int32_t, 11>(c, acc_d, gsw_torus_d, batch);
@@ -1424,6 +1568,7 @@ int tfhe_amd_extern_mul_exact(tfhe_amd_ctx *c, void *acc_d, const void *gsw_toru
 
 // ---- Real96 high-precision anticyclic transforms (high-precision-anticyclic-fft/src/code.cpp)
 static int hp_prepare(tfhe_amd_ctx *c) {
+    if (c->generic) return fail(c, TFHE_AMD_ERR_PARAM, "Real96 transforms: N = 1024 or 2048 (the reference's code.cpp is N = 2048 only)");
     if (c->hp_tw_d) return TFHE_AMD_OK;
     const int n = 2 * c->p.N;
     std::vector<uint64_t> tw((size_t)2 * n * 4);

@@ -82,6 +82,14 @@ struct PrecompView {
     void *buf;
 };
 
+// the reference's plugin object of ring degree N: its two global instances (fft_processor_spqlios.cpp:163-164), or a new
+// one -- FFT_Processor_Spqlios(N) is constructible for every power of two >= 16 (:18-25, spqlios-fft-impl.cpp:157-160)
+FFT_Processor_Spqlios &processor(int N) {
+    if (N == 1024) return fftp1024;
+    if (N == 2048) return fftp2048;
+    return *new FFT_Processor_Spqlios(N);  // lives as long as the process, like the globals
+}
+
 // A Globals object WITHOUT running Globals::Globals() (which would spend ~75 s generating
 // 2.7 GB of keys, poc:342-423): raw storage, fields filled by hand.
 Globals *bare_globals() {
@@ -144,7 +152,7 @@ int main(int argc, char **argv) {
     }
     if (op == "rev_int" || op == "rev_t32") {  // int32 -> Lagrange
         const int N = (int)arg(0);
-        FFT_Processor_Spqlios &P = (N == 1024) ? fftp1024 : fftp2048;
+        FFT_Processor_Spqlios &P = processor(N);
         auto in = slurp(inp);
         const size_t cnt = in.size() / 4 / N;
         std::vector<double> out(cnt * N);
@@ -157,7 +165,7 @@ int main(int argc, char **argv) {
     }
     if (op == "rev_t64") {  // int64 -> Lagrange
         const int N = (int)arg(0);
-        FFT_Processor_Spqlios &P = (N == 1024) ? fftp1024 : fftp2048;
+        FFT_Processor_Spqlios &P = processor(N);
         auto in = slurp(inp);
         const size_t cnt = in.size() / 8 / N;
         std::vector<double> out(cnt * N);
@@ -167,7 +175,7 @@ int main(int argc, char **argv) {
     }
     if (op == "dir_t32") {  // Lagrange -> Torus32.  ONE N per process (static _2sN, fft_processor_spqlios.cpp:78)
         const int N = (int)arg(0);
-        FFT_Processor_Spqlios &P = (N == 1024) ? fftp1024 : fftp2048;
+        FFT_Processor_Spqlios &P = processor(N);
         auto in = slurp(inp);
         const size_t cnt = in.size() / 8 / N;
         std::vector<int32_t> out(cnt * N);
@@ -177,7 +185,7 @@ int main(int argc, char **argv) {
     }
     if (op == "dir_t64") {  // Lagrange -> Torus64.  ONE N per process (static _2sN, :106)
         const int N = (int)arg(0);
-        FFT_Processor_Spqlios &P = (N == 1024) ? fftp1024 : fftp2048;
+        FFT_Processor_Spqlios &P = processor(N);
         auto in = slurp(inp);
         const size_t cnt = in.size() / 8 / N;
         std::vector<int64_t> out(cnt * N);
@@ -344,10 +352,13 @@ int main(int argc, char **argv) {
         // (decomposition tgsw_functions.cpp:224-337, rotation numeric_functions.cpp:304-347,
         // extraction tlwe_functions.cpp:351-363, mod switch numeric_functions.cpp:54-60, key switch
         // lwe_functions.cpp:136-171) is written here because those reference files do not compile.
-        //   boot32  args: n l Bgbit ks_t ks_bb count [first] ; in: [mu i32][pad i32][bkfft][ks][x rows] ; out: count*(n+1) i32
+        //   boot32  args: n l Bgbit ks_t ks_bb count [first [N]] ; in: [mu i32][pad i32][bkfft][ks][x rows] ; out: count*(n+1) i32
         //           (rows first .. first+count-1 of x: one input file serves several processes)
         //   bench32 args: n l Bgbit ks_t ks_bb seconds ; synthetic keys/samples; prints "<count> <seconds>"
-        const int N = 1024, n = (int)arg(0), l = (int)arg(1), Bgbit = (int)arg(2), t = (int)arg(3), bb = (int)arg(4);
+        const int n = (int)arg(0), l = (int)arg(1), Bgbit = (int)arg(2), t = (int)arg(3), bb = (int)arg(4);
+        const int N = arg(7) ? (int)arg(7) : 1024;  // boot32 only: ring degree (default 1024)
+        FFT_Processor_Spqlios &fftpN = processor(N);
+        const int logn = __builtin_ctz((unsigned)N);
         const int kpl = 2 * l, base = 1 << bb;
         const size_t bk_len = (size_t)n * kpl * 2 * N, ks_len = (size_t)N * t * base * (n + 1);
         std::vector<double> bk(bk_len);
@@ -379,7 +390,7 @@ int main(int argc, char **argv) {
             std::vector<int32_t> tor(N);
             for (size_t r = 0; r < bk_len / N; r++) {
                 for (int j = 0; j < N; j++) tor[j] = rng.next32();
-                fftp1024.execute_reverse_torus32(bk.data() + r * N, tor.data());
+                fftpN.execute_reverse_torus32(bk.data() + r * N, tor.data());
             }
             for (auto &v : ks) v = rng.next32();
             count = 1u << 20;  // upper bound; the time budget stops the loop
@@ -395,7 +406,7 @@ int main(int argc, char **argv) {
         std::vector<int32_t> acc(2 * N), tmp(2 * N), deca((size_t)kpl * N), u(N + 1),
             out((op == "boot32" ? count : 1) * (size_t)(n + 1));
         std::vector<double> decaF((size_t)kpl * N), tmpa(2 * N);
-        auto modsw = [&](int32_t ph) { return (int)((((uint64_t)(uint32_t)ph << 32) + (1ull << 52)) >> 53); };
+        auto modsw = [&](int32_t ph) { return (int)((((uint64_t)(uint32_t)ph << 32) + (1ull << (62 - logn))) >> (63 - logn)); };
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         size_t done = 0;
@@ -424,14 +435,14 @@ int main(int argc, char **argv) {
                         for (int j = 0; j < N; j++)
                             o[j] = (int32_t)((((uint32_t)tmp[q * N + j] + offset) >> decal) & mask) - halfBg;
                     }
-                for (int p = 0; p < kpl; p++) fftp1024.execute_reverse_int(decaF.data() + (size_t)p * N, deca.data() + (size_t)p * N);
+                for (int p = 0; p < kpl; p++) fftpN.execute_reverse_int(decaF.data() + (size_t)p * N, deca.data() + (size_t)p * N);
                 std::fill(tmpa.begin(), tmpa.end(), 0.0);
                 const double *row = bk.data() + (size_t)i * kpl * 2 * N;
                 for (int p = 0; p < kpl; p++)
                     for (int q = 0; q < 2; q++)
                         LagrangeHalfCPolynomialAddMulASM(tmpa.data() + q * N, decaF.data() + (size_t)p * N,
                                                          (double *)row + ((size_t)p * 2 + q) * N, N / 2);
-                for (int q = 0; q < 2; q++) fftp1024.execute_direct_torus32(tmp.data() + q * N, tmpa.data() + q * N);
+                for (int q = 0; q < 2; q++) fftpN.execute_direct_torus32(tmp.data() + q * N, tmpa.data() + q * N);
                 for (int j = 0; j < 2 * N; j++) acc[j] = (int32_t)((uint32_t)acc[j] + (uint32_t)tmp[j]);
             }
             u[0] = acc[0];

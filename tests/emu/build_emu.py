@@ -9,7 +9,7 @@ CSRC = os.path.join(ROOT, "experimental-tfhe_amd", "csrc")
 OUTDIR = os.path.join(HERE, "_build")
 SRCS = [os.path.join(CSRC, "tfhe_amd.hip"), os.path.join(CSRC, "keygen.cpp"), os.path.join(CSRC, "hp_twiddles.cpp"), os.path.join(CSRC, "pool.cpp"),
         os.path.join(HERE, "emu_runtime.cpp")]
-DEPS = SRCS + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "devport.h"),
+DEPS = SRCS + [os.path.join(CSRC, "tfhe_kernels.h"), os.path.join(CSRC, "tfhe_kernels_generic.h"), os.path.join(CSRC, "devport.h"),
                os.path.join(HERE, "emu_runtime.h"), os.path.join(ROOT, "include", "tfhe_amd.h")]
 
 

@@ -78,7 +78,32 @@ def cases(small):
     x = rs.randint(-2 ** 31, 2 ** 31, size=(rows, n + 1), dtype=np.int64).astype(np.int32)
     out.append(("boot32", "boot32", np.array([1 << 29, 0], np.int32).tobytes() + bk.tobytes() + ks.tobytes() + x.tobytes(),
                 (n, l, Bgbit, t, bb, rows, 0)))
+    # ring degrees the reference accepts but never instantiates: `new FFT_Processor_Spqlios(N)` / new_*_table(N) for any power
+    # of two >= 16 (fft_processor_spqlios.cpp:18-25, spqlios-fft-impl.cpp:157-160) -- the seam library must construct them too
+    rs = np.random.RandomState(20261004)
+    for N in RING_DEGREES:
+        c2 = 2
+        out.append((f"tables{N}", "tables", b"\0" * 8, (N,)))
+        out.append((f"rev_int{N}", "rev_int", rs.randint(-512, 512, size=(c2, N)).astype(np.int32).tobytes(), (N,)))
+        out.append((f"rev_t64_{N}", "rev_t64", rs.randint(-2 ** 63, 2 ** 63 - 1, size=(c2, N), dtype=np.int64).tobytes(), (N,)))
+        lag = rs.standard_normal((c2, N)) * 2.0 ** 40
+        out.append((f"dir_t32_{N}", "dir_t32", lag.tobytes(), (N,)))
+        out.append((f"dir_t64_{N}", "dir_t64", (lag * 2.0 ** 22).tobytes(), (N,)))
+        out.append((f"ifft{N}", "ifft", (rs.standard_normal((c2, N)) * 1e6).tobytes(), (N,)))
+        out.append((f"fft{N}", "fft", (rs.standard_normal((c2, N)) * 1e6).tobytes(), (N,)))
+        out.append((f"addmul{N}", "addmul", rs.standard_normal((c2, 3, N)).tobytes(), (N,)))
+    N, n, l, Bgbit, t, bb, rows = 512, 5, 2, 10, 3, 2, 2
+    tor = rs.randint(-2 ** 31, 2 ** 31, size=(n * 2 * l * 2, N), dtype=np.int64).astype(np.int32)
+    bk = O.ref("rev_t32", tor, np.float64, N)
+    ks = rs.randint(-2 ** 31, 2 ** 31, size=N * t * (1 << bb) * (n + 1), dtype=np.int64).astype(np.int32)
+    x = rs.randint(-2 ** 31, 2 ** 31, size=(rows, n + 1), dtype=np.int64).astype(np.int32)
+    out.append((f"boot32_{N}", "boot32", np.array([1 << 29, 0], np.int32).tobytes() + bk.tobytes() + ks.tobytes() + x.tobytes(),
+                (n, l, Bgbit, t, bb, rows, 0, N)))
     return out
+
+
+RING_DEGREES = (16, 512, 4096)
+N_CASES = 22 + 8 * len(RING_DEGREES) + 1
 
 
 def run_both(seam_exe, run_dir, small):
@@ -187,7 +212,7 @@ def test_unmodified_reference_objects_on_the_seam_library_gpu(gpu_lib):
     done = os.path.join(RUN_DIR, "done")
     assert os.path.exists(done), "the seam binaries did not run before the session's GPU tests"
     names = open(done).read().split()
-    assert "cbwoks" in names and "boot32" in names and len(names) == 22
+    assert "cbwoks" in names and "boot32" in names and "rev_int512" in names and "boot32_512" in names and len(names) == N_CASES
     compare(RUN_DIR, names)
 
 
