@@ -337,13 +337,16 @@ struct GenFftPlan {
     size_t lds;
     double *work;
 };
+bool gen_fft_in_lds(const tfhe_amd_ctx *c) {
+    return (size_t)(GEN_BLOCK / gen_team_size(c->p.N / 2)) * c->p.N * sizeof(double) <= GEN_LDS_MAX;
+}
 template <typename KernelT>
 int gen_fft_plan(tfhe_amd_ctx *c, KernelT kernel, int batch, GenFftPlan *pl) {
     const int N = c->p.N, teams = GEN_BLOCK / gen_team_size(N / 2);
     const size_t bytes = (size_t)teams * N * sizeof(double);
     const int needed = (batch + teams - 1) / teams;
     if (int rc = set_lds(c, kernel, GEN_LDS_MAX)) return rc;
-    if (bytes <= GEN_LDS_MAX) {
+    if (gen_fft_in_lds(c)) {
         pl->lds = bytes;
         pl->work = nullptr;
         return persistent_grid(c, kernel, GEN_BLOCK, bytes, needed, &pl->grid);
@@ -356,55 +359,72 @@ int gen_fft_plan(tfhe_amd_ctx *c, KernelT kernel, int batch, GenFftPlan *pl) {
     pl->work = (double *)c->ws_gen;
     return TFHE_AMD_OK;
 }
+template <typename TIN, bool PACK, bool LDS>
+int launch_gen_ifft_p(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
+    GenFftPlan pl;
+    if (int rc = gen_fft_plan(c, kg_ifft_batch<TIN, PACK, LDS>, batch, &pl)) return rc;
+    TFHE_LAUNCH((kg_ifft_batch<TIN, PACK, LDS>), dim3(pl.grid), dim3(GEN_BLOCK), pl.lds, c->stream, out_d, in_d,
+                (const double2 *)c->tw_d, batch, c->logn, pl.work);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
 template <typename TIN, bool PACK>
 int launch_gen_ifft(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
+    return gen_fft_in_lds(c) ? launch_gen_ifft_p<TIN, PACK, true>(c, out_d, in_d, batch) : launch_gen_ifft_p<TIN, PACK, false>(c, out_d, in_d, batch);
+}
+template <typename TOUT, bool LDS>
+int launch_gen_fft_p(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
     GenFftPlan pl;
-    if (int rc = gen_fft_plan(c, kg_ifft_batch<TIN, PACK>, batch, &pl)) return rc;
-    TFHE_LAUNCH((kg_ifft_batch<TIN, PACK>), dim3(pl.grid), dim3(GEN_BLOCK), pl.lds, c->stream, out_d, in_d,
+    if (int rc = gen_fft_plan(c, kg_fft_batch<TOUT, LDS>, batch, &pl)) return rc;
+    TFHE_LAUNCH((kg_fft_batch<TOUT, LDS>), dim3(pl.grid), dim3(GEN_BLOCK), pl.lds, c->stream, out_d, in_d,
                 (const double2 *)c->tw_d, batch, c->logn, pl.work);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
 template <typename TOUT>
 int launch_gen_fft(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
-    GenFftPlan pl;
-    if (int rc = gen_fft_plan(c, kg_fft_batch<TOUT>, batch, &pl)) return rc;
-    TFHE_LAUNCH((kg_fft_batch<TOUT>), dim3(pl.grid), dim3(GEN_BLOCK), pl.lds, c->stream, out_d, in_d,
-                (const double2 *)c->tw_d, batch, c->logn, pl.work);
-    HIPCHECK(c, hipGetLastError());
-    return TFHE_AMD_OK;
+    return gen_fft_in_lds(c) ? launch_gen_fft_p<TOUT, true>(c, out_d, in_d, batch) : launch_gen_fft_p<TOUT, false>(c, out_d, in_d, batch);
 }
 // blind rotation: accumulator, digit and Fourier-accumulator areas in LDS while they fit (all three; else the two
 // transform areas; else none), the rest in a per-workgroup slice of global scratch
 template <typename T>
 int launch_br_gen(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
     const size_t N = (size_t)c->p.N;
-    const size_t acc_b = sizeof(T) * 2 * N, dig_b = sizeof(double) * N, fac_b = sizeof(double) * 2 * N;
+    const size_t acc_b = sizeof(T) * 2 * N, dig1_b = sizeof(double) * N, fac_b = sizeof(double) * 2 * N;
     GenBrPlace g;
     memset(&g, 0, sizeof(g));
     g.logn = c->logn;
+    // digits transformed together (one barrier sequence for all of them): all 2l rows, else one polynomial's l, else one
+    const int nd_try[3] = {2 * c->p.l, c->p.l, 1};
     size_t lds = 0, glob = 0;
-    if (acc_b + dig_b + fac_b <= GEN_LDS_MAX) {
+    g.nd = 0;
+    for (int k = 0; k < 3 && !g.nd; k++)
+        if (acc_b + nd_try[k] * dig1_b + fac_b <= GEN_LDS_MAX) g.nd = nd_try[k];
+    if (g.nd) {
         g.acc_lds = 0;
         g.dig_lds = (long long)acc_b;
-        g.fac_lds = (long long)(acc_b + dig_b);
-        lds = acc_b + dig_b + fac_b;
-    } else if (dig_b + fac_b <= GEN_LDS_MAX) {
+        g.fac_lds = (long long)(acc_b + g.nd * dig1_b);
+        lds = acc_b + g.nd * dig1_b + fac_b;
+    } else if (dig1_b + fac_b <= GEN_LDS_MAX) {
+        g.nd = 1;
         g.acc_lds = -1;
         g.dig_lds = 0;
-        g.fac_lds = (long long)dig_b;
-        lds = dig_b + fac_b;
+        g.fac_lds = (long long)dig1_b;
+        lds = dig1_b + fac_b;
         glob = acc_b;
     } else {
+        g.nd = 2 * c->p.l;
         g.acc_lds = g.dig_lds = g.fac_lds = -1;
-        glob = acc_b + dig_b + fac_b;
+        glob = acc_b + g.nd * dig1_b + fac_b;
     }
     int block = (int)(N / 4);  // NC/2 butterflies per layer
     block = block < 64 ? 64 : (block > GEN_BLOCK ? GEN_BLOCK : block);
-    auto kernel = kg_blind_rotate<T>;
-    if (int rc = set_lds(c, kernel, GEN_LDS_MAX)) return rc;
+    const bool all_lds = glob == 0;
+    if (int rc = all_lds ? set_lds(c, kg_blind_rotate<T, true>, GEN_LDS_MAX) : set_lds(c, kg_blind_rotate<T, false>, GEN_LDS_MAX)) return rc;
     int grid = 0;
-    if (int rc = persistent_grid(c, kernel, block, lds, a.batch, &grid)) return rc;
+    if (int rc = all_lds ? persistent_grid(c, kg_blind_rotate<T, true>, block, lds, a.batch, &grid)
+                         : persistent_grid(c, kg_blind_rotate<T, false>, block, lds, a.batch, &grid))
+        return rc;
     if (glob) {
         const long long cap = (long long)(GEN_WORK_MAX / glob);
         if (grid > cap) grid = cap < 1 ? 1 : (int)cap;
@@ -412,7 +432,10 @@ int launch_br_gen(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
         g.work = (unsigned char *)c->ws_gen;
         g.work_stride = (long long)glob;
     }
-    TFHE_LAUNCH((kg_blind_rotate<T>), dim3(grid), dim3(block), lds, c->stream, a, g);
+    if (all_lds)
+        TFHE_LAUNCH((kg_blind_rotate<T, true>), dim3(grid), dim3(block), lds, c->stream, a, g);
+    else
+        TFHE_LAUNCH((kg_blind_rotate<T, false>), dim3(grid), dim3(block), lds, c->stream, a, g);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }

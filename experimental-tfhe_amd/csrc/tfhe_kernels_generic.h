@@ -61,43 +61,103 @@ TFHE_DEVICE void gen_fft_head4(double *re, double *im) {
 // are workgroup barriers), `active` = false for those whose team has no polynomial.  tw: the kernels' table
 // (tfhe_amd.hip build_tables: [0,NC) twist, half-size h at 2 NC - 2 h).  The caller has synchronised its writes; on
 // return every result is visible to the whole workgroup.
+// Barriers: the layers are the reference's radix-2 layers, node for node, but a work-item carries its points through
+// TWO layers (four points) between barriers, and through the last three (h = 4, size 4, size 2: eight consecutive points).
+struct GenC {
+    double r, i;
+};
+TFHE_DEVICE GenC gen_ld(const double *re, int NC, int j) { return GenC{re[j], re[NC + j]}; }
+TFHE_DEVICE void gen_st(double *re, int NC, int j, const GenC &v) {
+    re[j] = v.r;
+    re[NC + j] = v.i;
+}
 TFHE_DEVICE void gen_ifft(double *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active) {
-    // twist by omega^j (spqlios-ifft-fma.s:63-78) fused into the first layer (h = NC/2: its butterfly owns both points)
-    bool first = true;
-    for (int h = NC >> 1; h >= 4; h >>= 1) {
+    {  // layer h = NC/2 with the twist by omega^j (spqlios-ifft-fma.s:63-78) fused: its butterfly owns both points
+        const int h = NC >> 1;
         if (active) {
-            const double2 *ts = tw + (2 * NC - 2 * h);
-            for (int bf = lt; bf < (NC >> 1); bf += tpp) {
-                const int off = bf & (h - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + h;
-                const double2 w = ts[off];
-                double2 w1 = w, w2 = w;
-                if (first) {
-                    w1 = tw[i1];
-                    w2 = tw[i2];
-                }
+            const double2 *ts = tw + NC;  // 2 NC - 2 h
+            for (int bf = lt; bf < h; bf += tpp) {
+                const double2 w = ts[bf], w1 = tw[bf], w2 = tw[bf + h];
                 for (int p = 0; p < np; p++) {
-                    double *re = buf + p * pstride, *im = re + NC;
-                    double ar = re[i1], ai = im[i1], br = re[i2], bi = im[i2];
-                    if (first) {
-                        const double tr = __builtin_fma(-ai, w1.y, ar * w1.x), ti = __builtin_fma(ai, w1.x, ar * w1.y);
-                        const double ur = __builtin_fma(-bi, w2.y, br * w2.x), ui = __builtin_fma(bi, w2.x, br * w2.y);
-                        ar = tr;
-                        ai = ti;
-                        br = ur;
-                        bi = ui;
-                    }
-                    dif_bfly(ar, ai, br, bi, w.x, w.y);
-                    re[i1] = ar;
-                    im[i1] = ai;
-                    re[i2] = br;
-                    im[i2] = bi;
+                    double *re = buf + p * pstride;
+                    GenC a = gen_ld(re, NC, bf), b = gen_ld(re, NC, bf + h);
+                    const GenC ta{__builtin_fma(-a.i, w1.y, a.r * w1.x), __builtin_fma(a.i, w1.x, a.r * w1.y)};
+                    const GenC tb{__builtin_fma(-b.i, w2.y, b.r * w2.x), __builtin_fma(b.i, w2.x, b.r * w2.y)};
+                    a = ta;
+                    b = tb;
+                    dif_bfly(a.r, a.i, b.r, b.i, w.x, w.y);
+                    gen_st(re, NC, bf, a);
+                    gen_st(re, NC, bf + h, b);
                 }
             }
         }
-        first = false;
         __syncthreads();
     }
-    if (active) {
+    if (NC > 8) {
+        int h = NC >> 2, layers = 0;  // middle layers h = NC/4 .. 8
+        for (int t = h; t >= 8; t >>= 1) layers++;
+        if (layers & 1) {  // an odd one out: alone
+            if (active) {
+                const double2 *ts = tw + (2 * NC - 2 * h);
+                for (int bf = lt; bf < (NC >> 1); bf += tpp) {
+                    const int off = bf & (h - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + h;
+                    const double2 w = ts[off];
+                    for (int p = 0; p < np; p++) {
+                        double *re = buf + p * pstride;
+                        GenC a = gen_ld(re, NC, i1), b = gen_ld(re, NC, i2);
+                        dif_bfly(a.r, a.i, b.r, b.i, w.x, w.y);
+                        gen_st(re, NC, i1, a);
+                        gen_st(re, NC, i2, b);
+                    }
+                }
+            }
+            __syncthreads();
+            h >>= 1;
+        }
+        for (; h >= 16; h >>= 2) {  // layers h and h/2 on the four points base + {0, h/2, h, 3h/2}
+            if (active) {
+                const int hh = h >> 1;
+                const double2 *ta = tw + (2 * NC - 2 * h), *tb = tw + (2 * NC - h);
+                for (int q4 = lt; q4 < (NC >> 2); q4 += tpp) {
+                    const int off = q4 & (hh - 1), base = ((q4 - off) << 2) + off;
+                    const double2 wa0 = ta[off], wa1 = ta[off + hh], wb = tb[off];
+                    for (int p = 0; p < np; p++) {
+                        double *re = buf + p * pstride;
+                        GenC x0 = gen_ld(re, NC, base), x1 = gen_ld(re, NC, base + hh), x2 = gen_ld(re, NC, base + h),
+                             x3 = gen_ld(re, NC, base + h + hh);
+                        dif_bfly(x0.r, x0.i, x2.r, x2.i, wa0.x, wa0.y);
+                        dif_bfly(x1.r, x1.i, x3.r, x3.i, wa1.x, wa1.y);
+                        dif_bfly(x0.r, x0.i, x1.r, x1.i, wb.x, wb.y);
+                        dif_bfly(x2.r, x2.i, x3.r, x3.i, wb.x, wb.y);
+                        gen_st(re, NC, base, x0);
+                        gen_st(re, NC, base + hh, x1);
+                        gen_st(re, NC, base + h, x2);
+                        gen_st(re, NC, base + h + hh, x3);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // layer h = 4, then size 4 and size 2, on eight consecutive points
+        if (active) {
+            const double2 *t4 = tw + (2 * NC - 8);
+            const double2 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
+            for (int g = lt; g < (NC >> 3); g += tpp) {
+                for (int p = 0; p < np; p++) {
+                    double *re = buf + p * pstride + 8 * g, *im = re + NC;
+                    dif_bfly(re[0], im[0], re[4], im[4], w0.x, w0.y);
+                    dif_bfly(re[1], im[1], re[5], im[5], w1.x, w1.y);
+                    dif_bfly(re[2], im[2], re[6], im[6], w2.x, w2.y);
+                    dif_bfly(re[3], im[3], re[7], im[7], w3.x, w3.y);
+                    gen_ifft_tail4(re, im);
+                    gen_ifft_tail4(re + 4, im + 4);
+                }
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    if (active) {  // NC = 8: the fused first layer was h = 4
         for (int g = lt; g < (NC >> 2); g += tpp)
             for (int p = 0; p < np; p++) gen_ifft_tail4(buf + p * pstride + 4 * g, buf + p * pstride + NC + 4 * g);
     }
@@ -105,43 +165,95 @@ TFHE_DEVICE void gen_ifft(double *buf, int np, long pstride, int NC, const doubl
 }
 
 // Lagrange -> coefficient, in place (the caller has applied the 2/N scale); same calling rules as gen_ifft.
+// (the reference's fft table is the conjugate of its ifft table except cos at the quarter turn: flip_sign_if)
 TFHE_DEVICE void gen_fft(double *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active) {
-    if (active) {
-        for (int g = lt; g < (NC >> 2); g += tpp)
-            for (int p = 0; p < np; p++) gen_fft_head4(buf + p * pstride + 4 * g, buf + p * pstride + NC + 4 * g);
-    }
-    __syncthreads();
-    for (int h = 4; h <= (NC >> 1); h <<= 1) {
-        const bool last = h == (NC >> 1);
+    if (NC > 8) {
+        // size 2, size 4, then layer h = 4, on eight consecutive points
         if (active) {
-            const double2 *ts = tw + (2 * NC - 2 * h);
-            for (int bf = lt; bf < (NC >> 1); bf += tpp) {
-                const int off = bf & (h - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + h;
-                const double2 w = ts[off];
-                // the reference's fft table is the conjugate of its ifft table except cos at the quarter turn (flip_sign_if)
-                const double wc = flip_sign_if(w.x, off == (h >> 1));
-                double2 w1 = w, w2 = w;
-                if (last) {
-                    w1 = tw[i1];
-                    w2 = tw[i2];
-                }
+            const double2 *t4 = tw + (2 * NC - 8);
+            const double2 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
+            for (int g = lt; g < (NC >> 3); g += tpp) {
                 for (int p = 0; p < np; p++) {
-                    double *re = buf + p * pstride, *im = re + NC;
-                    double ar = re[i1], ai = im[i1], br = re[i2], bi = im[i2];
-                    dit_bfly(ar, ai, br, bi, wc, w.y);
-                    if (last) {
-                        // final twist by conj(omega^j), four rounded products (spqlios-fft-fma.s:255-274)
-                        const double arc = ar * w1.x, ars = ar * w1.y, aic = ai * w1.x, ais = ai * w1.y;
-                        const double brc = br * w2.x, brs = br * w2.y, bic = bi * w2.x, bis = bi * w2.y;
-                        ar = arc + ais;
-                        ai = aic - ars;
-                        br = brc + bis;
-                        bi = bic - brs;
+                    double *re = buf + p * pstride + 8 * g, *im = re + NC;
+                    gen_fft_head4(re, im);
+                    gen_fft_head4(re + 4, im + 4);
+                    dit_bfly(re[0], im[0], re[4], im[4], w0.x, w0.y);
+                    dit_bfly(re[1], im[1], re[5], im[5], w1.x, w1.y);
+                    dit_bfly(re[2], im[2], re[6], im[6], -w2.x, w2.y);  // quarter turn: off == h/2
+                    dit_bfly(re[3], im[3], re[7], im[7], w3.x, w3.y);
+                }
+            }
+        }
+        __syncthreads();
+        int layers = 0;  // middle layers h = 8 .. NC/4
+        for (int t = 8; t <= (NC >> 2); t <<= 1) layers++;
+        int h = 8;
+        for (int pr = 0; pr < (layers >> 1); pr++, h <<= 2) {  // layers h and 2h on the four points base + {0, h, 2h, 3h}
+            if (active) {
+                const int h2 = h << 1;
+                const double2 *ta = tw + (2 * NC - 2 * h), *tb = tw + (2 * NC - 2 * h2);
+                for (int q4 = lt; q4 < (NC >> 2); q4 += tpp) {
+                    const int off = q4 & (h - 1), base = ((q4 - off) << 2) + off;
+                    const double2 wa = ta[off], wb0 = tb[off], wb1 = tb[off + h];
+                    const double wac = flip_sign_if(wa.x, off == (h >> 1));
+                    const double wb1c = flip_sign_if(wb1.x, off == 0);  // off + h == h2 / 2
+                    for (int p = 0; p < np; p++) {
+                        double *re = buf + p * pstride;
+                        GenC x0 = gen_ld(re, NC, base), x1 = gen_ld(re, NC, base + h), x2 = gen_ld(re, NC, base + h2),
+                             x3 = gen_ld(re, NC, base + h2 + h);
+                        dit_bfly(x0.r, x0.i, x1.r, x1.i, wac, wa.y);
+                        dit_bfly(x2.r, x2.i, x3.r, x3.i, wac, wa.y);
+                        dit_bfly(x0.r, x0.i, x2.r, x2.i, wb0.x, wb0.y);
+                        dit_bfly(x1.r, x1.i, x3.r, x3.i, wb1c, wb1.y);
+                        gen_st(re, NC, base, x0);
+                        gen_st(re, NC, base + h, x1);
+                        gen_st(re, NC, base + h2, x2);
+                        gen_st(re, NC, base + h2 + h, x3);
                     }
-                    re[i1] = ar;
-                    im[i1] = ai;
-                    re[i2] = br;
-                    im[i2] = bi;
+                }
+            }
+            __syncthreads();
+        }
+        if (layers & 1) {  // the odd one out: h == NC/4
+            if (active) {
+                const double2 *ts = tw + (2 * NC - 2 * h);
+                for (int bf = lt; bf < (NC >> 1); bf += tpp) {
+                    const int off = bf & (h - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + h;
+                    const double2 w = ts[off];
+                    const double wc = flip_sign_if(w.x, off == (h >> 1));
+                    for (int p = 0; p < np; p++) {
+                        double *re = buf + p * pstride;
+                        GenC a = gen_ld(re, NC, i1), b = gen_ld(re, NC, i2);
+                        dit_bfly(a.r, a.i, b.r, b.i, wc, w.y);
+                        gen_st(re, NC, i1, a);
+                        gen_st(re, NC, i2, b);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
+        if (active) {
+            for (int g = lt; g < (NC >> 2); g += tpp)
+                for (int p = 0; p < np; p++) gen_fft_head4(buf + p * pstride + 4 * g, buf + p * pstride + NC + 4 * g);
+        }
+        __syncthreads();
+    }
+    {  // layer h = NC/2 with the final twist by conj(omega^j), four rounded products (spqlios-fft-fma.s:255-274)
+        const int h = NC >> 1;
+        if (active) {
+            const double2 *ts = tw + NC;
+            for (int bf = lt; bf < h; bf += tpp) {
+                const double2 w = ts[bf], w1 = tw[bf], w2 = tw[bf + h];
+                const double wc = flip_sign_if(w.x, bf == (h >> 1));
+                for (int p = 0; p < np; p++) {
+                    double *re = buf + p * pstride;
+                    GenC a = gen_ld(re, NC, bf), b = gen_ld(re, NC, bf + h);
+                    dit_bfly(a.r, a.i, b.r, b.i, wc, w.y);
+                    const double arc = a.r * w1.x, ars = a.r * w1.y, aic = a.i * w1.x, ais = a.i * w1.y;
+                    const double brc = b.r * w2.x, brs = b.r * w2.y, bic = b.i * w2.x, bis = b.i * w2.y;
+                    gen_st(re, NC, bf, GenC{arc + ais, aic - ars});
+                    gen_st(re, NC, bf + h, GenC{brc + bis, bic - brs});
                 }
             }
         }
@@ -156,8 +268,9 @@ constexpr int GEN_BLOCK = 256;
 // ------------------------------------------------------------ FFT plugin boundary, any N
 // execute_reverse_int / _torus32 / _torus64 and the bare `ifft` (TIN = double): coefficients -> LagrangeHalfC.
 // PACK: write the key layout of kg_blind_rotate instead ([row][NC] complex in reference order, scaled by 2/N).
-// work: the transform buffers -- null: dynamic LDS (teams x N doubles), else global scratch, one slice per workgroup.
-template <typename TIN, bool PACK>
+// LDS: the transform buffers are dynamic LDS (teams x N doubles; a template parameter so that the compiler addresses them
+// with DS instructions instead of flat ones), else slices of the global scratch `work`, one per workgroup.
+template <typename TIN, bool PACK, bool LDS>
 TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
     kg_ifft_batch(double *__restrict__ out, const TIN *__restrict__ in, const double2 *__restrict__ tw, int batch, int logn,
                   double *__restrict__ work) {
@@ -165,7 +278,7 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
     const int tpp = gen_team_size(NC), teams = GEN_BLOCK / tpp;
     const int team = (int)threadIdx.x / tpp, lt = (int)threadIdx.x - team * tpp;
     TFHE_DYN_LDS(smem);
-    double *buf = (work ? work + (size_t)blockIdx.x * teams * N : reinterpret_cast<double *>(smem)) + (size_t)team * N;
+    double *buf = (LDS ? reinterpret_cast<double *>(smem) : work + (size_t)blockIdx.x * teams * N) + (size_t)team * N;
     for (int b0 = (int)blockIdx.x * teams; b0 < batch; b0 += (int)gridDim.x * teams) {  // workgroup-uniform
         const int b = b0 + team;
         const bool active = b < batch;
@@ -194,7 +307,7 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
 
 // execute_direct_torus32 / _torus64 (scale 2/N, transform, round as fft_processor_spqlios.cpp:102,131-142) and the bare
 // `fft` (TOUT = double: no scale, no rounding)
-template <typename TOUT>
+template <typename TOUT, bool LDS>
 TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
     kg_fft_batch(TOUT *__restrict__ out, const double *__restrict__ in, const double2 *__restrict__ tw, int batch, int logn,
                  double *__restrict__ work) {
@@ -203,7 +316,7 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
     const int team = (int)threadIdx.x / tpp, lt = (int)threadIdx.x - team * tpp;
     constexpr bool RAW = std::is_same<TOUT, double>::value;
     TFHE_DYN_LDS(smem);
-    double *buf = (work ? work + (size_t)blockIdx.x * teams * N : reinterpret_cast<double *>(smem)) + (size_t)team * N;
+    double *buf = (LDS ? reinterpret_cast<double *>(smem) : work + (size_t)blockIdx.x * teams * N) + (size_t)team * N;
     const double scale = 2.0 / (double)N;  // fft_processor_spqlios.cpp:78
     for (int b0 = (int)blockIdx.x * teams; b0 < batch; b0 += (int)gridDim.x * teams) {
         const int b = b0 + team;
@@ -245,7 +358,7 @@ TFHE_GLOBAL void kg_modswitch(int32_t *__restrict__ out, const int32_t *__restri
 
 // ------------------------------------------------------------ blind rotation, any N
 // One workgroup per ciphertext (persistent: the grid walks the batch), every flag of k_blind_rotate honoured with the
-// same meaning.  Work areas: acc [2][N] torus, dig [N] doubles (one gadget digit at a time: extract, transform,
+// same meaning.  Work areas: acc [2][N] torus, dig [nd][N] doubles (nd gadget digits at a time: extract, transform,
 // multiply-accumulate, discard), fac [2][N] doubles (the Fourier accumulator of tLweFFTClear / tLweFFTAddMulRTo).
 // Each of the three is in dynamic LDS when its offset is >= 0, else in the workgroup's slice of `work`.
 struct GenBrPlace {
@@ -253,26 +366,37 @@ struct GenBrPlace {
     long long work_stride;                // bytes of global scratch per workgroup
     unsigned char *work;
     int logn;
+    int nd;  // gadget digits transformed together: 2l, l or 1 (dig holds nd polynomials)
 };
 
-template <typename T>
+// ALL_LDS: the three areas are dynamic LDS at the offsets of G (compile-time knowledge: DS instructions, not flat ones)
+template <typename T, bool ALL_LDS>
 TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T> A, GenBrPlace G) {
     using U = typename Torus<T>::U;
     constexpr int BITS = Torus<T>::BITS;
     const int logn = G.logn, N = 1 << logn, NC = N >> 1;
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
     TFHE_DYN_LDS(smem);
-    unsigned char *wsl = G.work ? G.work + (size_t)blockIdx.x * (size_t)G.work_stride : nullptr;
-    size_t woff = 0;
-    auto place = [&](long long lds_off, size_t bytes) -> unsigned char * {
-        if (lds_off >= 0) return smem + lds_off;
-        unsigned char *p = wsl + woff;
-        woff += bytes;
-        return p;
-    };
-    T *acc = reinterpret_cast<T *>(place(G.acc_lds, sizeof(T) * 2 * (size_t)N));
-    double *dig = reinterpret_cast<double *>(place(G.dig_lds, sizeof(double) * (size_t)N));
-    double *fac = reinterpret_cast<double *>(place(G.fac_lds, sizeof(double) * 2 * (size_t)N));
+    const int nd = G.nd;
+    T *acc;
+    double *dig, *fac;
+    if constexpr (ALL_LDS) {
+        acc = reinterpret_cast<T *>(smem);
+        dig = reinterpret_cast<double *>(smem + sizeof(T) * 2 * (size_t)N);
+        fac = dig + (size_t)nd * N;
+    } else {
+        unsigned char *wsl = G.work ? G.work + (size_t)blockIdx.x * (size_t)G.work_stride : nullptr;
+        size_t woff = 0;
+        auto place = [&](long long lds_off, size_t bytes) -> unsigned char * {
+            if (lds_off >= 0) return smem + lds_off;
+            unsigned char *p = wsl + woff;
+            woff += bytes;
+            return p;
+        };
+        acc = reinterpret_cast<T *>(place(G.acc_lds, sizeof(T) * 2 * (size_t)N));
+        dig = reinterpret_cast<double *>(place(G.dig_lds, sizeof(double) * (size_t)nd * N));
+        fac = reinterpret_cast<double *>(place(G.fac_lds, sizeof(double) * 2 * (size_t)N));
+    }
     const U offset = (U)A.gd.offset;
     const int Bgbit = A.gd.Bgbit, l = A.gd.l;
     const U mask = ((U)1 << Bgbit) - 1;
@@ -330,10 +454,13 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
                 if (a == 0) continue;  // :348-350 (workgroup-uniform)
             }
             const double2 *bkrow = bk0 + (size_t)i * A.bk_step_stride;
-            for (int j = tid; j < 2 * N; j += nt) fac[j] = 0.0;  // tLweFFTClear (tgsw_functions.cpp:438)
-            for (int q = 0; q < 2; q++) {
-                const T *pa = acc + q * N;
-                for (int d = 0; d < l; d++) {
+            // rows p = q*l + d (tgsw_functions.cpp:435-443) in groups of nd: extract, transform together, multiply-accumulate
+            // in row order (the chain of lagrangehalfc_impl_fma.s:96-107 is sequential in p for every point)
+            for (int p0 = 0; p0 < 2 * l; p0 += nd) {
+                for (int e = 0; e < nd; e++) {
+                    const int q = (p0 + e) / l, d = (p0 + e) - q * l;
+                    const T *pa = acc + q * N;
+                    double *dg = dig + (size_t)e * N;
                     const int decal = BITS - (d + 1) * Bgbit;
                     // digit d of polynomial q of (X^a - 1) * acc (numeric_functions.cpp:304-323), or of acc itself;
                     // decomposition tgsw_functions.cpp:224-337 / poc:492-515 (offset from the host)
@@ -344,28 +471,41 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
                             const U src = (U)pa[idx & (N - 1)];
                             v = ((idx & N) ? (U)(0 - src) : src) - v;
                         }
-                        dig[j] = (double)((int32_t)(((U)(v + offset) >> decal) & mask) - halfBg);
+                        dg[j] = (double)((int32_t)(((U)(v + offset) >> decal) & mask) - halfBg);
                     }
-                    __syncthreads();
-                    gen_ifft(dig, 1, 0, NC, A.tw, tid, nt, true);
-                    // tLweFFTAddMulRTo (tlwe_functions.cpp:318-325): row p = q*l + d, both output polynomials;
-                    // the chain of lagrangehalfc_impl_fma.s:96-107 on an accumulator that started as +0
-                    const double2 *row = bkrow + (size_t)(q * l + d) * 2 * NC;
-                    for (int j = tid; j < NC; j += nt) {
-                        const double ar = dig[j], ai = dig[NC + j];
-                        for (int q2 = 0; q2 < 2; q2++) {
-                            const double2 b = row[(size_t)q2 * NC + j];
-                            double *fr = fac + q2 * N + j, *fi = fr + NC;
-                            const double tneg = __builtin_fma(ai, b.y, -*fr);
-                            *fr = __builtin_fma(ar, b.x, -tneg);
-                            const double u = __builtin_fma(ar, b.y, *fi);
-                            *fi = __builtin_fma(ai, b.x, u);
-                        }
-                    }
-                    __syncthreads();  // the next digit's fill overwrites dig (not always from the work-item that read it: N < 2 x block)
                 }
+                __syncthreads();
+                gen_ifft(dig, nd, N, NC, A.tw, tid, nt, true);
+                // tLweFFTAddMulRTo (tlwe_functions.cpp:318-325), both output polynomials, on an accumulator that starts as
+                // the +0 of tLweFFTClear (tgsw_functions.cpp:438)
+                for (int j = tid; j < NC; j += nt) {
+                    double fr0 = 0.0, fi0 = 0.0, fr1 = 0.0, fi1 = 0.0;
+                    if (p0) {
+                        fr0 = fac[j];
+                        fi0 = fac[NC + j];
+                        fr1 = fac[N + j];
+                        fi1 = fac[N + NC + j];
+                    }
+                    for (int e = 0; e < nd; e++) {
+                        const double ar = dig[(size_t)e * N + j], ai = dig[(size_t)e * N + NC + j];
+                        const double2 *row = bkrow + (size_t)(p0 + e) * 2 * NC;
+                        const double2 b0 = row[j], b1 = row[NC + j];
+                        const double t0 = __builtin_fma(ai, b0.y, -fr0);
+                        fr0 = __builtin_fma(ar, b0.x, -t0);
+                        const double u0 = __builtin_fma(ar, b0.y, fi0);
+                        fi0 = __builtin_fma(ai, b0.x, u0);
+                        const double t1 = __builtin_fma(ai, b1.y, -fr1);
+                        fr1 = __builtin_fma(ar, b1.x, -t1);
+                        const double u1 = __builtin_fma(ar, b1.y, fi1);
+                        fi1 = __builtin_fma(ai, b1.x, u1);
+                    }
+                    fac[j] = fr0;
+                    fac[NC + j] = fi0;
+                    fac[N + j] = fr1;
+                    fac[N + NC + j] = fi1;
+                }
+                __syncthreads();  // the next group's fill overwrites dig (not always from the work-item that read it: N < 2 x block)
             }
-            __syncthreads();
             // tLweFromFFTConvert (key rows carry the 2/N scale) + tLweAddTo
             gen_fft(fac, 2, N, NC, A.tw, tid, nt, true);
             for (int j = tid; j < 2 * N; j += nt) {

@@ -49,8 +49,12 @@ enum {
 
 /* Parameters of one bootstrapping level.  Reference: LweParams/TLweParams/TGswParams
  * (CB/lwe_functions.cpp:17, CB/tgsw_functions.cpp:15-38) and the PoC's Globals
- * (CB/poc_types.h:267-283).  Supported: N in {1024, 2048}, k = 1, l in [1,8],
- * l*Bgbit <= torus_bits - 1, torus_bits in {32, 64}. */
+ * (CB/poc_types.h:267-283).  Supported: N = every power of two from 16 to 2^20 -- what the reference's plugin accepts
+ * (new_fft_table / FFT_Processor_Spqlios(N): a power of two >= 16, CB/spqlios/spqlios-fft-impl.cpp:157-160,
+ * fft_processor_spqlios.cpp:18-25); 1024 and 2048, the two the reference instantiates, run the wave-per-polynomial
+ * kernels, every other degree the team-per-polynomial kernels of csrc/tfhe_kernels_generic.h (same bits, several
+ * times slower per flop: profiles/r06_generic_n.txt).  k = 1, l in [1,8], l*Bgbit <= torus_bits - 1,
+ * torus_bits in {32, 64}.  (Real96 transforms, tfhe_amd_hp_*: N in {1024, 2048} only.) */
 typedef struct tfhe_amd_params {
     int32_t torus_bits; /* 32: Torus32 accumulator (gate bootstrap); 64: Torus64 (circuit bootstrap lvl2) */
     int32_t n;          /* LWE dimension = number of CMux steps of a blind rotation */
@@ -117,7 +121,7 @@ int tfhe_amd_event_destroy(tfhe_amd_ctx *ctx, void *event);
 /* twiddle tables as the reference lays them out (new_fft_table / new_ifft_table,
  * CB/spqlios/spqlios-fft-impl.cpp:158-193,400-437): 2N-8 doubles each; for SHA pinning. */
 int tfhe_amd_get_tables(const tfhe_amd_ctx *ctx, double *fft_trig, double *ifft_trig);
-/* the same two tables without a context or a device (host libm only), N in {1024, 2048}; either pointer may be NULL */
+/* the same two tables without a context or a device (host libm only), N a power of two in [16, 2^20]; either pointer may be NULL */
 int tfhe_amd_build_tables(int N, double *fft_trig, double *ifft_trig);
 
 /* device memory helpers so a host language needs no HIP binding of its own */

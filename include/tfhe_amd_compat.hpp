@@ -707,7 +707,7 @@ inline void tfhe_MuxRotate_FFT(TLweSample *result, const TLweSample *accum, cons
     get_tlwe(R, result, R.d_in, R.N);
 }
 // lweKeySwitch(result, ks, sample): a key-switch key seen on its own gets its own resident engine
-// (input dimension ks->n must be a ring degree the engine supports: 1024 or 2048)
+// (input dimension ks->n must be a ring degree the engine supports: a power of two in [16, 2^20])
 inline Resident &attach_ks(const LweKeySwitchKey *ks) {
     auto &reg = registry();
     const ResidentKey key{(const void *)ks, (const void *)ks, ks->out_params->n, ks->n, 0, 0};

@@ -72,7 +72,7 @@ def test_version_and_params_struct(hip_lib):
 
 def test_bad_parameters_rejected(hip_lib):
     ctx = C.c_void_p()
-    for bad in (dict(k=2), dict(N=512), dict(torus_bits=16), dict(l=0), dict(l=4, Bgbit=10), dict(n=0)):
+    for bad in (dict(k=2), dict(N=8), dict(N=1000), dict(N=1 << 21), dict(torus_bits=16), dict(l=0), dict(l=4, Bgbit=10), dict(n=0)):
         kw = dict(torus_bits=32, n=630, N=1024, k=1, l=2, Bgbit=10, ks_t=8, ks_basebit=2, ks_n_out=630)
         kw.update(bad)
         p = T.Params(*[kw[f[0]] for f in T.Params._fields_])
