@@ -125,6 +125,16 @@ template <typename V>
 __device__ __forceinline__ V tfhe_nontemporal_load(const V *p) { return __builtin_nontemporal_load(p); }
 template <typename V>
 __device__ __forceinline__ void tfhe_nontemporal_store(V v, V *p) { __builtin_nontemporal_store(v, p); }
+// 32-bit load / store through a pointer KNOWN to be global memory (a generic pointer compiles to flat_* instructions, which
+// count against the LDS wait counter too)
+__device__ __forceinline__ uint32_t tfhe_global_load32(const void *p, int idx) {
+    typedef __attribute__((address_space(1))) const uint32_t glob_u32;
+    return ((glob_u32 *)(uintptr_t)p)[idx];
+}
+__device__ __forceinline__ void tfhe_global_store32(void *p, int idx, uint32_t v) {
+    typedef __attribute__((address_space(1))) uint32_t glob_u32;
+    ((glob_u32 *)(uintptr_t)p)[idx] = v;
+}
 #define TFHE_TRAP() __builtin_trap()
 // counters of the clock probe: shader cycles (s_memtime), the constant 100 MHz reference (s_memrealtime); a short sleep
 #define TFHE_SHADER_CYCLES() __builtin_amdgcn_s_memtime()

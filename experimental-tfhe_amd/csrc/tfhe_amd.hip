@@ -211,6 +211,22 @@ int launch_br_t(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
 }
+// one CMux step in place in global memory, two workgroups per CU (tfhe_kernels.h k_cmux_stream)
+template <int LC, int BGC>
+int launch_cmux_stream(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
+    static_assert(StreamLds::total <= 80 * 1024, "two workgroups per CU");
+    auto kernel = k_cmux_stream<LC, BGC>;
+    if (int rc = set_lds(c, kernel, StreamLds::total)) return rc;
+    int grid = 0;
+    if (int rc = persistent_grid(c, kernel, 256, StreamLds::total, (a.batch + 3) / 4, &grid)) return rc;
+    TFHE_LAUNCH((k_cmux_stream<LC, BGC>), dim3(grid), dim3(256), StreamLds::total, c->stream, a);
+    HIPCHECK(c, hipGetLastError());
+    return TFHE_AMD_OK;
+}
+bool cmux_stream_applies(const tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
+    return c->logn == 10 && c->p.l == 2 && a.n_steps == 1 && (a.flags & ~(uint32_t)BR_MODSWITCH) == 0 && !a.gsw_sel && a.sel_div <= 0 &&
+           a.acc_io && a.rot;
+}
 // latency-shaped kernel (one ciphertext per 4-wave workgroup, tfhe_kernels.h k_blind_rotate_split): gate gadget
 // length, N = 1024, plain blind rotations only
 template <int BGC>
@@ -255,6 +271,14 @@ int launch_br32(tfhe_amd_ctx *c, const BlindRotateArgs<int32_t> &a) {
         if (c->p.l == 2) return launch_br_t<int32_t, 10, 4, 2, 2>(c, a);
         return launch_br_t<int32_t, 10, 4, 2>(c, a);
     }
+#ifndef TFHE_NO_CMUX_STREAM
+    // the one-launch-per-CMux schedule (tfhe_amd_bootstrap_streamed, tfhe_amd_mux_rotate): accumulators in place in global memory
+    if (cmux_stream_applies(c, a)) {
+        if (c->p.Bgbit == 10) return launch_cmux_stream<2, 10>(c, a);
+        if (c->p.Bgbit == 8) return launch_cmux_stream<2, 8>(c, a);
+        return launch_cmux_stream<2, 0>(c, a);
+    }
+#endif
     if (c->p.l == 2 && c->p.Bgbit == 10) return launch_br_t<int32_t, 10, 8, 2, 2, 10>(c, a);
     if (c->p.l == 2 && c->p.Bgbit == 8) return launch_br_t<int32_t, 10, 8, 2, 2, 8>(c, a);
     if (c->p.l == 2) return launch_br_t<int32_t, 10, 8, 2, 2>(c, a);

@@ -747,6 +747,34 @@ TFHE_DEVICE void rotated_minus_one(const WaveLds<T, LOGN> &w, int q, int a, type
     }
 }
 
+// The same straight from GLOBAL memory (Torus32; k_cmux_stream: the accumulator is never staged in LDS).  For a fixed
+// register index the 64 lanes read 64 consecutive coefficients (rotated: consecutive modulo N), so every load instruction
+// is one or two contiguous runs -- as coalesced as the copy into LDS it replaces.
+template <int LOGN>
+TFHE_DEVICE void rotated_minus_one_g(const int32_t *p, int a, uint32_t offset, uint32_t flip, uint32_t (&lo)[Geom<LOGN>::PPL],
+                                     uint32_t (&hi)[Geom<LOGN>::PPL], int t) {
+    using G = Geom<LOGN>;
+    constexpr int PPL = G::PPL, N = G::N, NC = G::NC;
+    const int base = (t - a) & (2 * N - 1);
+    uint32_t src[2 * PPL], own[2 * PPL];
+#pragma unroll
+    for (int e = 0; e < 2 * PPL; e++) {  // every load is issued before the first use
+        const int K = 64 * (e >> 1) + (e & 1) * NC;
+        src[e] = tfhe_global_load32(p, (base + K) & (N - 1));
+        own[e] = tfhe_global_load32(p, t + K);
+    }
+#pragma unroll
+    for (int e = 0; e < 2 * PPL; e++) {
+        const int K = 64 * (e >> 1) + (e & 1) * NC;
+        const uint32_t s = ((base + K) & N) ? 0xFFFFFFFFu : 0u;
+        const uint32_t v = ((((src[e] ^ s) - s) - own[e]) + offset) ^ flip;
+        if (e & 1)
+            hi[e >> 1] = v;
+        else
+            lo[e >> 1] = v;
+    }
+}
+
 // The same for an accumulator held in registers (BlindRotateLds::ACCREG): own[h][m] = coefficient
 // t + 64m + h*N/2 of the polynomial.  The polynomial is written to the wave's LDS scratch (which the
 // transposes reuse afterwards: the wave's DS operations execute in order), the rotated source is read back.
@@ -797,7 +825,9 @@ TFHE_DEVICE void rotated_minus_one_reg(const WaveLds<T, LOGN> &w, const typename
 // groups are unrolled: no loop-carried Fourier accumulator (its zero-initialisation disappears into the
 // first multiply), key-row addresses become immediates.
 // ACCREG: the accumulator is accr[q][h][m] (registers) instead of w.acc (LDS); see BlindRotateLds.
-template <typename T, int LOGN, int PAIR, int LC = 0, int BGC = 0, bool CPLX = false, bool KEEP_ROT = false, bool ACCREG = false>
+// ACCGLOBAL: w.acc points into GLOBAL memory (the caller's accumulator array, updated in place): see k_cmux_stream.
+template <typename T, int LOGN, int PAIR, int LC = 0, int BGC = 0, bool CPLX = false, bool KEEP_ROT = false, bool ACCREG = false,
+          bool ACCGLOBAL = false>
 TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict__ bkrow, int a, bool rotate,
                            const Gadget &gd, int t, typename Torus<T>::U (&accr)[2][2][ACCREG ? Geom<LOGN>::PPL : 1]) {
     using G = Geom<LOGN>;
@@ -830,6 +860,8 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
                     hi[m] = (accr[q][1][m] + offset) ^ flip;
                 }
             }
+        } else if (ACCGLOBAL && rotate) {
+            if constexpr (ACCGLOBAL) rotated_minus_one_g<LOGN>(w.acc + qq * N, a, (uint32_t)offset, (uint32_t)flip, lo, hi, t);
         } else if (rotate) {
             rotated_minus_one<T, LOGN>(w, qq, a, offset, flip, lo, hi, t);
         } else {
@@ -949,6 +981,34 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
                     accr[q][1][m] = r1[q][m];
                 }
         }
+        return;
+    }
+    if constexpr (ACCGLOBAL) {  // acc (+)= result in place in global memory: every lane owns its coefficients
+        uint32_t old0[2][PPL], old1[2][PPL];
+        if (rotate) {
+            TFHE_KEEP_BRANCH();
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int m = 0; m < PPL; m++) {
+                    old0[q][m] = tfhe_global_load32(w.acc + q * N, G::jA(t, m));
+                    old1[q][m] = tfhe_global_load32(w.acc + q * N, G::jA(t, m) + NC);
+                }
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int m = 0; m < PPL; m++) {
+                    r0[q][m] += old0[q][m];
+                    r1[q][m] += old1[q][m];
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int m = 0; m < PPL; m++) {
+                tfhe_global_store32(w.acc + q * N, G::jA(t, m), (uint32_t)r0[q][m]);
+                tfhe_global_store32(w.acc + q * N, G::jA(t, m) + NC, (uint32_t)r1[q][m]);
+            }
         return;
     }
     // (the wave-uniform `rotate` test sits outside the unrolled loops: inside them hipcc keeps one
@@ -1229,6 +1289,59 @@ TFHE_GLOBAL void __launch_bounds__(WAVES * 64) k_blind_rotate(BlindRotateArgs<T>
 #undef ACC_SET
 #undef ACC_GET
     TFHE_PROBE_KERNEL_END(t);
+}
+
+// ------------------------------------------- one CMux step per launch, accumulators in place in global memory
+// BASELINE config 2 as worded ("one external-product kernel per CMux"; tfhe_amd_bootstrap_streamed): acc_io[ct] <- CMux step.
+// k_blind_rotate copies the 8 KB accumulator into LDS, computes, copies it back -- three phases that the single 8-wave
+// workgroup of a CU walks in lockstep, so the chip alternates between an HBM-bound and a compute-bound state (36.6 against
+// 25.7 us per CMux inside the persistent kernel, round 5).  Here the rotated coefficients are read straight from global memory
+// (coalesced: rotated_minus_one_g) and the result is added in place, so a wave needs no accumulator in LDS: 16 KB of twiddles +
+// 4 x 9 KB of transposes = 53 KB per 4-wave workgroup, two workgroups per CU, their memory phases under each other's arithmetic.
+// Torus32, N = 1024, gate gadget length; flags: BR_MODSWITCH only.  Round 6, MI355X, batch 4096 (profiles/r06_streamed_ab.txt):
+// 36.8 -> 34.6 us per launch, 0.228 -> 0.242 of 8 TB/s on the contract bytes, bit-identical.  (Tried beside it and dropped:
+// k_blind_rotate in 4-wave workgroups of 67 KB with 8-byte transposes, two per CU: 39.6 us; touching the wave's next
+// accumulator into L2 a CMux ahead: 35.0 us; one ciphertext per wave without the persistent loop: the same 34.6.)
+struct StreamLds {
+    using G = Geom<10>;
+    static constexpr int WAVES = 4;
+    static constexpr size_t tw_bytes = sizeof(double2) * G::TW;
+    static constexpr size_t xch_bytes = sizeof(double2) * G::XCH;
+    static constexpr size_t total = tw_bytes + WAVES * xch_bytes;
+};
+template <int LC, int BGC>
+TFHE_GLOBAL void __launch_bounds__(256, 2) k_cmux_stream(BlindRotateArgs<int32_t> A) {
+    using G = Geom<10>;
+    using L = StreamLds;
+    TFHE_DYN_LDS(smem);
+    {
+        double2 *tw = reinterpret_cast<double2 *>(smem);
+        for (int i = threadIdx.x; i < G::TW; i += 256) tw[i] = A.tw[i];
+        __syncthreads();
+    }
+    const int wave = TFHE_UNIFORM((int)(threadIdx.x >> 6));
+    const int t = threadIdx.x & 63;
+    WaveLds<int32_t, 10> w;
+    w.smem = smem;
+    w.acc_lds = 0;
+    w.xch = WaveFFT<10>::make_xch(reinterpret_cast<double *>(smem + L::tw_bytes + (size_t)wave * L::xch_bytes), t);
+    w.tw.tw = reinterpret_cast<const double2 *>(smem);
+    w.tw.t = t;
+    w.tw.load_uniform(A.tw);
+    w.progress_lds = 0;
+    w.self = w.partner = wave;
+    uint32_t none[2][2][1];
+    // persistent waves: the grid is what the chip holds (two workgroups per CU); a wave walks its ciphertexts
+    const int stride = TFHE_UNIFORM((int)(gridDim.x * L::WAVES));
+#pragma unroll 1
+    for (int ct = TFHE_UNIFORM((int)(blockIdx.x * L::WAVES) + wave); ct < A.batch; ct += stride) {
+        int a = tfhe_uniform_load32(A.rot + (size_t)ct * A.rot_stride, 0);
+        if (A.flags & BR_MODSWITCH) a = modswitch_2N<10>(a);
+        a = TFHE_UNIFORM(a);
+        if (a == 0) continue;  // lwe_functions.cpp:348-350
+        w.acc = A.acc_io + (size_t)ct * 2 * G::N;  // GLOBAL memory
+        cmux_step<int32_t, 10, 2, LC, BGC, true, false, false, true>(w, A.bk, a, true, A.gd, t, none);
+    }
 }
 
 // ------------------------------------------- latency-shaped blind rotation (small batches)

@@ -81,6 +81,8 @@ template <typename V>
 static inline V tfhe_nontemporal_load(const V *p) { return *p; }
 template <typename V>
 static inline void tfhe_nontemporal_store(V v, V *p) { *p = v; }
+static inline uint32_t tfhe_global_load32(const void *p, int idx) { return ((const uint32_t *)p)[idx]; }
+static inline void tfhe_global_store32(void *p, int idx, uint32_t v) { ((uint32_t *)p)[idx] = v; }
 #define TFHE_TRAP() abort()
 // clock probe: the reference counter is the wall clock at 100 MHz, the "shader" counter 24 cycles per tick (a nominal 2.4 GHz)
 unsigned long long emu_ref_ticks();
