@@ -656,27 +656,6 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
     if constexpr (HALFROW) {
         static_assert(!HALFROW || ND == 1, "half-row form: one digit at a time");
         mac_half_row<PPL, FIRST>(fr[0], fi[0], xr[0], xi[0], bk[0]);
-#ifdef TFHE_CB_PAIR_PROXY
-        // EXPERIMENT BUILD ONLY (profiles/r06_cb_pair_by_q.txt), results are NOT a CMux: the instruction and LDS stream of ONE
-        // wave of a pair that splits a ciphertext by output polynomial -- its own digit published through LDS (16 x 16 B per
-        // lane), the partner's digit read from there, a second key half-row, a second MAC into the SAME output polynomial
-        {
-            double2 *pub = reinterpret_cast<double2 *>(w.xch.buf) + t;
-#pragma unroll
-            for (int m = 0; m < PPL; m++) pub[64 * m] = make_double2(xr[0][m], xi[0][m]);
-            TFHE_WAVE_FENCE();
-#pragma unroll
-            for (int m = 0; m < PPL; m++) bk[0][m] = TFHE_BK(row0 + 1, 0, m);
-#pragma unroll
-            for (int m = 0; m < PPL; m++) {
-                const double2 v = pub[64 * m];
-                xr[0][m] = v.x;
-                xi[0][m] = v.y;
-            }
-            TFHE_WAVE_FENCE();
-            mac_half_row<PPL, false>(fr[0], fi[0], xr[0], xi[0], bk[0]);
-        }
-#else
         // (requesting this half-row earlier -- in front of the first MAC, or with the first half-row under the transform --
         // was measured in round 4: 19.07 / 21.82 ms against 18.27 per 1024 x 500 CMux.  Its 64 registers do not exist:
         // accumulator 128 + Fourier accumulator 128 + rotated coefficients 64 + transform 64 + one half-row 64 already
@@ -684,7 +663,6 @@ TFHE_DEVICE void ifft_mac_digits(const WaveLds<T, LOGN> &w, const double2 *__res
 #pragma unroll
         for (int m = 0; m < PPL; m++) bk[0][m] = TFHE_BK(row0, 1, m);
         mac_half_row<PPL, FIRST>(fr[1], fi[1], xr[0], xi[0], bk[0]);
-#endif
     } else {
 #pragma unroll
         for (int e = 0; e < ND; e++) {
@@ -870,11 +848,7 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
     int qrt = 0;  // run-time polynomial index of the rolled loop below
     // the (rotated) coefficients j and j+N/2 of polynomial q, offset added, digit tops flipped
     auto read_poly = [&](auto qc, U (&lo)[PPL], U (&hi)[PPL]) {
-#ifdef TFHE_CB_PAIR_PROXY
-        constexpr int q = 0;  // (the partner's polynomial would come from LDS: the same instruction stream on the wave's own one)
-#else
         constexpr int q = decltype(qc)::value < 0 ? 0 : decltype(qc)::value;
-#endif
         const int qq = decltype(qc)::value < 0 ? qrt : q;  // run-time polynomial index (LDS accumulator only)
         if constexpr (ACCREG) {
             if (rotate) {
@@ -925,25 +899,15 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
         {
             U lo[PPL], hi[PPL];
             read_poly(std::integral_constant<int, 0>{}, lo, hi);
-#ifdef TFHE_CB_PAIR_PROXY
-            const int my_groups = groups / 2;  // one wave of the pair transforms every other digit (see ifft_mac_digits)
-#else
-            const int my_groups = groups;
-#endif
             digits(0, 0, lo, hi, std::true_type{});  // first row as multiplies: no zero-initialised accumulator (-0.9 %)
 #pragma unroll 1
-            for (int gi = 1; gi < my_groups; gi++) digits(0, gi * PAIR, lo, hi, std::false_type{});
+            for (int gi = 1; gi < groups; gi++) digits(0, gi * PAIR, lo, hi, std::false_type{});
         }
         {
             U lo[PPL], hi[PPL];
             read_poly(std::integral_constant<int, 1>{}, lo, hi);
-#ifdef TFHE_CB_PAIR_PROXY
-            const int my_groups = groups / 2;
-#else
-            const int my_groups = groups;
-#endif
 #pragma unroll 1
-            for (int gi = 0; gi < my_groups; gi++) digits(1, gi * PAIR, lo, hi, std::false_type{});
+            for (int gi = 0; gi < groups; gi++) digits(1, gi * PAIR, lo, hi, std::false_type{});
         }
     } else {
 #pragma unroll
@@ -969,22 +933,13 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
     }
     // back to coefficients (both polynomials together), round, accumulate into acc
     // (tLweFromFFTConvert + tLweAddTo)
-#ifdef TFHE_CB_PAIR_PROXY
-    constexpr int NQ = ACCREG ? 1 : 2;  // the wave owns ONE output polynomial
-#else
-    constexpr int NQ = 2;
-#endif
-    if constexpr (NQ == 1)
-        WaveFFT<LOGN>::template fft<1, TwLds<LOGN>, CPLX, TWD>(reinterpret_cast<double(&)[1][PPL]>(fr), reinterpret_cast<double(&)[1][PPL]>(fi),
-                                                               w.tw, w.xch, t);
-    else
-        WaveFFT<LOGN>::template fft<2, TwLds<LOGN>, CPLX, TWD>(fr, fi, w.tw, w.xch, t);
+    WaveFFT<LOGN>::template fft<2, TwLds<LOGN>, CPLX, TWD>(fr, fi, w.tw, w.xch, t);
     U r0[2][PPL], r1[2][PPL];
     bool exact_path = true;
     if (Torus<T>::HAS_FAST) {  // Torus32: short rounding sequence, valid while every |x| < 2^51
         uint32_t guard = 0;
 #pragma unroll
-        for (int q = 0; q < NQ; q++)
+        for (int q = 0; q < 2; q++)
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 r0[q][m] = (U)Torus<T>::from_double_fast(fr[q][m], guard);
@@ -995,7 +950,7 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
     if (exact_path) {
         TFHE_KEEP_BRANCH();
 #pragma unroll
-        for (int q = 0; q < NQ; q++)
+        for (int q = 0; q < 2; q++)
 #pragma unroll
             for (int m = 0; m < PPL; m++) {
                 TFHE_OPAQUE(fr[q][m]);
@@ -1010,7 +965,7 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
         if (rotate) {
             TFHE_KEEP_BRANCH();
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
+            for (int q = 0; q < 2; q++)
 #pragma unroll
                 for (int m = 0; m < PPL; m++) {
                     accr[q][0][m] += r0[q][m];
@@ -1019,7 +974,7 @@ TFHE_DEVICE void cmux_step(const WaveLds<T, LOGN> &w, const double2 *__restrict_
         } else {
             TFHE_KEEP_BRANCH();
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
+            for (int q = 0; q < 2; q++)
 #pragma unroll
                 for (int m = 0; m < PPL; m++) {
                     accr[q][0][m] = r0[q][m];
