@@ -20,6 +20,11 @@ switch 8x2 bits).  Workload by flags:
   --gpus N (N > 1)    BASELINE config 5: 2^20 samples per step cut into N contiguous slices, one
                       launch per rank and step, replicated keys, no data-path collective ("strong")
   --batch B           B samples per GPU per step ("weak");  --total M: M per step over all GPUs
+                      (`--gpus 1 --total 1048576` is the N = 1 point of the strong-scaling series config 5 names: the same
+                      2^20 samples per step on one GPU)
+Every line carries `per_gpu_bootstraps_per_s` (min / max / mean over the ranks' own samples / own seconds) and, with N > 1,
+`efficiency_vs`: the rate rank 0 reaches ALONE on its own slice right after the timed region while the other ranks idle behind
+a barrier -- the N = 1 reference at the same per-GPU batch.  (No efficiency is computed here: whoever reads the series divides.)
   --dist              the multi-GPU code path (torch first, process group, barrier, max over ranks)
                       with the world size --gpus names -- also 1
 value = all ranks' bootstraps / max-over-ranks time.
@@ -262,6 +267,11 @@ def write_detail(line, a):
         return None
 
 
+def per_gpu_rates(ranks, steps):
+    rates = [r["batch"] * steps / r["seconds"] for r in ranks if r["seconds"] > 0]
+    return {"min": min(rates), "max": max(rates), "mean": sum(rates) / len(rates)} if rates else None
+
+
 def compact_line(full, detail_path):
     """The ONE JSON line on stdout, kept to ~3.5 KB: whoever stores only a tail of a run's stdout must still hold the whole line.
     Contract keys first, with `roofline` and `cpu_baseline` in the contract's shape; the other BASELINE configs and the
@@ -290,6 +300,11 @@ def compact_line(full, detail_path):
                                "per_core_value": b.get("per_core_value"), "measured_by": (b.get("measured_by") or "").split(":")[0].split(" (")[0]}
     out["ranks_seen"] = full["ranks_seen"]
     out["n_devices"] = full["n_devices"]
+    pg = full.get("per_gpu_bootstraps_per_s")
+    out["per_gpu_bootstraps_per_s"] = None if not pg else {k: round(v, 1) for k, v in pg.items()}
+    ev = full.get("efficiency_vs")
+    out["efficiency_vs"] = None if not ev else {"per_gpu_bootstraps_per_s": round(ev["per_gpu_bootstraps_per_s"], 1), "batch": ev["batch"],
+                                                "what": "rank 0 alone on its own slice after the timed region, other ranks idle"}
     out["pci"] = full["ranks"][0].get("pci")
     if full["n_gpus"] > 1:
         out["ranks"] = [[x["rank"], x["device"], x["batch"], round(x["seconds"], 4), x.get("pci")] for x in full["ranks"]]  # rank, device, batch, s, PCI bus id
@@ -422,7 +437,8 @@ def main():
                     help="bootstraps per GPU per step (weak scaling); default: 4096 on one GPU (BASELINE config 2)")
     ap.add_argument("--total", type=int, default=None,
                     help="bootstraps per step over ALL GPUs, sharded contiguously (strong scaling); default with "
-                         "--gpus > 1: 2^20 (BASELINE config 5)")
+                         "--gpus > 1: 2^20 (BASELINE config 5).  `--gpus 1 --total 1048576` is the strong-scaling N = 1 point "
+                         "(with N > 1 every line also carries `efficiency_vs`: rank 0 alone on its own slice)")
     ap.add_argument("--dist", action="store_true",
                     help="take the multi-GPU code path (torch imported before the engine, torch.distributed process group, "
                          "barrier + max-over-ranks on a device tensor) even with one rank: the path the driver's "
@@ -640,6 +656,23 @@ def main():
         ranks_seen, ranks = shard.rank_census(rank, device, B, elapsed_local, dev, pci)
         if ranks_seen != world:
             raise SystemExit(f"bench.py: {ranks_seen} ranks answered the census, world size is {world}")
+    # What ONE GPU does on the very slice it was given, measured behind a barrier while the other ranks idle: the N = 1 rate the
+    # aggregate is to be compared with (same per-GPU batch, same kernels, same box) -- a scaling series whose N = 1 point is another
+    # workload (config 2: 4096 per step) cannot say whether a shortfall is the slice size or the other GPUs.  Never part of `value`.
+    solo = None
+    if dist is not None and world > 1:
+        t_solo = None
+        if rank == 0:
+            ts = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            eng.sync()
+            t_solo = time.perf_counter() - ts
+        fence()  # the other ranks wait here, GPUs idle
+        if rank == 0:
+            solo = {"per_gpu_bootstraps_per_s": B * a.steps / t_solo, "batch": B, "steps": a.steps, "seconds": t_solo,
+                    "what": "rank 0 alone on its own slice, after the timed region, the other ranks idle behind a barrier: the N = 1 "
+                            "rate at THIS per-GPU batch (value / n_gpus against it = what the other GPUs running cost)"}
     n_devices = shard.distinct_devices(ranks)
     if dist is not None and a.backend == "nccl" and n_devices != world:
         # N ranks under RCCL are N GPUs or nothing: two ranks doubled up on one chip would report half the rate as "N GPUs"
@@ -866,6 +899,9 @@ def main():
             "ranks_seen": ranks_seen,
             "n_devices": n_devices,
             "ranks": ranks,
+            # every rank's own rate over the timed region (its samples / its seconds): the spread says whether one GPU holds the rest up
+            "per_gpu_bootstraps_per_s": per_gpu_rates(ranks, a.steps),
+            "efficiency_vs": solo,
             "config": {"workload": f"{baseline_config}: {total_per_step} gate bootstraps per step ({B} on rank 0), "
                                    f"{cfg.describe()}, persistent blind-rotation kernel + key-switch kernel, inputs resident in HBM",
                        "baseline_config": baseline_config,

@@ -40,6 +40,9 @@ def test_bench_line_on_emulator(emu_lib, tmp_path):
     assert abs(r["hbm_contract_frac"] - r["hbm_contract_bytes"] / (r["kernel_ms"] * 1e-3) / 8.0e12) < 1e-9
     assert abs(r["fp64_issue_frac"] - 2 * 630 * 2144 / (r["kernel_ms"] * 1e-3) / (1024 * 2.4e9 / 4)) < 1e-9
     assert d["ranks_seen"] == 1 and "ranks" not in d
+    # one rank: its own rate IS the value; no solo reference
+    pg = d["per_gpu_bootstraps_per_s"]
+    assert pg["min"] == pg["max"] == pg["mean"] and abs(pg["mean"] - d["value"]) < 0.02 * d["value"] and d["efficiency_vs"] is None
     assert "config1_latency" not in d and "config2_streamed" not in d and "sustained" not in d and "pool_check" not in d  # --headline-only
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "bootstraps/s" and c["sample"]
@@ -83,6 +86,13 @@ def test_bench_multi_rank_path_on_emulator(emu_lib):
     assert "gloo, world 2" in d["config"]["process_group"]
     assert d["checks"]["decrypt"] is True
     assert abs(d["value"] - 5 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # the series describes itself: every rank's own rate (samples / its seconds over the timed region) and what rank 0 does
+    # ALONE on its slice afterwards (the N = 1 point at the same per-GPU batch)
+    rates = [r[2] * d["steps"] / r[3] for r in d["ranks"]]
+    pg = d["per_gpu_bootstraps_per_s"]
+    assert abs(pg["min"] - min(rates)) < 0.01 * pg["min"] and abs(pg["max"] - max(rates)) < 0.01 * pg["max"]  # (seconds are rounded on the line)
+    ev = d["efficiency_vs"]
+    assert ev["batch"] == 3 and ev["per_gpu_bootstraps_per_s"] > 0 and "alone" in ev["what"]
 
 
 def test_bench_dist_flag_single_rank_on_emulator(emu_lib):
@@ -135,6 +145,10 @@ def test_bench_eight_self_launched_ranks_on_emulator(emu_lib):
     assert [r[1] for r in d["ranks"]] == list(range(8)) and d["n_devices"] == 8 and len({r[4] for r in d["ranks"]}) == 8  # rank r on emulated device r
     assert abs(d["value"] - 19 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["ms_per_step"] * 1e-3 >= max(r[3] for r in d["ranks"]) - 1e-3  # the MAX over ranks is what is reported
+    pg, ev = d["per_gpu_bootstraps_per_s"], d["efficiency_vs"]
+    assert 0 < pg["min"] <= pg["mean"] <= pg["max"] and ev["batch"] == 3 and ev["per_gpu_bootstraps_per_s"] > 0
+    # (value <= sum of the ranks' own rates: the slowest rank sets the time)
+    assert d["value"] <= sum(r[2] * d["steps"] / r[3] for r in d["ranks"]) * 1.01
 
 
 def test_bench_never_reports_ranks_that_did_not_run(emu_lib):
