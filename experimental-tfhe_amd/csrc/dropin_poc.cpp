@@ -15,6 +15,7 @@
 // parallel/src/test_parallel_multiplications.cpp:62).
 #include <cstring>
 #include <map>
+#include <memory>
 
 #include "poc_types.h"
 
@@ -24,8 +25,12 @@
 
 namespace {
 typedef tfhe_amd_compat::PocEngine<Globals> Engine;
+// Engines are held by shared_ptr: tfhe_CircuitBootstrapFFT calls its engine WITHOUT the shims' lock (so that concurrent callers
+// can meet in the engine's coalescer), and takes its own reference under the lock first -- a tfhe_amd_dropin_release(env), or a
+// rebuild after a fingerprint change, from another thread then only drops the map's reference; the engine (its coalescer, its
+// GPU buffers) dies when the last caller inside it has returned.
 struct Slot {
-    Engine *eng;
+    std::shared_ptr<Engine> eng;
     uint64_t fingerprint;
 };
 std::map<const Globals *, Slot> &engines() {
@@ -65,18 +70,18 @@ uint64_t env_fingerprint(const Globals *env) {
     }
     return h;
 }
-Engine &engine_of(const Globals *env) {
+std::shared_ptr<Engine> engine_ref(const Globals *env) {  // (under the shims' lock)
     auto &m = engines();
     const uint64_t fp = env_fingerprint(env);
     auto it = m.find(env);
     if (it != m.end() && it->second.fingerprint != fp) {  // rebuilt in place: upload again
-        delete it->second.eng;
         m.erase(it);
         it = m.end();
     }
-    if (it == m.end()) it = m.emplace(env, Slot{new Engine(env, tfhe_amd_compat::device_ordinal()), fp}).first;
-    return *it->second.eng;
+    if (it == m.end()) it = m.emplace(env, Slot{std::make_shared<Engine>(env, tfhe_amd_compat::device_ordinal()), fp}).first;
+    return it->second.eng;
 }
+Engine &engine_of(const Globals *env) { return *engine_ref(env); }  // callers that keep the lock for the whole call
 }  // namespace
 
 void preKeySwitch(LweSample32 *result, const LweSample32 *x, const Globals *env) { TFHE_AMD_SHIM_GUARD(); engine_of(env).preKeySwitch(result, x); }
@@ -88,12 +93,14 @@ void circuitPrivKS(TLweSample32 *result, const int u, const LweSample64 *x, cons
     engine_of(env).circuitPrivKS(result, u, x);
 }
 void tfhe_CircuitBootstrapFFT(TGswSample32 *result, const LweSample32 *sample, const Globals *env) {
-    Engine *e;
+    std::shared_ptr<Engine> e;
     {  // the lookup under the lock, the call outside it: concurrent callers meet in the engine's coalescer and share a launch
         TFHE_AMD_SHIM_GUARD();
-        e = &engine_of(env);
+        e = engine_ref(env);  // this caller's own reference: see Slot
     }
     e->tfhe_CircuitBootstrapFFT(result, sample);
+    // (released meanwhile and this is the last caller inside: the engine dies here, outside the lock -- its destructor only calls
+    // the C ABI on handles nobody else holds)
 }
 void tfhe_CircuitBootstrapFFT_array(TGswSample32 *const *results, const LweSample32 *const *samples, const Globals *env, int count) { TFHE_AMD_SHIM_GUARD();
     engine_of(env).tfhe_CircuitBootstrapFFT_array(results, samples, count);
@@ -106,6 +113,5 @@ void tfhe_amd_dropin_release(const Globals *env) { TFHE_AMD_SHIM_GUARD();
     auto &m = engines();
     auto it = m.find(env);
     if (it == m.end()) return;
-    delete it->second.eng;
-    m.erase(it);
+    m.erase(it);  // (an engine with callers still inside it lives until the last of them returns)
 }

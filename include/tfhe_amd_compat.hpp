@@ -45,6 +45,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -132,9 +133,14 @@ inline std::recursive_mutex &shim_mutex() {
 // ran out while callers were still arriving lengthens the next one, a wait during which nobody came halves it (down to 1/16 of
 // the bound; the full wait is tried again every 16th batch).  TFHE_AMD_COALESCE_LINGER_US in the environment fixes the bound
 // (0: never wait).
+// process-wide sums over coalescers that report into them (they outlive a coalescer dropped with its key)
+struct CoalescerTotals {
+    std::atomic<unsigned long> batches{0}, requests{0}, lingers{0}, linger_timeouts{0};
+};
 template <class Item>
 class Coalescer {
    public:
+    explicit Coalescer(CoalescerTotals *totals = nullptr) : totals_(totals) {}
     // run(items): executes the batch; called without the coalescer's lock, by exactly one thread at a time
     template <class RunBatch>
     void call(const Item &item, RunBatch run) {
@@ -166,6 +172,7 @@ class Coalescer {
             const int shift = (linger_fixed_us() >= 0 || batches_ % 16 == 15) ? 0 : shift_;
             const size_t had = pending_.size();
             lingers_++;
+            if (totals_) totals_->lingers++;
             lingering_ = true;
 #if defined(__SANITIZE_THREAD__)
             // (gcc 11's ThreadSanitizer runtime does not intercept pthread_cond_clockwait, what a wait on the steady clock
@@ -184,7 +191,10 @@ class Coalescer {
                 shift_ = shift_ > 0 ? shift_ - 1 : 0;
             else
                 shift_ = shift_ < 4 ? shift_ + 1 : 4;
-            if (!all_here) linger_timeouts_++;
+            if (!all_here) {
+                linger_timeouts_++;
+                if (totals_) totals_->linger_timeouts++;
+            }
         }
         std::vector<Req *> batch;
         batch.swap(pending_);
@@ -198,6 +208,10 @@ class Coalescer {
         lk.lock();
         crowd_ = batch.size() + pending_.size();
         requests_ += batch.size();
+        if (totals_) {
+            totals_->requests += batch.size();
+            totals_->batches++;
+        }
         linger_bound_ = linger_fixed_us() >= 0 ? std::chrono::nanoseconds(1000LL * linger_fixed_us())
                                                 : std::min(took / 8, std::chrono::nanoseconds(500000));
         batches_++;
@@ -273,53 +287,72 @@ class Coalescer {
     std::chrono::nanoseconds linger_bound_{0};  // an eighth of the last launch, 0.5 ms at most
     int shift_ = 0;                           // the bound is halved `shift_` times after waits that ran out
     unsigned long batches_ = 0, requests_ = 0, lingers_ = 0, linger_timeouts_ = 0;
+    CoalescerTotals *totals_;
 };
 struct LweCall {
     LweSample *result;
     const LweSample *x;
+    Torus32 mu;  // the call's test-vector value (0 for the key switch): calls of one batch are run grouped by it
 };
-// one coalescer per (entry point, key object, mu): only calls that can share a launch meet in it
-struct CoalesceKey {
-    int kind;
-    const void *key;
-    int32_t mu;
-    bool operator<(const CoalesceKey &o) const {
-        if (kind != o.kind) return kind < o.kind;
-        if (key != o.key) return key < o.key;
-        return mu < o.mu;
-    }
-};
+// One coalescer per (entry point, key object): calls on one key meet in it whatever their mu; the leader runs its batch as one
+// launch per DISTINCT mu (for_each_mu_group) -- a caller that sweeps mu does not grow this registry.  Entries are shared_ptr: a
+// caller holds its coalescer for the length of its call, so release() of the key (which drops the entry) never frees one in use.
+typedef std::pair<int, const void *> CoalesceKey;  // (kind, key object)
 struct LweCoalescers {
     std::mutex m;
-    std::map<CoalesceKey, Coalescer<LweCall> *> reg;  // entries live for the process (a few hundred bytes per key and mu)
+    std::map<CoalesceKey, std::shared_ptr<Coalescer<LweCall>>> reg;
+    CoalescerTotals totals;  // all keys, released ones included
 };
 inline LweCoalescers &lwe_coalescers() {
     static LweCoalescers r;
     return r;
 }
-inline Coalescer<LweCall> &lwe_coalescer(int kind, const void *key, int32_t mu) {
+inline std::shared_ptr<Coalescer<LweCall>> lwe_coalescer(int kind, const void *key) {
     LweCoalescers &r = lwe_coalescers();
     std::lock_guard<std::mutex> lk(r.m);
-    Coalescer<LweCall> *&c = r.reg[CoalesceKey{kind, key, mu}];
-    if (!c) c = new Coalescer<LweCall>();
-    return *c;
+    std::shared_ptr<Coalescer<LweCall>> &c = r.reg[CoalesceKey(kind, key)];
+    if (!c) c = std::make_shared<Coalescer<LweCall>>(&r.totals);
+    return c;
+}
+inline size_t lwe_coalescer_count() {
+    LweCoalescers &r = lwe_coalescers();
+    std::lock_guard<std::mutex> lk(r.m);
+    return r.reg.size();
+}
+// the coalescers of a key object that is going away (release()); key == nullptr: all of them (release_all())
+inline void lwe_coalescers_drop(const void *key) {
+    LweCoalescers &r = lwe_coalescers();
+    std::lock_guard<std::mutex> lk(r.m);
+    for (auto it = r.reg.begin(); it != r.reg.end();) {
+        auto cur = it++;
+        if (key && cur->first.second != key) continue;
+        r.reg.erase(cur);  // (callers inside it hold their own reference; its counts are in r.totals)
+    }
+}
+// f(mu, calls of that mu) for every distinct mu of a batch, in order of first appearance; calls keep their order inside a group
+template <class F>
+inline void for_each_mu_group(const std::vector<LweCall> &calls, F f) {
+    std::vector<char> taken(calls.size(), 0);
+    std::vector<LweCall> group;
+    for (size_t i = 0; i < calls.size(); i++) {
+        if (taken[i]) continue;
+        group.clear();
+        for (size_t j = i; j < calls.size(); j++)
+            if (!taken[j] && calls[j].mu == calls[i].mu) {
+                taken[j] = 1;
+                group.push_back(calls[j]);
+            }
+        f(calls[i].mu, group);
+    }
 }
 // launches and one-sample requests of the coalesced gate entry points so far, all keys (diagnostics)
 inline void lwe_coalescer_totals(unsigned long *batches, unsigned long *requests, unsigned long *lingers = nullptr,
                                  unsigned long *linger_timeouts = nullptr) {
     LweCoalescers &r = lwe_coalescers();
-    std::lock_guard<std::mutex> lk(r.m);
-    *batches = *requests = 0;
-    if (lingers) *lingers = 0;
-    if (linger_timeouts) *linger_timeouts = 0;
-    for (auto &e : r.reg) {
-        unsigned long b, q, w, t;
-        e.second->stats(&b, &q, &w, &t);
-        *batches += b;
-        *requests += q;
-        if (lingers) *lingers += w;
-        if (linger_timeouts) *linger_timeouts += t;
-    }
+    *batches = r.totals.batches.load();
+    *requests = r.totals.requests.load();
+    if (lingers) *lingers = r.totals.lingers.load();
+    if (linger_timeouts) *linger_timeouts = r.totals.linger_timeouts.load();
 }
 
 inline int &device_ordinal() {
@@ -571,10 +604,18 @@ inline void release_entry(std::map<ResidentKey, Resident>::iterator it) {
 inline void release(const void *key_object) {
     TFHE_AMD_SHIM_GUARD();
     auto &reg = registry();
+    std::vector<const void *> gone(1, key_object);  // every address this key was seen under: their coalescers go too
     for (auto it = reg.begin(); it != reg.end();) {
         auto cur = it++;
-        if (cur->first.obj == key_object || cur->first.ks == key_object || cur->second.owner == key_object) release_entry(cur);
+        if (cur->first.obj == key_object || cur->first.ks == key_object || cur->second.owner == key_object) {
+            gone.push_back(cur->first.obj);
+            gone.push_back(cur->first.ks);
+            gone.push_back(cur->second.owner);
+            release_entry(cur);
+        }
     }
+    for (const void *g : gone)
+        if (g) lwe_coalescers_drop(g);
     auto &pools = pool_registry();
     for (auto it = pools.begin(); it != pools.end();) {
         auto cur = it++;
@@ -589,6 +630,7 @@ inline void release_all() {
     while (!registry().empty()) release_entry(registry().begin());
     for (auto &e : pool_registry()) tfhe_amd_pool_destroy(e.second.pool);
     pool_registry().clear();
+    lwe_coalescers_drop(nullptr);
 }
 
 inline Resident &attach(const LweBootstrappingKeyFFT *bk) {
@@ -641,7 +683,8 @@ inline void run_lwe_calls(const std::vector<LweCall> &calls, One one, Many many)
     many(rs.data(), xs.data(), (int)calls.size());
 }
 inline void tfhe_bootstrap_woKS_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x) {
-    lwe_coalescer(0, bk, mu).call(LweCall{result, x}, [&](const std::vector<LweCall> &calls) {
+    lwe_coalescer(0, bk)->call(LweCall{result, x, mu}, [&](const std::vector<LweCall> &batch) {
+      for_each_mu_group(batch, [&](Torus32 mu, const std::vector<LweCall> &calls) {  // (shadows the leader's own mu: a group's)
         run_lwe_calls(calls,
                       [&](LweSample *r, const LweSample *in) {
                           TFHE_AMD_SHIM_GUARD();
@@ -651,10 +694,12 @@ inline void tfhe_bootstrap_woKS_FFT(LweSample *result, const LweBootstrappingKey
                           get_lwe(R, r, R.d_out, R.N);
                       },
                       [&](LweSample *const *rs, const LweSample *const *xs, int n) { ::tfhe_amd_compat::tfhe_bootstrap_woKS_FFT_array(rs, bk, mu, xs, n); });
+      });
     });
 }
 inline void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *bk, Torus32 mu, const LweSample *x) {
-    lwe_coalescer(1, bk, mu).call(LweCall{result, x}, [&](const std::vector<LweCall> &calls) {
+    lwe_coalescer(1, bk)->call(LweCall{result, x, mu}, [&](const std::vector<LweCall> &batch) {
+      for_each_mu_group(batch, [&](Torus32 mu, const std::vector<LweCall> &calls) {
         run_lwe_calls(calls,
                       [&](LweSample *r, const LweSample *in) {
                           TFHE_AMD_SHIM_GUARD();
@@ -664,6 +709,7 @@ inline void tfhe_bootstrap_FFT(LweSample *result, const LweBootstrappingKeyFFT *
                           get_lwe(R, r, R.d_out, R.n);
                       },
                       [&](LweSample *const *rs, const LweSample *const *xs, int n) { ::tfhe_amd_compat::tfhe_bootstrap_FFT_array(rs, bk, mu, xs, n); });
+      });
     });
 }
 inline void tfhe_blindRotate_FFT(TLweSample *accum, const TGswSampleFFT *bkFFT, const int *bara, const int n,
@@ -742,7 +788,7 @@ inline Resident &attach_ks(const LweKeySwitchKey *ks) {
     return it->second;
 }
 inline void lweKeySwitch(LweSample *result, const LweKeySwitchKey *ks, const LweSample *sample) {
-    lwe_coalescer(2, ks, 0).call(LweCall{result, sample}, [&](const std::vector<LweCall> &calls) {
+    lwe_coalescer(2, ks)->call(LweCall{result, sample, 0}, [&](const std::vector<LweCall> &calls) {
         run_lwe_calls(calls,
                       [&](LweSample *r, const LweSample *in) {
                           TFHE_AMD_SHIM_GUARD();

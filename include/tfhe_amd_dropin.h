@@ -18,7 +18,9 @@
 //   Declared here when TFHE_AMD_DROPIN_POC is defined AFTER poc_types.h has been included; they are
 //   defined by experimental-tfhe_amd/csrc/dropin_poc.cpp, which a PoC build compiles next to its own
 //   poc_types.h (C++ linkage on user types cannot be pre-built).  The engine behind an `env` is created
-//   on first use (keys uploaded once) and kept until tfhe_amd_dropin_release(env).
+//   on first use (keys uploaded once) and kept until tfhe_amd_dropin_release(env).  release may be called while other host
+//   threads are inside tfhe_CircuitBootstrapFFT(env) (the one entry point that runs outside the shims' lock): those calls
+//   finish on the engine they started on, which is destroyed when the last of them returns.
 #ifndef TFHE_AMD_DROPIN_H
 #define TFHE_AMD_DROPIN_H
 

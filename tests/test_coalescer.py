@@ -26,6 +26,15 @@ def test_coalescer(tmp_path, tsan):
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["carried"] == d["calls"] and d["wrong"] == 0 and d["overlaps"] == 0 and d["led_more_than_one"] == 0
     assert d["batches"] < d["calls"] and d["max_batch"] > 1  # calls did share batches
+    # the shims' registry: 10^4 calls with 10^4 distinct mu on two key objects from 8 threads, one of the keys released again and
+    # again meanwhile -- at most one coalescer per key (the registry used to grow by one per mu and never shrank), every call
+    # answered with its own mu's result, every request counted, nothing left after release_all
+    out = subprocess.run([exe, "registry", "8", "10000"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr[-3000:]
+    assert "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["wrong"] == 0 and r["max_registry"] <= 2 and r["requests_counted"] == 10000 and r["registry_after_release_all"] == 0
+    assert r["groups"] >= r["batches"]
     if not tsan:
         # a tight loop of 8 threads on a 2 ms "launch": the leader waits for the callers of the batch that just finished, so a
         # launch carries (nearly) all 8 -- without that wait the loop settles into two alternating groups (mean batch 5.3 measured)
