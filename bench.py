@@ -343,7 +343,8 @@ def compact_line(full, detail_path):
     def b_pool(pc):
         return {"[devices, samples per call, bootstraps/s]": [[m["devices"], m.get("samples_per_call"), round(m["bootstraps_per_s"], 1)] for m in pc["pools"]],
                 "pcie_included": True,
-                "identical_to_headline": all(m["identical_to_headline"] for m in pc["pools"])}
+                "identical_to_headline": all(m["identical_to_headline"] for m in pc["pools"] if m["identical_to_headline"] is not None),
+                "errors": [str(m["error"])[:120] for m in pc["pools"] if "error" in m] or None}
 
     def b_c3(c3):
         br = c3.get("blind_rotation_roofline", {})
@@ -830,8 +831,9 @@ def main():
                 if not same:
                     extras_ok = False
             except T.TfheAmdError as e:
-                pool_check["pools"].append({"devices": devs, "error": str(e), "bootstraps_per_s": 0.0, "identical_to_headline": False})
-                extras_ok = False
+                # a pool that could not be BUILT or RUN (allocation failure, a bad --pool-devices list) costs its own entry, never
+                # the run's exit status: only outputs that DIFFER from the headline's do (identical_to_headline False above)
+                pool_check["pools"].append({"devices": devs, "error": str(e), "bootstraps_per_s": 0.0, "identical_to_headline": None})
 
     pipelined = None
     if world == 1 and a.pipelined:

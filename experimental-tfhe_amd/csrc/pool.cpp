@@ -161,11 +161,13 @@ struct Pipe {
             if (int rc = st[s].ensure(c, in_need, out_need)) return rc;
             if (mid_need)
                 if (int rc = st[s].ensure_mid(c, mid_need)) return rc;
-            if (!ev_in[s]) {
+            // each event on its own: a set whose second creation failed once is completed by the next call, not skipped
+            if (!ev_in[s])
                 if (int rc = tfhe_amd_event_create(c, &ev_in[s])) return rc;
+            if (!ev_done[s])
                 if (int rc = tfhe_amd_event_create(c, &ev_done[s])) return rc;
+            if (!ev_out[s])
                 if (int rc = tfhe_amd_event_create(c, &ev_out[s])) return rc;
-            }
         }
         if (!s_in)
             if (int rc = tfhe_amd_stream_create(c, &s_in)) return rc;
@@ -298,8 +300,10 @@ struct tfhe_amd_pool {
     std::mutex call_mu;  // one sharded call at a time
     std::string err;
     int chunk_rows = DEFAULT_CHUNK_ROWS;
-    // a key load that failed on SOME members leaves the members with different keys: the operations refuse to run (their
-    // outputs would depend on the slice a sample fell into) until a load of that key has succeeded on every member
+    // a load of a key that succeeded on SOME members and failed on others leaves the members with different keys: the operations
+    // that use THAT key refuse to run (their outputs would depend on the slice a sample fell into) until a load of it has had the
+    // same outcome on every member.  (A failure that is the same everywhere -- bad parameters, a context without key-switch
+    // parameters -- leaves every member with its previous key: nothing is mixed.)
     bool bk_mixed = false, ks_mixed = false;
 };
 
@@ -323,15 +327,17 @@ int member_status(tfhe_amd_pool::Member &mb, int rc) {
     return rc;
 }
 
+enum : unsigned { NEEDS_BK = 1, NEEDS_KS = 2 };  // which keys an operation reads
 // launch(ctx, d_mid, d_out, d_in, rows): the operation on device buffers; d_mid (rows x mid_ints) is scratch owned by the caller.
 // rows_in / rows_out move rows between the caller's representation and the members' pinned staging buffers; they are called
 // on the members' threads, concurrently for DISJOINT row ranges.
 template <class RowsIn, class RowsOut, class Launch>
-int pool_rows_fn(tfhe_amd_pool *pool, RowsOut rows_out, size_t out_ints, RowsIn rows_in, size_t in_ints, size_t mid_ints, int count, Launch launch) {
+int pool_rows_fn(tfhe_amd_pool *pool, RowsOut rows_out, size_t out_ints, RowsIn rows_in, size_t in_ints, size_t mid_ints, unsigned needs, int count,
+                 Launch launch) {
     if (!pool || count < 0) return TFHE_AMD_ERR_PARAM;
     std::lock_guard<std::mutex> lk(pool->call_mu);
-    if (pool->bk_mixed || pool->ks_mixed) {
-        pool->err = "the last key load failed on some members: the members hold different keys, load the keys again";
+    if (((needs & NEEDS_BK) && pool->bk_mixed) || ((needs & NEEDS_KS) && pool->ks_mixed)) {  // only the keys this operation uses
+        pool->err = "the last load of a key this operation uses succeeded on some members only: the members hold different keys, load it again";
         return TFHE_AMD_ERR_STATE;
     }
     const int members = (int)pool->m.size();
@@ -365,20 +371,20 @@ int pool_rows_fn(tfhe_amd_pool *pool, RowsOut rows_out, size_t out_ints, RowsIn 
 }
 // flat host arrays
 template <class Launch>
-int pool_rows(tfhe_amd_pool *pool, int32_t *out, size_t out_ints, const int32_t *x, size_t in_ints, size_t mid_ints, int count, Launch launch) {
+int pool_rows(tfhe_amd_pool *pool, int32_t *out, size_t out_ints, const int32_t *x, size_t in_ints, size_t mid_ints, unsigned needs, int count, Launch launch) {
     if (!out || !x) return TFHE_AMD_ERR_PARAM;
     return pool_rows_fn(
         pool, [=](int first, int rows, const void *src) { memcpy(out + (size_t)first * out_ints, src, (size_t)rows * out_ints * 4); }, out_ints,
-        [=](int first, int rows, void *dst) { memcpy(dst, x + (size_t)first * in_ints, (size_t)rows * in_ints * 4); }, in_ints, mid_ints, count, launch);
+        [=](int first, int rows, void *dst) { memcpy(dst, x + (size_t)first * in_ints, (size_t)rows * in_ints * 4); }, in_ints, mid_ints, needs, count, launch);
 }
 // the caller's own representation, through its two callbacks
 template <class Launch>
 int pool_rows_cb(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, size_t out_ints, tfhe_amd_rows_in_fn get, size_t in_ints, size_t mid_ints, void *user,
-                 int count, Launch launch) {
+                 unsigned needs, int count, Launch launch) {
     if (!put || !get) return TFHE_AMD_ERR_PARAM;
     return pool_rows_fn(
         pool, [=](int first, int rows, const void *src) { put(user, first, rows, (const int32_t *)src); }, out_ints,
-        [=](int first, int rows, void *dst) { get(user, first, rows, (int32_t *)dst); }, in_ints, mid_ints, count, launch);
+        [=](int first, int rows, void *dst) { get(user, first, rows, (int32_t *)dst); }, in_ints, mid_ints, needs, count, launch);
 }
 }  // namespace
 
@@ -439,6 +445,9 @@ tfhe_amd_ctx *tfhe_amd_pool_ctx(tfhe_amd_pool *pool, int member) {
 static int pool_load(tfhe_amd_pool *pool, const void *bk, bool bk_is_fft, const int32_t *ks) {
     if (!pool || (!bk && !ks)) return TFHE_AMD_ERR_PARAM;
     std::lock_guard<std::mutex> lk(pool->call_mu);
+    // per member and per key: 1 = loaded, 0 = failed (the member keeps its previous one), -1 = not attempted
+    std::vector<int> bk_done(pool->m.size(), -1), ks_done(pool->m.size(), -1);
+    int *bk_ok = bk_done.data(), *ks_ok = ks_done.data();
     const int status = on_every_member(pool, [=](int i) {
         tfhe_amd_pool::Member &mb = pool->m[i];
         if (bk) {
@@ -446,6 +455,7 @@ static int pool_load(tfhe_amd_pool *pool, const void *bk, bool bk_is_fft, const 
             int rc = bk_is_fft ? tfhe_amd_gsw_from_fft(mb.ctx, (const double *)bk, pool->p.n, &g)
                                : tfhe_amd_gsw_from_torus(mb.ctx, bk, pool->p.n, &g);
             if (!rc) rc = tfhe_amd_set_bootstrap_key(mb.ctx, g);
+            bk_ok[i] = rc == TFHE_AMD_OK;
             if (rc) {
                 if (g) tfhe_amd_gsw_free(g);
                 return member_status(mb, rc);
@@ -453,13 +463,22 @@ static int pool_load(tfhe_amd_pool *pool, const void *bk, bool bk_is_fft, const 
             if (mb.bk) tfhe_amd_gsw_free(mb.bk);  // the previous key, after the new one is in place
             mb.bk = g;
         }
-        if (ks)
-            if (int rc = tfhe_amd_load_keyswitch_key(mb.ctx, ks)) return member_status(mb, rc);
+        if (ks) {
+            const int rc = tfhe_amd_load_keyswitch_key(mb.ctx, ks);
+            ks_ok[i] = rc == TFHE_AMD_OK;
+            if (rc) return member_status(mb, rc);
+        }
         return (int)TFHE_AMD_OK;
     });
-    const bool several = pool->m.size() > 1;  // (one member: a failed load leaves its previous key, as on a bare context)
-    if (bk) pool->bk_mixed = status != TFHE_AMD_OK && several;
-    if (ks) pool->ks_mixed = status != TFHE_AMD_OK && several;
+    // a key is MIXED when its load did not have the same outcome on every member (a member that failed the bk step never tried
+    // its ks step: counted as a failed one).  The same outcome everywhere -- all loaded, or all refused -- clears the flag.
+    auto mixed = [&](const std::vector<int> &done) {
+        int ok = 0;
+        for (int v : done) ok += v == 1;
+        return ok != 0 && ok != (int)done.size();
+    };
+    if (bk) pool->bk_mixed = mixed(bk_done);
+    if (ks) pool->ks_mixed = mixed(ks_done);
     return status;
 }
 int tfhe_amd_pool_load_keys(tfhe_amd_pool *pool, const double *bkfft, const int32_t *ks) { return pool_load(pool, bkfft, true, ks); }
@@ -472,19 +491,19 @@ int tfhe_amd_pool_bootstrap_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, 
     const size_t row = (size_t)pool->p.n + 1;
     // blind rotation + extraction into the member's own intermediate buffer, then the key switch: tfhe_amd_bootstrap's two
     // kernels without the context's scratch, so that two chunks can be in flight
-    return pool_rows(pool, out, row, x, row, (size_t)pool->p.N + 1, count, [mu](tfhe_amd_ctx *c, int32_t *mid, int32_t *o, const int32_t *in, int rows) {
+    return pool_rows(pool, out, row, x, row, (size_t)pool->p.N + 1, NEEDS_BK | NEEDS_KS, count, [mu](tfhe_amd_ctx *c, int32_t *mid, int32_t *o, const int32_t *in, int rows) {
         const int rc = tfhe_amd_bootstrap_woks(c, mid, mu, in, rows);
         return rc ? rc : tfhe_amd_keyswitch(c, o, mid, rows);
     });
 }
 int tfhe_amd_pool_bootstrap_woks_host(tfhe_amd_pool *pool, int32_t *out, int32_t mu, const int32_t *x, int count) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
-    return pool_rows(pool, out, (size_t)pool->p.N + 1, x, (size_t)pool->p.n + 1, 0, count,
+    return pool_rows(pool, out, (size_t)pool->p.N + 1, x, (size_t)pool->p.n + 1, 0, NEEDS_BK, count,
                      [mu](tfhe_amd_ctx *c, int32_t *, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_bootstrap_woks(c, o, mu, in, rows); });
 }
 int tfhe_amd_pool_keyswitch_host(tfhe_amd_pool *pool, int32_t *out, const int32_t *x, int count) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
-    return pool_rows(pool, out, (size_t)pool->p.ks_n_out + 1, x, (size_t)pool->p.N + 1, 0, count,
+    return pool_rows(pool, out, (size_t)pool->p.ks_n_out + 1, x, (size_t)pool->p.N + 1, 0, NEEDS_KS, count,
                      [](tfhe_amd_ctx *c, int32_t *, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_keyswitch(c, o, in, rows); });
 }
 // the same three operations on the CALLER's representation of the rows (e.g. an array of LweSample pointers): `get` fills a
@@ -496,17 +515,17 @@ static int launch_bootstrap(tfhe_amd_ctx *c, int32_t mu, int32_t *mid, int32_t *
 int tfhe_amd_pool_bootstrap_rows(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int32_t mu, int count) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
     const size_t row = (size_t)pool->p.n + 1;
-    return pool_rows_cb(pool, put, row, get, row, (size_t)pool->p.N + 1, user, count,
+    return pool_rows_cb(pool, put, row, get, row, (size_t)pool->p.N + 1, user, NEEDS_BK | NEEDS_KS, count,
                         [mu](tfhe_amd_ctx *c, int32_t *mid, int32_t *o, const int32_t *in, int rows) { return launch_bootstrap(c, mu, mid, o, in, rows); });
 }
 int tfhe_amd_pool_bootstrap_woks_rows(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int32_t mu, int count) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
-    return pool_rows_cb(pool, put, (size_t)pool->p.N + 1, get, (size_t)pool->p.n + 1, 0, user, count,
+    return pool_rows_cb(pool, put, (size_t)pool->p.N + 1, get, (size_t)pool->p.n + 1, 0, user, NEEDS_BK, count,
                         [mu](tfhe_amd_ctx *c, int32_t *, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_bootstrap_woks(c, o, mu, in, rows); });
 }
 int tfhe_amd_pool_keyswitch_rows(tfhe_amd_pool *pool, tfhe_amd_rows_out_fn put, tfhe_amd_rows_in_fn get, void *user, int count) {
     if (!pool) return TFHE_AMD_ERR_PARAM;
-    return pool_rows_cb(pool, put, (size_t)pool->p.ks_n_out + 1, get, (size_t)pool->p.N + 1, 0, user, count,
+    return pool_rows_cb(pool, put, (size_t)pool->p.ks_n_out + 1, get, (size_t)pool->p.N + 1, 0, user, NEEDS_KS, count,
                         [](tfhe_amd_ctx *c, int32_t *, int32_t *o, const int32_t *in, int rows) { return tfhe_amd_keyswitch(c, o, in, rows); });
 }
 int tfhe_amd_pool_set_option(tfhe_amd_pool *pool, int option, int value) {

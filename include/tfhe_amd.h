@@ -89,7 +89,13 @@ int tfhe_amd_device_pci_bus_id(int device, char *buf, size_t len);
  * after them and read the idle clock (2.4 GHz).  The clock UNDER a blind rotation comes from the probe build of the library
  * (libtfhe_amd_probe.so, tools/wave_probe.py), which stamps inside the kernel. */
 int tfhe_amd_clock_probe(tfhe_amd_ctx *ctx, int duration_us, double *ghz_median, double *ghz_min, double *ghz_max);
-/* use an existing hipStream_t (passed as void*); NULL = the context's own stream */
+/* use an existing hipStream_t (passed as void*); NULL = the context's own stream.  The switch does NOT wait and inserts no
+ * dependency: work already queued on the previous stream stays ordered there, work queued after the call is ordered on the new
+ * stream only.  A caller that moves a context between streams and needs later work to follow earlier work -- the context's
+ * scratch (used by tfhe_amd_bootstrap, _streamed, _lut_eval, the circuit bootstrap's workspaces) is shared by both -- orders
+ * them itself: tfhe_amd_event_record before the switch + tfhe_amd_stream_wait_event after it (device side, no host wait), or
+ * tfhe_amd_sync before it.  (The pool's copy / compute pipeline relies on the switch being free: it ties its three streams
+ * with events of its own.) */
 int tfhe_amd_set_stream(tfhe_amd_ctx *ctx, void *hip_stream);
 int tfhe_amd_sync(tfhe_amd_ctx *ctx);
 /* Scheduling options.  They select among kernels that compute the SAME results bit for bit.  (The
@@ -300,6 +306,7 @@ typedef struct tfhe_amd_cb tfhe_amd_cb;
 int tfhe_amd_cb_create(const tfhe_amd_cb_params *params, int device, tfhe_amd_cb **out);
 void tfhe_amd_cb_destroy(tfhe_amd_cb *cb);
 const char *tfhe_amd_cb_last_error(const tfhe_amd_cb *cb);
+/* both levels' contexts onto one stream; like tfhe_amd_set_stream the switch neither waits nor orders: see there */
 int tfhe_amd_cb_set_stream(tfhe_amd_cb *cb, void *hip_stream);
 int tfhe_amd_cb_sync(tfhe_amd_cb *cb);
 /* the two single-level contexts inside (borrowed, do not destroy): Torus32 lvl1->lvl0 context

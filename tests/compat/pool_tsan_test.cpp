@@ -79,6 +79,10 @@ int main() {
         if (out[0] != -1) bad++;  // nothing ran
         if (tfhe_amd_pool_load_keys(pool, nullptr, &ks) != TFHE_AMD_OK) bad++;  // the other key loads, the failed one is still owed
         if (tfhe_amd_pool_bootstrap_host(pool, out.data(), MU, x.data(), 8) != TFHE_AMD_ERR_STATE) bad++;
+        // ... while the operation that reads only the key every member now holds does run (each checks the keys IT uses)
+        std::vector<int32_t> kin((size_t)8 * (N + 1), 1), kout((size_t)8 * (n + 1), -1);
+        if (tfhe_amd_pool_keyswitch_host(pool, kout.data(), kin.data(), 8) != TFHE_AMD_OK) bad++;
+        if (tfhe_amd_pool_bootstrap_woks_host(pool, kin.data(), MU, x.data(), 8) != TFHE_AMD_ERR_STATE) bad++;  // (uses the mixed one)
         pool_mock_fail_key_load_on_device = -1;
         if (tfhe_amd_pool_load_keys(pool, &bk, nullptr) != TFHE_AMD_OK) bad++;
         if (tfhe_amd_pool_bootstrap_host(pool, out.data(), MU, x.data(), 8) != TFHE_AMD_OK) bad++;

@@ -252,6 +252,23 @@ def test_pool_errors(emu_lib):
         pool.close()
 
 
+def test_pool_uniform_load_failure_is_not_a_mixed_state(emu_lib):
+    """a key load refused by EVERY member alike (here: a key-switch key offered to contexts without key-switch parameters) leaves
+    all members with what they had -- nothing differs between them, so the operations on the key that did load keep running"""
+    N, n, l, Bgbit = 1024, 2, 2, 10
+    lk, tk = O.keygen_binary(n, P.SEED, 1), O.keygen_binary(N, P.SEED, 2)
+    bk = O.bk_create32(N, lk, tk, l, Bgbit, 2.0 ** -25, P.SEED, 1000)
+    pool = T.Pool([2, 4], torus_bits=32, n=n, N=N, l=l, Bgbit=Bgbit, ks_t=0, lib_path=emu_lib)
+    try:
+        with pytest.raises(T.TfheAmdError, match="no key-switch parameters"):
+            pool.load_keys(bk, np.zeros(16, np.int32))  # bk loads everywhere, ks is refused everywhere
+        x = np.random.RandomState(3).randint(-2 ** 31, 2 ** 31, size=(3, n + 1)).astype(np.int32)
+        want = np.stack([O.bootstrap_woks32(N, bk, 1 << 29, x[i], l, Bgbit) for i in range(3)])
+        assert np.array_equal(pool.bootstrap_woks(1 << 29, x), want)
+    finally:
+        pool.close()
+
+
 def test_circuit_bootstrap_pool(emu_lib):
     n0, N1, N2, l1, bg1, l2, bg2, t10, bb10, t21, bb21 = 2, 1024, 1024, 2, 8, 3, 10, 2, 2, 2, 3
     key0, key2 = O.keygen_binary(n0, P.SEED, 21), O.keygen_binary(N2, P.SEED, 23)
