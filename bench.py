@@ -86,7 +86,7 @@ FP64_PEAK = 78.6e12      # flop/s vector fp64 (256 CU x 128 flop/clk x 2.4 GHz)
 BYTES_PER_CMUX = 16388   # acc read+write 16,384 + rotation 4
 BYTES_PER_ROW = 65536    # bootstrapping-key row, once per CMux per launch
 FLOP_PER_CMUX = 173056
-FP64_INSTR_PER_CMUX = 2144  # v_*_f64 wave-instructions per CMux per sample: floor of the bit-exact radix-2 DAG
+FP64_INSTR_PER_CMUX = 2144  # v_*_f64 wave-instructions per CMux per sample: floor of the bit-exact radix-2 DAG (docs/experiments.md, measured bound of the gate kernel)
 FP64_ISSUE_CYCLES = 4       # cycles per wave64 fp64 instruction on one SIMD
 SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 
@@ -95,7 +95,7 @@ def kernel_sources_sha256():
     """identity of the kernel sources a PMC traffic figure belongs to (tools/make_traffic.py writes the same hash)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("tfhe_kernels.h", "tfhe_amd.hip", "devport.h"):
+    for f in ("tfhe_kernels.h", "tfhe_kernels_generic.h", "tfhe_amd.hip", "devport.h"):
         with open(os.path.join(ROOT, "experimental-tfhe_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -946,7 +946,7 @@ def main():
                                         "floor_cmux_per_s": fp64_instr_peak / FP64_INSTR_PER_CMUX,
                                         "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64 instruction; 2,144 such "
                                                 "instructions per CMux per sample is the floor of the reference's radix-2 DAG "
-                                                "reproduced bit for bit (DESIGN.md 2)"}},
+                                                "reproduced bit for bit (docs/experiments.md, measured bound of the gate kernel)"}},
             "kernels_ms": {"blind_rotate_extract": br_ms, "keyswitch": ks_ms},
             "decrypt_check": bool(ok),
             "oracle_bit_check": None if oracle_want is None else {"samples": len(oracle_idx), "identical": oracle_ok},

@@ -2,7 +2,7 @@
 // full signatures, `const Globals* env` included, served by the MI355X engine:
 //     preKeySwitch           CB/poc_CircuitBootstrapping.cpp:437-465
 //     preModSwitch           :472-484
-//     circuitBootstrapWoKS   :530-659  (library rotation semantics)
+//     circuitBootstrapWoKS   :530-659  (library rotation semantics, DESIGN.md section 1, "PoC defects")
 //     circuitPrivKS          :667-698
 //     tfhe_CircuitBootstrapFFT :823-873  (+ _array: the driver loop :1009-1013 over `count` samples as one launch)
 //     CMux                   :877-879 (empty upstream)

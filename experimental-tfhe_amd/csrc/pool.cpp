@@ -148,7 +148,7 @@ constexpr int DEFAULT_CHUNK_ROWS = 2048;
 // alternating on two streams -- first: there the key switch of chunk k waits for a CU behind the blind rotation of chunk k + 1,
 // which has taken every CU's LDS, and the host learns of chunk k a whole chunk late.  Both forms measure 0.92-0.95 of the
 // device-resident rate; this one keeps the kernel order of the resident loop and the reason for what is left is plain: the
-// head and tail of a call and the key switch's lower efficiency at 2048 samples -- DESIGN.md 7a.)
+// head and tail of a call and the key switch's lower efficiency at 2048 samples -- DESIGN.md section 7, docs/experiments.md.)
 // launch(set, d_out, d_in, rows) issues the kernels on the context's current stream and may use set.d_mid; it must not touch
 // the context's own scratch.
 constexpr int SETS = 3;

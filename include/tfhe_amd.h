@@ -397,7 +397,7 @@ int tfhe_amd_cb_pool_circuit_bootstrap_rows(tfhe_amd_cb_pool *pool, tfhe_amd_row
 int tfhe_amd_cb_pool_set_option(tfhe_amd_cb_pool *pool, int option, int value);
 
 /* ---- harness: synthetic keys and samples (the reference's keygen/encrypt/phase,
- *      poc:88-134,191-227,342-423; PRNG spec in DESIGN.md) -- host side ------------------ */
+ *      poc:88-134,191-227,342-423; PRNG: splitmix64, one stream per key element, csrc/keygen.cpp) -- host side ------------------ */
 int tfhe_amd_keygen_binary(int32_t *key, int n, uint64_t seed, uint64_t stream);
 int tfhe_amd_lwe_encrypt32(int32_t *ct, int32_t mess, double stdev, const int32_t *key, int n,
                            uint64_t seed, uint64_t stream);

@@ -34,7 +34,7 @@
 // Errors: the reference returns void and asserts/aborts (lwe_functions.cpp:480-481,
 // spqlios-fft-impl.cpp:92-97); the shims do the same (message on stderr, abort()).
 // circuitBootstrapWoKS follows the LIBRARY rotation semantics, not the PoC's defective loop
-// (DESIGN.md section 6).
+// ("PoC defects").
 #ifndef TFHE_AMD_COMPAT_HPP
 #define TFHE_AMD_COMPAT_HPP
 

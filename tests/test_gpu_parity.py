@@ -328,8 +328,6 @@ def test_batch_4096_properties(gpu_lib):
         want_sign = np.tile(np.array(msgs) > 0, B // base)
         assert np.array_equal(ph > 0, want_sign), "decrypt-sign"
         assert np.abs(np.abs(ph.astype(np.int64)) - mu).max() < mu // 2
-        for i in range(base, B):
-            pass
         assert np.array_equal(out, np.tile(out[:base], (B // base, 1))), "position independence"
         sub = rs.choice(base, 12, replace=False)
         want = np.stack([O.bootstrap32(N, s.bk, s.ks, mu, xb[i], l, Bgbit, t, bb) for i in sub])

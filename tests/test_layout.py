@@ -1,7 +1,7 @@
 """Static properties of the kernels' LDS layout (no GPU): the padded transpose indices are
 permutations and, under the gfx950 banking rules of MI355X_MICROARCH.md, free of bank conflicts
 for every ds_write_b64 / ds_read_b64 (8-byte planes) and ds_write_b128 / ds_read_b128 (complex points,
-N=1024) of both transposes in both directions (DESIGN.md section 4)."""
+N=1024) of both transposes in both directions (DESIGN.md section 2)."""
 import os
 import subprocess
 import sys

@@ -1,6 +1,6 @@
 // ubench_acc_roundtrip.hip -- what would it cost the Torus64 blind rotation (k_blind_rotate<long,11,4,1>: one wave per
 // ciphertext, one wave per SIMD, 32 KB accumulator in 128 registers) to keep its accumulator in global memory between
-// CMux steps instead?  (DESIGN.md section 11, item 3.  Diagnostic tool, not part of the product.)
+// CMux steps instead?  (docs/experiments.md, round 4.  Diagnostic tool, not part of the product.)
 //
 // 1024 waves (256 workgroups x 4 waves, one workgroup per CU pinned by LDS), each owning one 32 KB accumulator of a
 // 32 MB buffer; `steps` dependent steps, each streaming a 256 KB key row (shared by all waves, as the kernel does:

@@ -5,7 +5,7 @@
 //   down  the same chain, k descending
 //   exact the exactly rounded value of c + sum a_k b_k (long double / compensated, one rounding)
 //   pair  fma(a0,b0, fma(a1,b1,.)) style two-level trees are not tried: "up" or "down" matching everywhere answers the question
-// The blind rotation's MAC (lagrangehalfc_impl_fma.s:96-107) is such a chain; DESIGN.md section 2 states why the matrix
+// The blind rotation's MAC (lagrangehalfc_impl_fma.s:96-107) is such a chain; DESIGN.md section 3 / docs/experiments.md state why the matrix
 // cores are not used for it -- this program is the measurement behind that sentence.
 #include <hip/hip_runtime.h>
 #include <math.h>
