@@ -25,53 +25,46 @@ TFHE_DEVICE int modswitch_rt(int32_t phase, int logn) {
     return (int)((((uint64_t)(uint32_t)phase << 32) + half) >> sh);
 }
 
-// ---- the two multiplication-free layers on one group of four consecutive points
-// inverse: size-4 (spqlios-ifft-fma.s:194-213) then size-2 (:247-263)
-TFHE_DEVICE void gen_ifft_tail4(double *re, double *im) {
-    const double r0 = re[0], r1 = re[1], r2 = re[2], r3 = re[3];
-    const double i0 = im[0], i1 = im[1], i2 = im[2], i3 = im[3];
-    const double a0 = r0 + r2, a1 = r1 + r3, a2 = r0 - r2, a3 = i3 - i1;
-    const double b0 = i0 + i2, b1 = i1 + i3, b2 = i0 - i2, b3 = r1 - r3;
-    re[0] = a0 + a1;
-    re[1] = a0 - a1;
-    re[2] = a2 + a3;
-    re[3] = a2 - a3;
-    im[0] = b0 + b1;
-    im[1] = b0 - b1;
-    im[2] = b2 + b3;
-    im[3] = b2 - b3;
-}
-// direct: size-2 (spqlios-fft-fma.s:79-95) then size-4 (:134-152)
-TFHE_DEVICE void gen_fft_head4(double *re, double *im) {
-    const double r0 = re[0] + re[1], r1 = re[0] - re[1], r2 = re[2] + re[3], r3 = re[2] - re[3];
-    const double i0 = im[0] + im[1], i1 = im[0] - im[1], i2 = im[2] + im[3], i3 = im[2] - im[3];
-    re[0] = r0 + r2;
-    re[1] = r1 + i3;
-    re[2] = r0 - r2;
-    re[3] = r1 - i3;
-    im[0] = i0 + i2;
-    im[1] = i1 - r3;
-    im[2] = i0 - i2;
-    im[3] = i1 + r3;
-}
-
-// Coefficient -> Lagrange, in place, for `np` polynomials `pstride` doubles apart; each is re[0..NC) | im[0..NC) and holds
-// a_j + i a_{j+NC} on entry (the fold of spqlios-ifft-fma.s:40-44 is the storage order itself).  A team of `tpp`
-// work-items (this one is number `lt`) shares the work; EVERY work-item of the workgroup must call this (the barriers
-// are workgroup barriers), `active` = false for those whose team has no polynomial.  tw: the kernels' table
-// (tfhe_amd.hip build_tables: [0,NC) twist, half-size h at 2 NC - 2 h).  The caller has synchronised its writes; on
-// return every result is visible to the whole workgroup.
-// Barriers: the layers are the reference's radix-2 layers, node for node, but a work-item carries its points through
-// TWO layers (four points) between barriers, and through the last three (h = 4, size 4, size 2: eight consecutive points).
+// ---- work buffers hold one 16-byte complex point per element (re = coefficient / position j, im = j + N/2 of the reference's
+// split storage): one ds_read_b128 / ds_write_b128 per point
 struct GenC {
     double r, i;
 };
-TFHE_DEVICE GenC gen_ld(const double *re, int NC, int j) { return GenC{re[j], re[NC + j]}; }
-TFHE_DEVICE void gen_st(double *re, int NC, int j, const GenC &v) {
-    re[j] = v.r;
-    re[NC + j] = v.i;
+TFHE_DEVICE GenC gen_ld(const double2 *buf, int j) {
+    const double2 v = buf[j];
+    return GenC{v.x, v.y};
 }
-TFHE_DEVICE void gen_ifft(double *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active) {
+TFHE_DEVICE void gen_st(double2 *buf, int j, const GenC &v) { buf[j] = make_double2(v.r, v.i); }
+// the two multiplication-free layers on one group of four consecutive points
+// inverse: size-4 (spqlios-ifft-fma.s:194-213) then size-2 (:247-263)
+TFHE_DEVICE void gen_ifft_tail4(GenC (&x)[4]) {
+    const double r0 = x[0].r, r1 = x[1].r, r2 = x[2].r, r3 = x[3].r;
+    const double i0 = x[0].i, i1 = x[1].i, i2 = x[2].i, i3 = x[3].i;
+    const double a0 = r0 + r2, a1 = r1 + r3, a2 = r0 - r2, a3 = i3 - i1;
+    const double b0 = i0 + i2, b1 = i1 + i3, b2 = i0 - i2, b3 = r1 - r3;
+    x[0] = GenC{a0 + a1, b0 + b1};
+    x[1] = GenC{a0 - a1, b0 - b1};
+    x[2] = GenC{a2 + a3, b2 + b3};
+    x[3] = GenC{a2 - a3, b2 - b3};
+}
+// direct: size-2 (spqlios-fft-fma.s:79-95) then size-4 (:134-152)
+TFHE_DEVICE void gen_fft_head4(GenC (&x)[4]) {
+    const double r0 = x[0].r + x[1].r, r1 = x[0].r - x[1].r, r2 = x[2].r + x[3].r, r3 = x[2].r - x[3].r;
+    const double i0 = x[0].i + x[1].i, i1 = x[0].i - x[1].i, i2 = x[2].i + x[3].i, i3 = x[2].i - x[3].i;
+    x[0] = GenC{r0 + r2, i0 + i2};
+    x[1] = GenC{r1 + i3, i1 - r3};
+    x[2] = GenC{r0 - r2, i0 - i2};
+    x[3] = GenC{r1 - i3, i1 + r3};
+}
+
+// Coefficient -> Lagrange, in place, for `np` polynomials `pstride` points apart; each is NC complex points holding
+// a_j + i a_{j+NC} on entry (the fold of spqlios-ifft-fma.s:40-44).  A team of `tpp` work-items (this one is number `lt`)
+// shares the work; EVERY work-item of the workgroup must call this (the barriers are workgroup barriers), `active` = false
+// for those whose team has no polynomial.  tw: the kernels' table (tfhe_amd.hip build_tables: [0,NC) twist, half-size h at
+// 2 NC - 2 h).  The caller has synchronised its writes; on return every result is visible to the whole workgroup.
+// Barriers: the layers are the reference's radix-2 layers, node for node, but a work-item carries its points through
+// TWO layers (four points) between barriers, and through the last three (h = 4, size 4, size 2: eight consecutive points).
+TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active) {
     {  // layer h = NC/2 with the twist by omega^j (spqlios-ifft-fma.s:63-78) fused: its butterfly owns both points
         const int h = NC >> 1;
         if (active) {
@@ -79,15 +72,15 @@ TFHE_DEVICE void gen_ifft(double *buf, int np, long pstride, int NC, const doubl
             for (int bf = lt; bf < h; bf += tpp) {
                 const double2 w = ts[bf], w1 = tw[bf], w2 = tw[bf + h];
                 for (int p = 0; p < np; p++) {
-                    double *re = buf + p * pstride;
-                    GenC a = gen_ld(re, NC, bf), b = gen_ld(re, NC, bf + h);
+                    double2 *x = buf + p * pstride;
+                    GenC a = gen_ld(x, bf), b = gen_ld(x, bf + h);
                     const GenC ta{__builtin_fma(-a.i, w1.y, a.r * w1.x), __builtin_fma(a.i, w1.x, a.r * w1.y)};
                     const GenC tb{__builtin_fma(-b.i, w2.y, b.r * w2.x), __builtin_fma(b.i, w2.x, b.r * w2.y)};
                     a = ta;
                     b = tb;
                     dif_bfly(a.r, a.i, b.r, b.i, w.x, w.y);
-                    gen_st(re, NC, bf, a);
-                    gen_st(re, NC, bf + h, b);
+                    gen_st(x, bf, a);
+                    gen_st(x, bf + h, b);
                 }
             }
         }
@@ -103,11 +96,11 @@ TFHE_DEVICE void gen_ifft(double *buf, int np, long pstride, int NC, const doubl
                     const int off = bf & (h - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + h;
                     const double2 w = ts[off];
                     for (int p = 0; p < np; p++) {
-                        double *re = buf + p * pstride;
-                        GenC a = gen_ld(re, NC, i1), b = gen_ld(re, NC, i2);
+                        double2 *x = buf + p * pstride;
+                        GenC a = gen_ld(x, i1), b = gen_ld(x, i2);
                         dif_bfly(a.r, a.i, b.r, b.i, w.x, w.y);
-                        gen_st(re, NC, i1, a);
-                        gen_st(re, NC, i2, b);
+                        gen_st(x, i1, a);
+                        gen_st(x, i2, b);
                     }
                 }
             }
@@ -122,17 +115,16 @@ TFHE_DEVICE void gen_ifft(double *buf, int np, long pstride, int NC, const doubl
                     const int off = q4 & (hh - 1), base = ((q4 - off) << 2) + off;
                     const double2 wa0 = ta[off], wa1 = ta[off + hh], wb = tb[off];
                     for (int p = 0; p < np; p++) {
-                        double *re = buf + p * pstride;
-                        GenC x0 = gen_ld(re, NC, base), x1 = gen_ld(re, NC, base + hh), x2 = gen_ld(re, NC, base + h),
-                             x3 = gen_ld(re, NC, base + h + hh);
+                        double2 *x = buf + p * pstride;
+                        GenC x0 = gen_ld(x, base), x1 = gen_ld(x, base + hh), x2 = gen_ld(x, base + h), x3 = gen_ld(x, base + h + hh);
                         dif_bfly(x0.r, x0.i, x2.r, x2.i, wa0.x, wa0.y);
                         dif_bfly(x1.r, x1.i, x3.r, x3.i, wa1.x, wa1.y);
                         dif_bfly(x0.r, x0.i, x1.r, x1.i, wb.x, wb.y);
                         dif_bfly(x2.r, x2.i, x3.r, x3.i, wb.x, wb.y);
-                        gen_st(re, NC, base, x0);
-                        gen_st(re, NC, base + hh, x1);
-                        gen_st(re, NC, base + h, x2);
-                        gen_st(re, NC, base + h + hh, x3);
+                        gen_st(x, base, x0);
+                        gen_st(x, base + hh, x1);
+                        gen_st(x, base + h, x2);
+                        gen_st(x, base + h + hh, x3);
                     }
                 }
             }
@@ -144,13 +136,19 @@ TFHE_DEVICE void gen_ifft(double *buf, int np, long pstride, int NC, const doubl
             const double2 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
             for (int g = lt; g < (NC >> 3); g += tpp) {
                 for (int p = 0; p < np; p++) {
-                    double *re = buf + p * pstride + 8 * g, *im = re + NC;
-                    dif_bfly(re[0], im[0], re[4], im[4], w0.x, w0.y);
-                    dif_bfly(re[1], im[1], re[5], im[5], w1.x, w1.y);
-                    dif_bfly(re[2], im[2], re[6], im[6], w2.x, w2.y);
-                    dif_bfly(re[3], im[3], re[7], im[7], w3.x, w3.y);
-                    gen_ifft_tail4(re, im);
-                    gen_ifft_tail4(re + 4, im + 4);
+                    double2 *x = buf + p * pstride + 8 * g;
+                    GenC lo[4] = {gen_ld(x, 0), gen_ld(x, 1), gen_ld(x, 2), gen_ld(x, 3)};
+                    GenC hi[4] = {gen_ld(x, 4), gen_ld(x, 5), gen_ld(x, 6), gen_ld(x, 7)};
+                    dif_bfly(lo[0].r, lo[0].i, hi[0].r, hi[0].i, w0.x, w0.y);
+                    dif_bfly(lo[1].r, lo[1].i, hi[1].r, hi[1].i, w1.x, w1.y);
+                    dif_bfly(lo[2].r, lo[2].i, hi[2].r, hi[2].i, w2.x, w2.y);
+                    dif_bfly(lo[3].r, lo[3].i, hi[3].r, hi[3].i, w3.x, w3.y);
+                    gen_ifft_tail4(lo);
+                    gen_ifft_tail4(hi);
+                    for (int k = 0; k < 4; k++) {
+                        gen_st(x, k, lo[k]);
+                        gen_st(x, 4 + k, hi[k]);
+                    }
                 }
             }
         }
@@ -159,14 +157,19 @@ TFHE_DEVICE void gen_ifft(double *buf, int np, long pstride, int NC, const doubl
     }
     if (active) {  // NC = 8: the fused first layer was h = 4
         for (int g = lt; g < (NC >> 2); g += tpp)
-            for (int p = 0; p < np; p++) gen_ifft_tail4(buf + p * pstride + 4 * g, buf + p * pstride + NC + 4 * g);
+            for (int p = 0; p < np; p++) {
+                double2 *x = buf + p * pstride + 4 * g;
+                GenC v[4] = {gen_ld(x, 0), gen_ld(x, 1), gen_ld(x, 2), gen_ld(x, 3)};
+                gen_ifft_tail4(v);
+                for (int k = 0; k < 4; k++) gen_st(x, k, v[k]);
+            }
     }
     __syncthreads();
 }
 
 // Lagrange -> coefficient, in place (the caller has applied the 2/N scale); same calling rules as gen_ifft.
 // (the reference's fft table is the conjugate of its ifft table except cos at the quarter turn: flip_sign_if)
-TFHE_DEVICE void gen_fft(double *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active) {
+TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active) {
     if (NC > 8) {
         // size 2, size 4, then layer h = 4, on eight consecutive points
         if (active) {
@@ -174,13 +177,19 @@ TFHE_DEVICE void gen_fft(double *buf, int np, long pstride, int NC, const double
             const double2 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
             for (int g = lt; g < (NC >> 3); g += tpp) {
                 for (int p = 0; p < np; p++) {
-                    double *re = buf + p * pstride + 8 * g, *im = re + NC;
-                    gen_fft_head4(re, im);
-                    gen_fft_head4(re + 4, im + 4);
-                    dit_bfly(re[0], im[0], re[4], im[4], w0.x, w0.y);
-                    dit_bfly(re[1], im[1], re[5], im[5], w1.x, w1.y);
-                    dit_bfly(re[2], im[2], re[6], im[6], -w2.x, w2.y);  // quarter turn: off == h/2
-                    dit_bfly(re[3], im[3], re[7], im[7], w3.x, w3.y);
+                    double2 *x = buf + p * pstride + 8 * g;
+                    GenC lo[4] = {gen_ld(x, 0), gen_ld(x, 1), gen_ld(x, 2), gen_ld(x, 3)};
+                    GenC hi[4] = {gen_ld(x, 4), gen_ld(x, 5), gen_ld(x, 6), gen_ld(x, 7)};
+                    gen_fft_head4(lo);
+                    gen_fft_head4(hi);
+                    dit_bfly(lo[0].r, lo[0].i, hi[0].r, hi[0].i, w0.x, w0.y);
+                    dit_bfly(lo[1].r, lo[1].i, hi[1].r, hi[1].i, w1.x, w1.y);
+                    dit_bfly(lo[2].r, lo[2].i, hi[2].r, hi[2].i, -w2.x, w2.y);  // quarter turn: off == h/2
+                    dit_bfly(lo[3].r, lo[3].i, hi[3].r, hi[3].i, w3.x, w3.y);
+                    for (int k = 0; k < 4; k++) {
+                        gen_st(x, k, lo[k]);
+                        gen_st(x, 4 + k, hi[k]);
+                    }
                 }
             }
         }
@@ -198,17 +207,16 @@ TFHE_DEVICE void gen_fft(double *buf, int np, long pstride, int NC, const double
                     const double wac = flip_sign_if(wa.x, off == (h >> 1));
                     const double wb1c = flip_sign_if(wb1.x, off == 0);  // off + h == h2 / 2
                     for (int p = 0; p < np; p++) {
-                        double *re = buf + p * pstride;
-                        GenC x0 = gen_ld(re, NC, base), x1 = gen_ld(re, NC, base + h), x2 = gen_ld(re, NC, base + h2),
-                             x3 = gen_ld(re, NC, base + h2 + h);
+                        double2 *x = buf + p * pstride;
+                        GenC x0 = gen_ld(x, base), x1 = gen_ld(x, base + h), x2 = gen_ld(x, base + h2), x3 = gen_ld(x, base + h2 + h);
                         dit_bfly(x0.r, x0.i, x1.r, x1.i, wac, wa.y);
                         dit_bfly(x2.r, x2.i, x3.r, x3.i, wac, wa.y);
                         dit_bfly(x0.r, x0.i, x2.r, x2.i, wb0.x, wb0.y);
                         dit_bfly(x1.r, x1.i, x3.r, x3.i, wb1c, wb1.y);
-                        gen_st(re, NC, base, x0);
-                        gen_st(re, NC, base + h, x1);
-                        gen_st(re, NC, base + h2, x2);
-                        gen_st(re, NC, base + h2 + h, x3);
+                        gen_st(x, base, x0);
+                        gen_st(x, base + h, x1);
+                        gen_st(x, base + h2, x2);
+                        gen_st(x, base + h2 + h, x3);
                     }
                 }
             }
@@ -222,11 +230,11 @@ TFHE_DEVICE void gen_fft(double *buf, int np, long pstride, int NC, const double
                     const double2 w = ts[off];
                     const double wc = flip_sign_if(w.x, off == (h >> 1));
                     for (int p = 0; p < np; p++) {
-                        double *re = buf + p * pstride;
-                        GenC a = gen_ld(re, NC, i1), b = gen_ld(re, NC, i2);
+                        double2 *x = buf + p * pstride;
+                        GenC a = gen_ld(x, i1), b = gen_ld(x, i2);
                         dit_bfly(a.r, a.i, b.r, b.i, wc, w.y);
-                        gen_st(re, NC, i1, a);
-                        gen_st(re, NC, i2, b);
+                        gen_st(x, i1, a);
+                        gen_st(x, i2, b);
                     }
                 }
             }
@@ -235,7 +243,12 @@ TFHE_DEVICE void gen_fft(double *buf, int np, long pstride, int NC, const double
     } else {
         if (active) {
             for (int g = lt; g < (NC >> 2); g += tpp)
-                for (int p = 0; p < np; p++) gen_fft_head4(buf + p * pstride + 4 * g, buf + p * pstride + NC + 4 * g);
+                for (int p = 0; p < np; p++) {
+                    double2 *x = buf + p * pstride + 4 * g;
+                    GenC v[4] = {gen_ld(x, 0), gen_ld(x, 1), gen_ld(x, 2), gen_ld(x, 3)};
+                    gen_fft_head4(v);
+                    for (int k = 0; k < 4; k++) gen_st(x, k, v[k]);
+                }
         }
         __syncthreads();
     }
@@ -247,13 +260,13 @@ TFHE_DEVICE void gen_fft(double *buf, int np, long pstride, int NC, const double
                 const double2 w = ts[bf], w1 = tw[bf], w2 = tw[bf + h];
                 const double wc = flip_sign_if(w.x, bf == (h >> 1));
                 for (int p = 0; p < np; p++) {
-                    double *re = buf + p * pstride;
-                    GenC a = gen_ld(re, NC, bf), b = gen_ld(re, NC, bf + h);
+                    double2 *x = buf + p * pstride;
+                    GenC a = gen_ld(x, bf), b = gen_ld(x, bf + h);
                     dit_bfly(a.r, a.i, b.r, b.i, wc, w.y);
                     const double arc = a.r * w1.x, ars = a.r * w1.y, aic = a.i * w1.x, ais = a.i * w1.y;
                     const double brc = b.r * w2.x, brs = b.r * w2.y, bic = b.i * w2.x, bis = b.i * w2.y;
-                    gen_st(re, NC, bf, GenC{arc + ais, aic - ars});
-                    gen_st(re, NC, bf + h, GenC{brc + bis, bic - brs});
+                    gen_st(x, bf, GenC{arc + ais, aic - ars});
+                    gen_st(x, bf + h, GenC{brc + bis, bic - brs});
                 }
             }
         }
@@ -278,16 +291,13 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
     const int tpp = gen_team_size(NC), teams = GEN_BLOCK / tpp;
     const int team = (int)threadIdx.x / tpp, lt = (int)threadIdx.x - team * tpp;
     TFHE_DYN_LDS(smem);
-    double *buf = (LDS ? reinterpret_cast<double *>(smem) : work + (size_t)blockIdx.x * teams * N) + (size_t)team * N;
+    double2 *buf = reinterpret_cast<double2 *>(LDS ? reinterpret_cast<double *>(smem) : work + (size_t)blockIdx.x * teams * N) + (size_t)team * NC;
     for (int b0 = (int)blockIdx.x * teams; b0 < batch; b0 += (int)gridDim.x * teams) {  // workgroup-uniform
         const int b = b0 + team;
         const bool active = b < batch;
         if (active) {
             const TIN *p = in + (size_t)b * N;
-            for (int j = lt; j < NC; j += tpp) {
-                buf[j] = (double)p[j];
-                buf[NC + j] = (double)p[j + NC];
-            }
+            for (int j = lt; j < NC; j += tpp) buf[j] = make_double2((double)p[j], (double)p[j + NC]);
         }
         __syncthreads();
         gen_ifft(buf, 1, 0, NC, tw, lt, tpp, active);
@@ -295,10 +305,14 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
             if (PACK) {
                 double2 *o = reinterpret_cast<double2 *>(out) + (size_t)b * NC;
                 const double scale = 2.0 / (double)N;  // exact: a power of two
-                for (int j = lt; j < NC; j += tpp) o[j] = make_double2(buf[j] * scale, buf[NC + j] * scale);
+                for (int j = lt; j < NC; j += tpp) o[j] = make_double2(buf[j].x * scale, buf[j].y * scale);
             } else {
                 double *o = out + (size_t)b * N;
-                for (int j = lt; j < N; j += tpp) o[j] = buf[j];
+                for (int j = lt; j < NC; j += tpp) {
+                    const double2 v = buf[j];
+                    o[j] = v.x;
+                    o[NC + j] = v.y;
+                }
             }
         }
         __syncthreads();  // the buffer is refilled by the next polynomial
@@ -316,23 +330,28 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
     const int team = (int)threadIdx.x / tpp, lt = (int)threadIdx.x - team * tpp;
     constexpr bool RAW = std::is_same<TOUT, double>::value;
     TFHE_DYN_LDS(smem);
-    double *buf = (LDS ? reinterpret_cast<double *>(smem) : work + (size_t)blockIdx.x * teams * N) + (size_t)team * N;
+    double2 *buf = reinterpret_cast<double2 *>(LDS ? reinterpret_cast<double *>(smem) : work + (size_t)blockIdx.x * teams * N) + (size_t)team * NC;
     const double scale = 2.0 / (double)N;  // fft_processor_spqlios.cpp:78
     for (int b0 = (int)blockIdx.x * teams; b0 < batch; b0 += (int)gridDim.x * teams) {
         const int b = b0 + team;
         const bool active = b < batch;
         if (active) {
             const double *p = in + (size_t)b * N;
-            for (int j = lt; j < N; j += tpp) buf[j] = RAW ? p[j] : p[j] * scale;
+            for (int j = lt; j < NC; j += tpp) buf[j] = RAW ? make_double2(p[j], p[NC + j]) : make_double2(p[j] * scale, p[NC + j] * scale);
         }
         __syncthreads();
         gen_fft(buf, 1, 0, NC, tw, lt, tpp, active);
         if (active) {
             TOUT *o = out + (size_t)b * N;
-            if constexpr (RAW) {
-                for (int j = lt; j < N; j += tpp) o[j] = buf[j];
-            } else {
-                for (int j = lt; j < N; j += tpp) o[j] = Torus<TOUT>::from_double(buf[j]);
+            for (int j = lt; j < NC; j += tpp) {
+                const double2 v = buf[j];
+                if constexpr (RAW) {
+                    o[j] = v.x;
+                    o[NC + j] = v.y;
+                } else {
+                    o[j] = Torus<TOUT>::from_double(v.x);
+                    o[NC + j] = Torus<TOUT>::from_double(v.y);
+                }
             }
         }
         __syncthreads();
@@ -379,11 +398,11 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
     TFHE_DYN_LDS(smem);
     const int nd = G.nd;
     T *acc;
-    double *dig, *fac;
+    double2 *dig, *fac;  // [nd][NC] and [2][NC] complex points
     if constexpr (ALL_LDS) {
         acc = reinterpret_cast<T *>(smem);
-        dig = reinterpret_cast<double *>(smem + sizeof(T) * 2 * (size_t)N);
-        fac = dig + (size_t)nd * N;
+        dig = reinterpret_cast<double2 *>(smem + sizeof(T) * 2 * (size_t)N);
+        fac = dig + (size_t)nd * NC;
     } else {
         unsigned char *wsl = G.work ? G.work + (size_t)blockIdx.x * (size_t)G.work_stride : nullptr;
         size_t woff = 0;
@@ -394,8 +413,8 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
             return p;
         };
         acc = reinterpret_cast<T *>(place(G.acc_lds, sizeof(T) * 2 * (size_t)N));
-        dig = reinterpret_cast<double *>(place(G.dig_lds, sizeof(double) * (size_t)nd * N));
-        fac = reinterpret_cast<double *>(place(G.fac_lds, sizeof(double) * 2 * (size_t)N));
+        dig = reinterpret_cast<double2 *>(place(G.dig_lds, sizeof(double) * (size_t)nd * N));
+        fac = reinterpret_cast<double2 *>(place(G.fac_lds, sizeof(double) * 2 * (size_t)N));
     }
     const U offset = (U)A.gd.offset;
     const int Bgbit = A.gd.Bgbit, l = A.gd.l;
@@ -460,57 +479,59 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
                 for (int e = 0; e < nd; e++) {
                     const int q = (p0 + e) / l, d = (p0 + e) - q * l;
                     const T *pa = acc + q * N;
-                    double *dg = dig + (size_t)e * N;
+                    double2 *dg = dig + (size_t)e * NC;
                     const int decal = BITS - (d + 1) * Bgbit;
                     // digit d of polynomial q of (X^a - 1) * acc (numeric_functions.cpp:304-323), or of acc itself;
-                    // decomposition tgsw_functions.cpp:224-337 / poc:492-515 (offset from the host)
-                    for (int j = tid; j < N; j += nt) {
+                    // decomposition tgsw_functions.cpp:224-337 / poc:492-515 (offset from the host); point j = (coef j, coef j + N/2)
+                    auto digit = [&](int j) {
                         U v = (U)pa[j];
                         if (rotate) {
                             const int idx = (j - a) & (2 * N - 1);
                             const U src = (U)pa[idx & (N - 1)];
                             v = ((idx & N) ? (U)(0 - src) : src) - v;
                         }
-                        dg[j] = (double)((int32_t)(((U)(v + offset) >> decal) & mask) - halfBg);
-                    }
+                        return (double)((int32_t)(((U)(v + offset) >> decal) & mask) - halfBg);
+                    };
+                    for (int j = tid; j < NC; j += nt) dg[j] = make_double2(digit(j), digit(j + NC));
                 }
                 __syncthreads();
-                gen_ifft(dig, nd, N, NC, A.tw, tid, nt, true);
+                gen_ifft(dig, nd, NC, NC, A.tw, tid, nt, true);
                 // tLweFFTAddMulRTo (tlwe_functions.cpp:318-325), both output polynomials, on an accumulator that starts as
                 // the +0 of tLweFFTClear (tgsw_functions.cpp:438)
                 for (int j = tid; j < NC; j += nt) {
-                    double fr0 = 0.0, fi0 = 0.0, fr1 = 0.0, fi1 = 0.0;
+                    double2 f0 = make_double2(0.0, 0.0), f1 = make_double2(0.0, 0.0);
                     if (p0) {
-                        fr0 = fac[j];
-                        fi0 = fac[NC + j];
-                        fr1 = fac[N + j];
-                        fi1 = fac[N + NC + j];
+                        f0 = fac[j];
+                        f1 = fac[NC + j];
                     }
                     for (int e = 0; e < nd; e++) {
-                        const double ar = dig[(size_t)e * N + j], ai = dig[(size_t)e * N + NC + j];
+                        const double2 x = dig[(size_t)e * NC + j];
+                        const double ar = x.x, ai = x.y;
                         const double2 *row = bkrow + (size_t)(p0 + e) * 2 * NC;
                         const double2 b0 = row[j], b1 = row[NC + j];
-                        const double t0 = __builtin_fma(ai, b0.y, -fr0);
-                        fr0 = __builtin_fma(ar, b0.x, -t0);
-                        const double u0 = __builtin_fma(ar, b0.y, fi0);
-                        fi0 = __builtin_fma(ai, b0.x, u0);
-                        const double t1 = __builtin_fma(ai, b1.y, -fr1);
-                        fr1 = __builtin_fma(ar, b1.x, -t1);
-                        const double u1 = __builtin_fma(ar, b1.y, fi1);
-                        fi1 = __builtin_fma(ai, b1.x, u1);
+                        const double t0 = __builtin_fma(ai, b0.y, -f0.x);
+                        f0.x = __builtin_fma(ar, b0.x, -t0);
+                        const double u0 = __builtin_fma(ar, b0.y, f0.y);
+                        f0.y = __builtin_fma(ai, b0.x, u0);
+                        const double t1 = __builtin_fma(ai, b1.y, -f1.x);
+                        f1.x = __builtin_fma(ar, b1.x, -t1);
+                        const double u1 = __builtin_fma(ar, b1.y, f1.y);
+                        f1.y = __builtin_fma(ai, b1.x, u1);
                     }
-                    fac[j] = fr0;
-                    fac[NC + j] = fi0;
-                    fac[N + j] = fr1;
-                    fac[N + NC + j] = fi1;
+                    fac[j] = f0;
+                    fac[NC + j] = f1;
                 }
                 __syncthreads();  // the next group's fill overwrites dig (not always from the work-item that read it: N < 2 x block)
             }
             // tLweFromFFTConvert (key rows carry the 2/N scale) + tLweAddTo
-            gen_fft(fac, 2, N, NC, A.tw, tid, nt, true);
-            for (int j = tid; j < 2 * N; j += nt) {
-                const U r = (U)Torus<T>::from_double(fac[j]);
-                acc[j] = (T)(rotate ? (U)acc[j] + r : r);
+            gen_fft(fac, 2, NC, NC, A.tw, tid, nt, true);
+            for (int j = tid; j < N; j += nt) {  // point j of polynomial q = coefficients j and j + N/2
+                const int q = j >> (logn - 1), c = j & (NC - 1);
+                const double2 v = fac[j];
+                const U r0 = (U)Torus<T>::from_double(v.x), r1 = (U)Torus<T>::from_double(v.y);
+                T *pa = acc + q * N;
+                pa[c] = (T)(rotate ? (U)pa[c] + r0 : r0);
+                pa[c + NC] = (T)(rotate ? (U)pa[c + NC] + r1 : r1);
             }
             __syncthreads();
         }

@@ -42,7 +42,7 @@ def test_bench_line_on_emulator(emu_lib, tmp_path):
     assert d["ranks_seen"] == 1 and "ranks" not in d
     # one rank: its own rate IS the value; no solo reference
     pg = d["per_gpu_bootstraps_per_s"]
-    assert pg["min"] == pg["max"] == pg["mean"] and abs(pg["mean"] - d["value"]) < 0.02 * d["value"] and d["efficiency_vs"] is None
+    assert pg["min"] == pg["max"] == pg["mean"] and abs(pg["mean"] - d["value"]) < 0.02 * d["value"] + 0.06 and d["efficiency_vs"] is None  # (the line rounds to 0.1)
     assert "config1_latency" not in d and "config2_streamed" not in d and "sustained" not in d and "pool_check" not in d  # --headline-only
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "bootstraps/s" and c["sample"]
