@@ -38,7 +38,7 @@ def main():
     runs = 0
     while time.time() < t_end:
         seed = rnd.randrange(1, 1 << 30)
-        kind = rnd.choice(["gate", "gate", "gate", "t64", "ks", "cmux", "lut", "fft", "exact", "wide", "pool", "privks"])
+        kind = rnd.choice(["gate", "gate", "gate", "t64", "ks", "cmux", "lut", "fft", "exact", "wide", "pool", "privks", "ring", "ring"])
         if kind == "gate":      # N=1024 Torus32: compile-time and run-time gadgets, ragged batches 1..41
             l, bg = rnd.choice([(2, 10), (2, 10), (2, 8), (2, 9), (3, 7), (4, 6), (1, 12)])
             t, bb = rnd.choice([(8, 2), (16, 1), (5, 3), (6, 2)])
@@ -46,6 +46,25 @@ def main():
             # one wave per ciphertext whatever the batch
             P.check_gate_path(lib, N=1024, n=rnd.randrange(2, 9), l=l, Bgbit=bg, ks_t=t, ks_bb=bb, B=rnd.randrange(1, 42),
                               seed=seed, check_export=False, br_split=rnd.choice([None, 1 << 30, 0]))
+        elif kind == "ring":    # ring degrees other than 1024 / 2048 (tfhe_kernels_generic.h): every path that takes an N
+            sub = rnd.choice(["gate", "gate", "t64", "fft", "consumers"])
+            if sub == "gate":
+                N = rnd.choice([16, 32, 64, 128, 256, 512, 512, 4096, 8192])
+                l, bg = rnd.choice([(2, 10), (3, 6), (1, 12), (4, 5)]) if N >= 64 else rnd.choice([(2, 8), (3, 6)])
+                big = N >= 4096
+                P.check_gate_path(lib, N=N, n=rnd.randrange(2, 4 if big else 8), l=l, Bgbit=bg, ks_t=rnd.choice([3, 4, 8]), ks_bb=rnd.choice([1, 2]),
+                                  B=rnd.randrange(1, 4 if big else 30), seed=seed, check_export=rnd.random() < 0.3)
+            elif sub == "t64":
+                N = rnd.choice([64, 256, 512, 4096])
+                l, bg = rnd.choice([(4, 9), (3, 10), (2, 16)])
+                P.check_torus64_path(lib, N=N, n=rnd.randrange(2, 5), l=l, Bgbit=bg, B=rnd.randrange(1, 4 if N >= 4096 else 10), seed=seed)
+            elif sub == "fft":
+                N = 1 << rnd.choice([4, 5, 6, 7, 8, 9, 12, 13, 14, 15])
+                P.check_fft_plugin(lib, N, count=rnd.randrange(1, 6 if N >= 4096 else 300), seed=seed)
+            else:
+                N = rnd.choice([256, 512])
+                P.check_cmux_data(lib, N=N, B=rnd.randrange(1, 20), seed=seed)
+                P.check_lut_eval(lib, N=N, d=rnd.randrange(1, 12), B=rnd.randrange(1, 4), seed=seed, decrypt_tol=None)
         elif kind == "wide":    # batches above 1024: the 8-wave workgroup instantiations of every gadget class
             l, bg = rnd.choice([(2, 10), (2, 8), (2, 9), (3, 7), (4, 6)])
             P.check_gate_wide_batch(lib, l=l, Bgbit=bg, B=rnd.randrange(1025, 1100), n=rnd.randrange(2, 7), seed=seed)

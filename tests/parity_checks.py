@@ -205,6 +205,17 @@ def check_gate_wide_batch(lib_path, l, Bgbit, B=1031, N=1024, n=6, ks_t=8, ks_bb
         want = np.stack([O.bootstrap32(N, s.bk, s.ks, 1 << 29, x[i], l, Bgbit, ks_t, ks_bb) for i in sub])
         assert np.array_equal(got[sub], want), (l, Bgbit)
         assert np.array_equal(got[:24], s.eng.bootstrap(1 << 29, x[:24])), (l, Bgbit, "8-wave vs 4-wave workgroups")
+        # the one-launch-per-CMux schedule at this batch: for l = 2 its launches take k_cmux_stream (accumulators in place in global
+        # memory, persistent waves: several ciphertexts per wave when the batch exceeds what the chip holds), plain and as a graph
+        assert np.array_equal(s.eng.bootstrap(1 << 29, x, streamed=True), got), (l, Bgbit, "one launch per CMux")
+        # ... and one CMux step on its own (tfhe_MuxRotate_FFT), rotation 0 (skipped) included
+        accm = rs.randint(-2 ** 31, 2 ** 31, size=(B, 2, N)).astype(np.int32)
+        ba = rs.randint(0, 2 * N, size=B).astype(np.int32)
+        ba[B - 1] = 0
+        mr = s.eng.mux_rotate(accm, s.gsw, n - 1, ba)
+        for i in (0, 5, B - 2, B - 1):
+            w = O.mux_rotate32(N, accm[i], s.bk[n - 1], ba[i], l, Bgbit).reshape(2, N) if ba[i] else accm[i]
+            assert np.array_equal(mr[i], w), (l, Bgbit, i, "CMux step")
         acc = rs.randint(-2 ** 31, 2 ** 31, size=(B, 2, N)).astype(np.int32)
         bara = rs.randint(0, 2 * N, size=(B, n)).astype(np.int32)
         bara[B - 1, 0] = 0

@@ -90,7 +90,7 @@ def test_bench_multi_rank_path_on_emulator(emu_lib):
     # ALONE on its slice afterwards (the N = 1 point at the same per-GPU batch)
     rates = [r[2] * d["steps"] / r[3] for r in d["ranks"]]
     pg = d["per_gpu_bootstraps_per_s"]
-    assert abs(pg["min"] - min(rates)) < 0.01 * pg["min"] and abs(pg["max"] - max(rates)) < 0.01 * pg["max"]  # (seconds are rounded on the line)
+    assert abs(pg["min"] - min(rates)) < 0.01 * pg["min"] + 0.06 and abs(pg["max"] - max(rates)) < 0.01 * pg["max"] + 0.06  # (rounded on the line)
     ev = d["efficiency_vs"]
     assert ev["batch"] == 3 and ev["per_gpu_bootstraps_per_s"] > 0 and "alone" in ev["what"]
 

@@ -163,10 +163,11 @@ def test_engine_vs_reference_golden_emu(emu_lib, N):
         e.close()
 
 
-@pytest.mark.parametrize("N", [16, 32, 512, 4096, 32768])
+@pytest.mark.parametrize("N", [16, 32, 512, 4096, 32768, 1 << 20])
 def test_fft_plugin_emu(emu_lib, N):
-    """every execute_*, AddMul and the C core against the oracle, ragged batches; 32768: transform buffers in global scratch"""
-    P.check_fft_plugin(emu_lib, N, count=3 if N >= 4096 else 67)
+    """every execute_*, AddMul and the C core against the oracle, ragged batches; 32768 and the largest degree served, 2^20:
+    transform buffers in global scratch"""
+    P.check_fft_plugin(emu_lib, N, count=1 if N > 32768 else (3 if N >= 4096 else 67))
 
 
 @pytest.mark.parametrize("N,n,l,Bgbit,ks_t,ks_bb,B", [(512, 4, 2, 10, 4, 2, 3), (4096, 3, 2, 10, 3, 2, 2), (16, 5, 3, 6, 5, 2, 5),
@@ -239,9 +240,15 @@ def test_engine_vs_reference_golden_gpu(gpu_lib, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N", [16, 64, 512, 4096, 8192, 32768])
+@pytest.mark.parametrize("N", [16, 64, 512, 4096, 8192, 32768, 1 << 20])
 def test_fft_plugin_gpu(gpu_lib, N):
-    P.check_fft_plugin(gpu_lib, N, count=5 if N >= 4096 else 131)
+    P.check_fft_plugin(gpu_lib, N, count=2 if N > 32768 else (5 if N >= 4096 else 131))
+
+
+@pytest.mark.gpu
+def test_gate_path_n65536_gpu(gpu_lib):
+    """far beyond what the LDS holds: accumulator, digits and Fourier accumulator (3.5 MB per ciphertext) in global scratch"""
+    P.check_gate_path(gpu_lib, N=1 << 16, n=2, l=2, Bgbit=10, ks_t=2, ks_bb=2, B=3, check_export=False)
 
 
 @pytest.mark.gpu
