@@ -354,6 +354,10 @@ int launch_fft_t(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
 // contexts of several ring degrees, and the attribute is per function, not per context)
 constexpr size_t GEN_LDS_MAX = (size_t)160 * 1024;
 constexpr size_t GEN_WORK_MAX = (size_t)256 << 20;  // global scratch of one launch when the LDS is too small
+// largest ring degree served one wavefront per ciphertext (kg_blind_rotate<T, true, true>).  Measured, MI355X, batch 4096 x 64 CMux
+// (profiles/r06_generic_n.txt), against a workgroup per ciphertext: N = 256: 1.72 against 1.93 ms; N = 512: 2.87 against 3.17 ms with
+// two digits at a time (80 KB per four waves: two workgroups per CU; all four digits, 112 KB: 4.14 ms); N = 64: equal
+constexpr size_t GEN_WAVE_MAX_N = 512;
 int grow(tfhe_amd_ctx *c, void **buf, size_t *have, size_t need);
 // transforms: grid and work area of a launch over `batch` polynomials
 struct GenFftPlan {
@@ -362,18 +366,19 @@ struct GenFftPlan {
     double *work;
 };
 bool gen_fft_in_lds(const tfhe_amd_ctx *c) {
-    return (size_t)(GEN_BLOCK / gen_team_size(c->p.N / 2)) * c->p.N * sizeof(double) <= GEN_LDS_MAX;
+    const int block = gen_block(c->p.N);
+    return (size_t)(block / gen_team_size(c->p.N / 2, block)) * c->p.N * sizeof(double) <= GEN_LDS_MAX;
 }
 template <typename KernelT>
 int gen_fft_plan(tfhe_amd_ctx *c, KernelT kernel, int batch, GenFftPlan *pl) {
-    const int N = c->p.N, teams = GEN_BLOCK / gen_team_size(N / 2);
+    const int N = c->p.N, block = gen_block(N), teams = block / gen_team_size(N / 2, block);
     const size_t bytes = (size_t)teams * N * sizeof(double);
     const int needed = (batch + teams - 1) / teams;
     if (int rc = set_lds(c, kernel, GEN_LDS_MAX)) return rc;
     if (gen_fft_in_lds(c)) {
         pl->lds = bytes;
         pl->work = nullptr;
-        return persistent_grid(c, kernel, GEN_BLOCK, bytes, needed, &pl->grid);
+        return persistent_grid(c, kernel, block, bytes, needed, &pl->grid);
     }
     long long g = (long long)(GEN_WORK_MAX / bytes);
     if (g < 1) g = 1;
@@ -387,7 +392,7 @@ template <typename TIN, bool PACK, bool LDS>
 int launch_gen_ifft_p(tfhe_amd_ctx *c, double *out_d, const TIN *in_d, int batch) {
     GenFftPlan pl;
     if (int rc = gen_fft_plan(c, kg_ifft_batch<TIN, PACK, LDS>, batch, &pl)) return rc;
-    TFHE_LAUNCH((kg_ifft_batch<TIN, PACK, LDS>), dim3(pl.grid), dim3(GEN_BLOCK), pl.lds, c->stream, out_d, in_d,
+    TFHE_LAUNCH((kg_ifft_batch<TIN, PACK, LDS>), dim3(pl.grid), dim3(gen_block(c->p.N)), pl.lds, c->stream, out_d, in_d,
                 (const double2 *)c->tw_d, batch, c->logn, pl.work);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
@@ -400,7 +405,7 @@ template <typename TOUT, bool LDS>
 int launch_gen_fft_p(tfhe_amd_ctx *c, TOUT *out_d, const double *in_d, int batch) {
     GenFftPlan pl;
     if (int rc = gen_fft_plan(c, kg_fft_batch<TOUT, LDS>, batch, &pl)) return rc;
-    TFHE_LAUNCH((kg_fft_batch<TOUT, LDS>), dim3(pl.grid), dim3(GEN_BLOCK), pl.lds, c->stream, out_d, in_d,
+    TFHE_LAUNCH((kg_fft_batch<TOUT, LDS>), dim3(pl.grid), dim3(gen_block(c->p.N)), pl.lds, c->stream, out_d, in_d,
                 (const double2 *)c->tw_d, batch, c->logn, pl.work);
     HIPCHECK(c, hipGetLastError());
     return TFHE_AMD_OK;
@@ -442,8 +447,28 @@ int launch_br_gen(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
         glob = acc_b + g.nd * dig1_b + fac_b;
     }
     int block = (int)(N / 4);  // NC/2 butterflies per layer
-    block = block < 64 ? 64 : (block > GEN_BLOCK ? GEN_BLOCK : block);
+    block = block < 64 ? 64 : (block > GEN_BR_BLOCK ? GEN_BR_BLOCK : block);
     const bool all_lds = glob == 0;
+#ifndef TFHE_GEN_NO_WAVE
+    // One WAVEFRONT per ciphertext up to N = 512: four independent ciphertexts per 256-thread workgroup, no workgroup barrier at
+    // all (kg_blind_rotate<T, true, true>), and as many digits at a time as leave room for TWO such workgroups on a CU
+    if (all_lds && N <= GEN_WAVE_MAX_N) {
+        int nd_w = 0;
+        for (int k = 0; k < 3 && !nd_w; k++)
+            if (4 * (acc_b + nd_try[k] * dig1_b + fac_b) <= GEN_LDS_MAX / 2) nd_w = nd_try[k];
+        if (nd_w) {
+            g.nd = nd_w;
+            g.wave_bytes = (long long)(acc_b + nd_w * dig1_b + fac_b);
+            const size_t wg_lds = 4 * (size_t)g.wave_bytes;
+            if (int rc = set_lds(c, kg_blind_rotate<T, true, true>, GEN_LDS_MAX)) return rc;
+            int grid = 0;
+            if (int rc = persistent_grid(c, kg_blind_rotate<T, true, true>, GEN_WAVE_BLOCK, wg_lds, (a.batch + 3) / 4, &grid)) return rc;
+            TFHE_LAUNCH((kg_blind_rotate<T, true, true>), dim3(grid), dim3(GEN_WAVE_BLOCK), wg_lds, c->stream, a, g);
+            HIPCHECK(c, hipGetLastError());
+            return TFHE_AMD_OK;
+        }
+    }
+#endif
     if (int rc = all_lds ? set_lds(c, kg_blind_rotate<T, true>, GEN_LDS_MAX) : set_lds(c, kg_blind_rotate<T, false>, GEN_LDS_MAX)) return rc;
     int grid = 0;
     if (int rc = all_lds ? persistent_grid(c, kg_blind_rotate<T, true>, block, lds, a.batch, &grid)

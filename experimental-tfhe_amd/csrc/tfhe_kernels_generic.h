@@ -4,7 +4,8 @@
 // (CB/spqlios/spqlios-fft-impl.cpp:157-160,400-403, fft_processor_spqlios.cpp:18-25); the reference only
 // instantiates 1024 and 2048, and those two keep the wave-per-polynomial kernels of tfhe_kernels.h.  Every other N
 // runs here: a TEAM of work-items (up to a 256-thread workgroup) owns one polynomial, the N/2 complex points live in
-// a work buffer (LDS while it fits, a global scratch slice beyond), one radix-2 layer per workgroup barrier.
+// a work buffer of 16-byte points (LDS while it fits, a global scratch slice beyond), and a work-item carries its points
+// through two radix-2 layers between workgroup barriers (three at the end).
 // The per-node arithmetic is the reference's, operation for operation (twist, dif/dit butterflies
 // with their FMA placement, the multiplication-free size-4 and size-2 steps, the four-product final twist), through
 // the same helper functions as the tuned kernels (dif_bfly, dit_bfly, Torus<T>::from_double, the AddMul chain) --
@@ -57,6 +58,17 @@ TFHE_DEVICE void gen_fft_head4(GenC (&x)[4]) {
     x[3] = GenC{r1 - i3, i1 + r3};
 }
 
+// What separates two phases that exchange points through the work buffer: a workgroup barrier when the team is (part of) a
+// workgroup, or -- WAVE: the team is exactly one wavefront -- nothing but a compiler fence, since a wave's LDS instructions execute
+// in order (the idiom of the tuned kernels).  WAVE teams of one workgroup never wait for each other.
+template <bool WAVE>
+TFHE_DEVICE void gen_sync() {
+    if constexpr (WAVE)
+        TFHE_WAVE_FENCE();
+    else
+        __syncthreads();
+}
+
 // Coefficient -> Lagrange, in place, for `np` polynomials `pstride` points apart; each is NC complex points holding
 // a_j + i a_{j+NC} on entry (the fold of spqlios-ifft-fma.s:40-44).  A team of `tpp` work-items (this one is number `lt`)
 // shares the work; EVERY work-item of the workgroup must call this (the barriers are workgroup barriers), `active` = false
@@ -64,6 +76,7 @@ TFHE_DEVICE void gen_fft_head4(GenC (&x)[4]) {
 // 2 NC - 2 h).  The caller has synchronised its writes; on return every result is visible to the whole workgroup.
 // Barriers: the layers are the reference's radix-2 layers, node for node, but a work-item carries its points through
 // TWO layers (four points) between barriers, and through the last three (h = 4, size 4, size 2: eight consecutive points).
+template <bool WAVE = false>
 TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active) {
     {  // layer h = NC/2 with the twist by omega^j (spqlios-ifft-fma.s:63-78) fused: its butterfly owns both points
         const int h = NC >> 1;
@@ -84,7 +97,7 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
                 }
             }
         }
-        __syncthreads();
+        gen_sync<WAVE>();
     }
     if (NC > 8) {
         int h = NC >> 2, layers = 0;  // middle layers h = NC/4 .. 8
@@ -104,7 +117,7 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
                     }
                 }
             }
-            __syncthreads();
+            gen_sync<WAVE>();
             h >>= 1;
         }
         for (; h >= 16; h >>= 2) {  // layers h and h/2 on the four points base + {0, h/2, h, 3h/2}
@@ -128,7 +141,7 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
                     }
                 }
             }
-            __syncthreads();
+            gen_sync<WAVE>();
         }
         // layer h = 4, then size 4 and size 2, on eight consecutive points
         if (active) {
@@ -152,7 +165,7 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
                 }
             }
         }
-        __syncthreads();
+        gen_sync<WAVE>();
         return;
     }
     if (active) {  // NC = 8: the fused first layer was h = 4
@@ -164,11 +177,12 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
                 for (int k = 0; k < 4; k++) gen_st(x, k, v[k]);
             }
     }
-    __syncthreads();
+    gen_sync<WAVE>();
 }
 
 // Lagrange -> coefficient, in place (the caller has applied the 2/N scale); same calling rules as gen_ifft.
 // (the reference's fft table is the conjugate of its ifft table except cos at the quarter turn: flip_sign_if)
+template <bool WAVE = false>
 TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active) {
     if (NC > 8) {
         // size 2, size 4, then layer h = 4, on eight consecutive points
@@ -193,7 +207,7 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
                 }
             }
         }
-        __syncthreads();
+        gen_sync<WAVE>();
         int layers = 0;  // middle layers h = 8 .. NC/4
         for (int t = 8; t <= (NC >> 2); t <<= 1) layers++;
         int h = 8;
@@ -220,7 +234,7 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
                     }
                 }
             }
-            __syncthreads();
+            gen_sync<WAVE>();
         }
         if (layers & 1) {  // the odd one out: h == NC/4
             if (active) {
@@ -238,7 +252,7 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
                     }
                 }
             }
-            __syncthreads();
+            gen_sync<WAVE>();
         }
     } else {
         if (active) {
@@ -250,7 +264,7 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
                     for (int k = 0; k < 4; k++) gen_st(x, k, v[k]);
                 }
         }
-        __syncthreads();
+        gen_sync<WAVE>();
     }
     {  // layer h = NC/2 with the final twist by conj(omega^j), four rounded products (spqlios-fft-fma.s:255-274)
         const int h = NC >> 1;
@@ -270,13 +284,17 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
                 }
             }
         }
-        __syncthreads();
+        gen_sync<WAVE>();
     }
 }
 
-// how a 256-thread workgroup is cut into teams: one team per polynomial, NC/2 butterflies per layer
-TFHE_HOST_DEVICE int gen_team_size(int NC) { return (NC >> 1) < 256 ? (NC >> 1) : 256; }
-constexpr int GEN_BLOCK = 256;
+// How a workgroup of `block` work-items is cut into teams: one team per polynomial, at most NC/2 butterflies per layer each.
+// The host picks the workgroup (gen_block): 256 up to N = 4096, the whole 1024 beyond -- measured on MI355X: 512 instead of 256
+// loses 6 % at N = 512, gains 4 % at 4096 and 34 % at 16384 (profiles/r06_generic_n.txt)
+constexpr int GEN_BLOCK_MAX = 1024;
+constexpr int GEN_WAVE_BLOCK = 256;  // workgroup of the one-wave-per-ciphertext blind rotation: four waves
+TFHE_HOST_DEVICE int gen_block(int N) { return N >= 8192 ? GEN_BLOCK_MAX : 256; }
+TFHE_HOST_DEVICE int gen_team_size(int NC, int block) { return (NC >> 1) < block ? (NC >> 1) : block; }
 
 // ------------------------------------------------------------ FFT plugin boundary, any N
 // execute_reverse_int / _torus32 / _torus64 and the bare `ifft` (TIN = double): coefficients -> LagrangeHalfC.
@@ -284,11 +302,11 @@ constexpr int GEN_BLOCK = 256;
 // LDS: the transform buffers are dynamic LDS (teams x N doubles; a template parameter so that the compiler addresses them
 // with DS instructions instead of flat ones), else slices of the global scratch `work`, one per workgroup.
 template <typename TIN, bool PACK, bool LDS>
-TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
+TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK_MAX)
     kg_ifft_batch(double *__restrict__ out, const TIN *__restrict__ in, const double2 *__restrict__ tw, int batch, int logn,
                   double *__restrict__ work) {
     const int N = 1 << logn, NC = N >> 1;
-    const int tpp = gen_team_size(NC), teams = GEN_BLOCK / tpp;
+    const int tpp = gen_team_size(NC, (int)blockDim.x), teams = (int)blockDim.x / tpp;
     const int team = (int)threadIdx.x / tpp, lt = (int)threadIdx.x - team * tpp;
     TFHE_DYN_LDS(smem);
     double2 *buf = reinterpret_cast<double2 *>(LDS ? reinterpret_cast<double *>(smem) : work + (size_t)blockIdx.x * teams * N) + (size_t)team * NC;
@@ -322,11 +340,11 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
 // execute_direct_torus32 / _torus64 (scale 2/N, transform, round as fft_processor_spqlios.cpp:102,131-142) and the bare
 // `fft` (TOUT = double: no scale, no rounding)
 template <typename TOUT, bool LDS>
-TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK)
+TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK_MAX)
     kg_fft_batch(TOUT *__restrict__ out, const double *__restrict__ in, const double2 *__restrict__ tw, int batch, int logn,
                  double *__restrict__ work) {
     const int N = 1 << logn, NC = N >> 1;
-    const int tpp = gen_team_size(NC), teams = GEN_BLOCK / tpp;
+    const int tpp = gen_team_size(NC, (int)blockDim.x), teams = (int)blockDim.x / tpp;
     const int team = (int)threadIdx.x / tpp, lt = (int)threadIdx.x - team * tpp;
     constexpr bool RAW = std::is_same<TOUT, double>::value;
     TFHE_DYN_LDS(smem);
@@ -377,8 +395,8 @@ TFHE_GLOBAL void kg_modswitch(int32_t *__restrict__ out, const int32_t *__restri
 
 // ------------------------------------------------------------ blind rotation, any N
 // One workgroup per ciphertext (persistent: the grid walks the batch), every flag of k_blind_rotate honoured with the
-// same meaning.  Work areas: acc [2][N] torus, dig [nd][N] doubles (nd gadget digits at a time: extract, transform,
-// multiply-accumulate, discard), fac [2][N] doubles (the Fourier accumulator of tLweFFTClear / tLweFFTAddMulRTo).
+// same meaning.  Work areas: acc [2][N] torus, dig [nd][N/2] complex points (nd gadget digits at a time: extract, transform,
+// multiply-accumulate, discard), fac [2][N/2] complex points (the Fourier accumulator of tLweFFTClear / tLweFFTAddMulRTo).
 // Each of the three is in dynamic LDS when its offset is >= 0, else in the workgroup's slice of `work`.
 struct GenBrPlace {
     long long acc_lds, dig_lds, fac_lds;  // byte offsets into dynamic LDS, or -1: global
@@ -386,16 +404,23 @@ struct GenBrPlace {
     unsigned char *work;
     int logn;
     int nd;  // gadget digits transformed together: 2l, l or 1 (dig holds nd polynomials)
+    long long wave_bytes;  // WAVE form: LDS bytes of one wavefront's three areas
 };
 
 // ALL_LDS: the three areas are dynamic LDS at the offsets of G (compile-time knowledge: DS instructions, not flat ones)
-template <typename T, bool ALL_LDS>
-TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T> A, GenBrPlace G) {
+// WAVE (with ALL_LDS): ONE WAVEFRONT per ciphertext, its three areas in its own slice of the workgroup's LDS (G.wave_bytes apart);
+// the waves of a workgroup are independent ciphertexts and no workgroup barrier exists (gen_sync<true>)
+constexpr int GEN_BR_BLOCK = 1024;  // widest workgroup of the blind rotation (a ciphertext of N >= 2048: two waves per SIMD between barriers)
+template <typename T, bool ALL_LDS, bool WAVE = false>
+TFHE_GLOBAL void __launch_bounds__(GEN_BR_BLOCK) kg_blind_rotate(BlindRotateArgs<T> A, GenBrPlace G) {
+    static_assert(!WAVE || ALL_LDS, "wave teams keep everything in LDS");
     using U = typename Torus<T>::U;
     constexpr int BITS = Torus<T>::BITS;
     const int logn = G.logn, N = 1 << logn, NC = N >> 1;
-    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
-    TFHE_DYN_LDS(smem);
+    const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, nt = WAVE ? 64 : (int)blockDim.x;
+    const int team = WAVE ? (int)(threadIdx.x >> 6) : 0, teams = WAVE ? (int)(blockDim.x >> 6) : 1;
+    TFHE_DYN_LDS(smem_all);
+    unsigned char *smem = smem_all + (WAVE ? (size_t)team * (size_t)G.wave_bytes : 0);
     const int nd = G.nd;
     T *acc;
     double2 *dig, *fac;  // [nd][NC] and [2][NC] complex points
@@ -422,7 +447,7 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
     const int32_t halfBg = 1 << (Bgbit - 1);
     const bool rotate = !(A.flags & BR_NO_ROTATE);
 
-    for (int ct = (int)blockIdx.x; ct < A.batch; ct += (int)gridDim.x) {  // workgroup-uniform
+    for (int ct = (int)blockIdx.x * teams + team; ct < A.batch; ct += (int)gridDim.x * teams) {  // team-uniform
         const int32_t *rot = A.rot + (size_t)ct * A.rot_stride;
         // ---- accumulator initialisation (as k_blind_rotate)
         if (A.flags & BR_INIT_TESTVEC) {
@@ -457,7 +482,7 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
             const T *src = A.acc_io + (size_t)ct * 2 * N;
             for (int j = tid; j < 2 * N; j += nt) acc[j] = src[j];
         }
-        __syncthreads();
+        gen_sync<WAVE>();
         const double2 *bk0 = A.bk;
         if (A.gsw_sel)
             bk0 += (size_t)A.gsw_sel[ct] * A.gsw_sample_stride;
@@ -494,8 +519,8 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
                     };
                     for (int j = tid; j < NC; j += nt) dg[j] = make_double2(digit(j), digit(j + NC));
                 }
-                __syncthreads();
-                gen_ifft(dig, nd, NC, NC, A.tw, tid, nt, true);
+                gen_sync<WAVE>();
+                gen_ifft<WAVE>(dig, nd, NC, NC, A.tw, tid, nt, true);
                 // tLweFFTAddMulRTo (tlwe_functions.cpp:318-325), both output polynomials, on an accumulator that starts as
                 // the +0 of tLweFFTClear (tgsw_functions.cpp:438)
                 for (int j = tid; j < NC; j += nt) {
@@ -521,10 +546,10 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
                     fac[j] = f0;
                     fac[NC + j] = f1;
                 }
-                __syncthreads();  // the next group's fill overwrites dig (not always from the work-item that read it: N < 2 x block)
+                gen_sync<WAVE>();  // the next group's fill overwrites dig (not always from the work-item that read it: N < 2 x block)
             }
             // tLweFromFFTConvert (key rows carry the 2/N scale) + tLweAddTo
-            gen_fft(fac, 2, NC, NC, A.tw, tid, nt, true);
+            gen_fft<WAVE>(fac, 2, NC, NC, A.tw, tid, nt, true);
             for (int j = tid; j < N; j += nt) {  // point j of polynomial q = coefficients j and j + N/2
                 const int q = j >> (logn - 1), c = j & (NC - 1);
                 const double2 v = fac[j];
@@ -533,7 +558,7 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
                 pa[c] = (T)(rotate ? (U)pa[c] + r0 : r0);
                 pa[c + NC] = (T)(rotate ? (U)pa[c + NC] + r1 : r1);
             }
-            __syncthreads();
+            gen_sync<WAVE>();
         }
 
         // ---- output
@@ -559,7 +584,7 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK) kg_blind_rotate(BlindRotateArgs<T>
             T *dst = A.acc_io + (size_t)ct * 2 * N;
             for (int j = tid; j < 2 * N; j += nt) dst[j] = acc[j];
         }
-        __syncthreads();  // acc is re-initialised for the workgroup's next ciphertext
+        gen_sync<WAVE>();  // acc is re-initialised for the workgroup's next ciphertext
     }
 }
 

@@ -222,6 +222,14 @@ def test_library_form_shims_emu(emu_lib, tmp_path):
     run_lib_form(build_driver(emu_lib, "emu"), tmp_path)
 
 
+@pytest.mark.parametrize("N", [512, 64])
+def test_library_form_shims_other_ring_degrees_emu(emu_lib, tmp_path, N):
+    """the reference-named entry points (tfhe_bootstrap_FFT, tfhe_blindRotateAndExtract_FFT, tfhe_MuxRotate_FFT, tGswFFTExternMulToTLwe,
+    lweKeySwitch, the FFT plugin object) at ring degrees the reference's code accepts but its PoC never instantiates: the shims
+    take N from the caller's parameter structs, the engine serves every power of two >= 16"""
+    run_lib_form(build_driver(emu_lib, "emu"), tmp_path, N=N, n=5, l=2, Bgbit=8, t=4, bb=2)
+
+
 def test_poc_form_shims_emu(emu_lib, tmp_path):
     run_poc_form(build_driver(emu_lib, "emu"), tmp_path)
 

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--degrees", default="512,1024,4096")
+    ap.add_argument("--lib", default=None)
     a = ap.parse_args()
     T = importlib.import_module("experimental-tfhe_amd")
     shard = importlib.import_module("experimental-tfhe_amd.shard")
@@ -39,7 +40,7 @@ def main():
     for N in [int(v) for v in a.degrees.split(",")]:
         batch = a.batch if N <= 4096 else max(64, a.batch * 4096 // N)
         cfg = shard.GateConfig(N=N, n=a.n, ks_t=4, ks_basebit=2)
-        job = shard.GateJob(cfg, 0x5446484500000001, device=0)
+        job = shard.GateJob(cfg, 0x5446484500000001, device=0, lib_path=a.lib)
         eng = job.eng
         x_d = eng.to_device(shard.synthetic_samples(cfg, batch, seed=7))
         u_d, o_d = eng.alloc(batch * (N + 1) * 4), eng.alloc(batch * (cfg.n + 1) * 4)
