@@ -412,7 +412,7 @@ struct GenBrPlace {
 // the waves of a workgroup are independent ciphertexts and no workgroup barrier exists (gen_sync<true>)
 constexpr int GEN_BR_BLOCK = 1024;  // widest workgroup of the blind rotation (a ciphertext of N >= 2048: two waves per SIMD between barriers)
 template <typename T, bool ALL_LDS, bool WAVE = false>
-TFHE_GLOBAL void __launch_bounds__(GEN_BR_BLOCK) kg_blind_rotate(BlindRotateArgs<T> A, GenBrPlace G) {
+TFHE_GLOBAL void __launch_bounds__(WAVE ? GEN_WAVE_BLOCK : GEN_BR_BLOCK) kg_blind_rotate(BlindRotateArgs<T> A, GenBrPlace G) {
     static_assert(!WAVE || ALL_LDS, "wave teams keep everything in LDS");
     using U = typename Torus<T>::U;
     constexpr int BITS = Torus<T>::BITS;
