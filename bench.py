@@ -31,6 +31,7 @@ value = all ranks' bootstraps / max-over-ranks time.
 
 Beside the timed region of a one-GPU run (never inside `value`; --headline-only skips them, which is what the
 rocprofv3 scripts under tools/ pass so that the default command's kernel table holds the headline kernels only):
+  ring_degrees        gate bootstraps at N = 512 and 4096 (the generic kernels of every ring degree other than 1024 / 2048), same child
   config3_circuit_bootstrap, config4_transforms   BASELINE configs 3 and 4 as tools/bench_configs.py measures them
                       (--other-configs), in a CHILD process that runs and exits BEFORE this process touches the GPU: a fault
                       there costs its own section, never the headline.  Config 3's timed outputs are bit-compared with the oracle.
@@ -178,13 +179,13 @@ def other_configs_child(a):
     through the C ABI, synthetic keys; config 3's timed outputs bit-compared with the oracle), run as a CHILD process that exits
     before this process touches the GPU -- a GPU fault, a hang (timeout) or an exception there costs that section only."""
     import tempfile
-    want = [w.strip() for w in a.other_configs.split(",") if w.strip() in ("3", "4")]
+    want = [w.strip() for w in a.other_configs.split(",") if w.strip() in ("3", "4", "ring")]
     if not want:
         return {}
     fd, path = tempfile.mkstemp(prefix="tfhe_bench_configs_", suffix=".json")
     os.close(fd)
     small = a.lwe_n is not None  # the test hook of the CPU emulator runs: tiny sizes
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_configs.py")] + [{"3": "cb", "4": "fft"}[w] for w in want] + [
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_configs.py")] + [{"3": "cb", "4": "fft", "ring": "ring"}[w] for w in want] + [
         "--json-out", path, "--reps", str(min(3, max(1, a.extras_reps))), "--cb-batch", "1024", "--batch", "8192"]
     if small:
         cmd.append("--small")
@@ -214,6 +215,11 @@ def other_configs_child(a):
                                                     "the PoC parameters, batch 1024)", lut_evaluation=sec[1])
         else:
             out["config3_circuit_bootstrap"] = {"error": (sec or {}).get("error") if isinstance(sec, dict) else (note or "no result")}
+    if "ring" in want:
+        sec = got.get("ring")
+        out["ring_degrees"] = ({"what": "gate bootstraps at ring degrees other than the reference's 1024 / 2048 (generic kernels), headline "
+                                        "gadget and key switch, timed outputs bit-compared with the oracle", "lines": sec}
+                               if isinstance(sec, list) else {"error": (sec or {}).get("error") if isinstance(sec, dict) else (note or "no result")})
     if "4" in want:
         sec = got.get("fft")
         if isinstance(sec, list):
@@ -370,6 +376,12 @@ def compact_line(full, detail_path):
     section("config2_streamed", "streamed_schedule", b_streamed)
     section("config3_circuit_bootstrap", "config3_circuit_bootstrap", b_c3)
     section("config4_transforms", "config4_transforms", b_c4)
+
+    def b_ring(rg):  # per ring degree: [bootstraps/s, fp64 TF/s of the blind rotation, timed outputs == oracle]
+        return {"[bootstraps/s, blind-rotation TF/s, oracle_bit_identical] by N": {str(x["N"]): [round(x["bootstraps_per_s"], 1), round(x["fp64_tflops"], 2),
+                                                                                           x["oracle_bit_identical"]] for x in rg["lines"]}}
+
+    section("ring_degrees", "ring_degrees", b_ring)
     section("pool_check", "pool_check", b_pool)
     if "key_broadcast" in full:
         out["key_broadcast"] = full["key_broadcast"]
@@ -467,10 +479,10 @@ def main():
                          "schedule): a rocprofv3 --stats run of the command then sees the headline kernels only")
     ap.add_argument("--streamed", action="store_true", help="(kept for older scripts: the streamed schedule is now on by default)")
     ap.add_argument("--latency-batches", default="1,8", help="batch sizes of the config 1 latency section")
-    ap.add_argument("--other-configs", default="3,4",
+    ap.add_argument("--other-configs", default="3,4,ring",
                     help="which of BASELINE's other one-GPU configs a one-GPU run also measures after the timed region "
-                         "(tools/bench_configs.py: 3 = circuit bootstrap at the PoC parameters, 4 = batched N = 2048 transforms); "
-                         "'' = none.  Never part of `value`; --headline-only skips them too")
+                         "(tools/bench_configs.py: 3 = circuit bootstrap at the PoC parameters, 4 = batched N = 2048 transforms, "
+                         "ring = gate bootstraps at N = 512 and 4096 on the generic kernels); '' = none.  Never part of `value`; --headline-only skips them too")
     ap.add_argument("--extras-reps", type=int, default=5, help="repetitions of each measurement after the timed region")
     ap.add_argument("--detail", default=None,
                     help="where the FULL record (all notes, stages, per-transform lines) is written as a file; default: "

@@ -169,7 +169,7 @@ def test_bench_post_region_sections_on_emulator(emu_lib):
     tfhe_amd_bootstrap) and config 2's literal schedule (one launch per CMux), both bit-compared with the headline outputs"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lib", emu_lib, "--batch", "2", "--steps", "1",
                           "--warmup", "0", "--no-cpu-baseline", "--extras-reps", "1", "--latency-batches", "1,2", "--lwe-n", "24",
-                          "--other-configs", "4", "--sustained-seconds", "1"],  # (config 3's 2049-coefficient private key switch is minutes on the emulator)
+                          "--other-configs", "4,ring", "--sustained-seconds", "1"],  # (config 3's 2049-coefficient private key switch is minutes on the emulator)
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
@@ -180,6 +180,8 @@ def test_bench_post_region_sections_on_emulator(emu_lib):
     c4 = d["config4_transforms"]["hbm_frac [reverse_int, reverse_torus64, direct_torus64, direct_torus32 | Real96: iFFT, FFT]"]
     assert any(k.startswith("N=2048") for k in c4) and any(k.startswith("N=1024") for k in c4) and any(k.startswith("Real96") for k in c4)
     assert "config3_circuit_bootstrap" not in d
+    rg = d["ring_degrees"]["[bootstraps/s, blind-rotation TF/s, oracle_bit_identical] by N"]  # the generic kernels, from the same child
+    assert set(rg) == {"512", "4096"} and all(v[0] > 0 and v[2] is True for v in rg.values())
     # the pool: one member, and two members sharing the device; host arrays in and out; identical to the headline outputs
     pc = d["pool_check"]
     rows = pc["[devices, samples per call, bootstraps/s]"]

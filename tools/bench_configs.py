@@ -4,6 +4,7 @@
     python tools/bench_configs.py fft   [--batch 8192] [--reps 5]     BASELINE config 4
     python tools/bench_configs.py cb    [--cb-batch 768] [--reps 3]   BASELINE config 3
     python tools/bench_configs.py lat   [--lat-batches 1,8,64,...]    BASELINE config 1 (latency) and small batches
+    python tools/bench_configs.py ring                                gate bootstraps at N = 512 and 4096 (the generic kernels)
     python tools/bench_configs.py all
 
 fft  batched N=2048 transforms through the FFT-plugin entry points: 8,192
@@ -209,6 +210,45 @@ def bench_cb(T, a):
     return [line, l2line]
 
 
+def bench_ring(T, a):
+    """gate bootstraps at ring degrees the reference's plugin accepts but never instantiates (csrc/tfhe_kernels_generic.h): N = 512 and
+    4096 with the headline set's other parameters (n = 630, l = 2, Bgbit = 10, key switch 8 x 2), synthetic keys, batch 4096 (1024 at
+    4096); a few of the TIMED outputs are bit-compared with the oracle (computed before the engine exists)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_py as O
+    lines = []
+    for N, B in ((512, 4096), (4096, 1024)):
+        n, l, bg, t, bb = (3, 2, 10, 2, 2) if a.small else (630, 2, 10, 8, 2)
+        if a.small:
+            B = 5
+        rs = np.random.RandomState(N)
+        bk = rand_bits(rs, (n, 2 * l, 2, N), np.int32)
+        ks = rand_bits(rs, (N, t, 1 << bb, n + 1), np.int32)
+        x = rand_bits(rs, (B, n + 1), np.int32)
+        rows = [0, B // 2, B - 1]
+        bkfft = O.execute_reverse_int(N, bk.reshape(-1, N)).reshape(bk.shape)  # tGswToFFTConvert (execute_reverse_torus32)
+        want = np.stack([O.bootstrap32(N, bkfft, ks, 1 << 29, x[r], l, bg, t, bb) for r in rows])
+        del bkfft
+        eng = T.Engine(torus_bits=32, n=n, N=N, l=l, Bgbit=bg, ks_t=t, ks_basebit=bb, lib_path=a.lib)
+        try:
+            eng.set_bootstrap_key(eng.gsw_from_torus(bk))
+            eng.load_keyswitch_key(ks)
+            x_d, u_d, o_d = eng.to_device(x), eng.alloc(B * (N + 1) * 4), eng.alloc(B * (n + 1) * 4)
+            br_min, _ = timed(eng, a.reps, lambda: eng._chk(eng.lib.tfhe_amd_bootstrap_woks(eng.ctx, u_d.ptr, 1 << 29, x_d.ptr, B)))
+            ks_min, _ = timed(eng, a.reps, lambda: eng._chk(eng.lib.tfhe_amd_keyswitch(eng.ctx, o_d.ptr, u_d.ptr, B)))
+            got = o_d.download(np.int32, (B, n + 1))
+            half = N // 2
+            fft = 5 * half * int(np.log2(half))
+            flop = 2 * l * fft + 2 * (fft + N) + 2 * l * 2 * 8 * half  # SURVEY 8d's formula at this N
+            lines.append({"N": N, "batch": B, "workload": f"tfhe_bootstrap_FFT n={n} N={N} l={l} Bgbit={bg} ks {t}x{bb}, synthetic keys",
+                          "blind_rotate_ms": br_min, "keyswitch_ms": ks_min, "bootstraps_per_s": B / ((br_min + ks_min) * 1e-3),
+                          "fp64_tflops": flop * n * B / (br_min * 1e-3) / 1e12, "oracle_bit_identical": bool(np.array_equal(got[rows], want))})
+            print(json.dumps(lines[-1]), flush=True)
+        finally:
+            eng.close()
+    return lines
+
+
 def bench_latency(T, a):
     """BASELINE config 1: a single gate bootstrap (and small batches) -- the reference's own unit of work is one
     sample per call (lwe_functions.cpp:434-446).  Each batch size is timed on both blind-rotation kernels: the
@@ -269,7 +309,7 @@ def bench_latency(T, a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", nargs="+", choices=["fft", "cb", "lat", "all"])
+    ap.add_argument("what", nargs="+", choices=["fft", "cb", "lat", "ring", "all"])
     ap.add_argument("--json-out", default=None,
                     help="also write {'cb': [...], 'fft': [...]} (the lines of the sections that ran, or {'error': ...} for one that "
                          "failed) to this file: how bench.py collects configs 3 and 4 from a child process")
@@ -293,7 +333,8 @@ def main():
     if "lat" in want:   # first: it times the reference in a child process before the GPU is in use
         bench_latency(T, a)
     # cb before fft: its oracle leg wants a process that has not touched the GPU yet
-    for name, fn in (("cb", bench_cb), ("fft", bench_fft)):
+    # (ring before anything else has used the GPU for the same reason)
+    for name, fn in (("ring", bench_ring), ("cb", bench_cb), ("fft", bench_fft)):
         if name not in want:
             continue
         try:
