@@ -10,7 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, emu_lib, q, keys="seed"):
+def _worker(rank, world, port, emu_lib, q, keys="seed", N=1024):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -19,13 +19,13 @@ def _worker(rank, world, port, emu_lib, q, keys="seed"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     shard = importlib.import_module("experimental-tfhe_amd.shard")
     T = importlib.import_module("experimental-tfhe_amd")
-    cfg = shard.GateConfig(N=1024, n=4, l=2, Bgbit=10, ks_t=8, ks_basebit=2)
+    cfg = shard.GateConfig(N=N, n=4, l=2, Bgbit=10, ks_t=8, ks_basebit=2)
     total = 7  # ragged: 4 + 3
     lo, hi = shard.shard_range(total, rank, world)
     # keys replicated from the seed, or built by rank 0 alone and broadcast as device-layout bytes; rank r on emulated device 3 r
     job = shard.GateJob(cfg, seed=0x5446484500000001, device=3 * rank, lib_path=emu_lib, keys=keys, tensor_device=torch.device("cpu"))
     if keys == "broadcast":
-        assert job.key_bytes_received == 4 * 4 * 2 * 1024 * 8 + 1024 * 8 * 4 * 5 * 4
+        assert job.key_bytes_received == 4 * 4 * 2 * N * 8 + N * 8 * 4 * 5 * 4
         assert (job.tlwe_key is None) == (rank != 0)  # only rank 0 ever held the host keys
     x_all = shard.synthetic_samples(cfg, total, seed=77)
     out = job.bootstrap(1 << 29, x_all[lo:hi])
@@ -42,15 +42,16 @@ def _worker(rank, world, port, emu_lib, q, keys="seed"):
 import pytest
 
 
-@pytest.mark.parametrize("keys", ["seed", "broadcast"])
-def test_two_rank_sharding(emu_lib, keys):
+@pytest.mark.parametrize("keys,N", [("seed", 1024), ("broadcast", 1024), ("broadcast", 512)])
+def test_two_rank_sharding(emu_lib, keys, N):
     """keys="broadcast": rank 1 never generates a key -- it bootstraps with the bytes rank 0 broadcast, on another
-    (emulated) device, and the gathered outputs still equal the single-rank result"""
+    (emulated) device, and the gathered outputs still equal the single-rank result.  N = 512: the same with the generic kernels'
+    key layout as the broadcast bytes"""
     import torch.multiprocessing as mp  # imported lazily: collecting -m gpu tests must stay light
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if keys == "broadcast" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib, q, keys)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if keys == "broadcast" else 0) + (13 if N != 1024 else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, emu_lib, q, keys, N)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
