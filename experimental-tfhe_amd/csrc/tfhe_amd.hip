@@ -423,17 +423,19 @@ int launch_br_gen(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
     GenBrPlace g;
     memset(&g, 0, sizeof(g));
     g.logn = c->logn;
-    // digits transformed together (one barrier sequence for all of them): all 2l rows, else one polynomial's l, else one
+    // digits transformed together (one barrier sequence for all of them): all 2l rows -- then the Fourier accumulator lives in the
+    // first two digit buffers (GenBrPlace::fac_in_dig) --, else one polynomial's l, else one
     const int nd_try[3] = {2 * c->p.l, c->p.l, 1};
+    auto areas = [&](int nd) { return acc_b + nd * dig1_b + (nd == 2 * c->p.l ? 0 : fac_b); };
     size_t lds = 0, glob = 0;
     g.nd = 0;
     for (int k = 0; k < 3 && !g.nd; k++)
-        if (acc_b + nd_try[k] * dig1_b + fac_b <= GEN_LDS_MAX) g.nd = nd_try[k];
+        if (areas(nd_try[k]) <= GEN_LDS_MAX) g.nd = nd_try[k];
     if (g.nd) {
         g.acc_lds = 0;
         g.dig_lds = (long long)acc_b;
         g.fac_lds = (long long)(acc_b + g.nd * dig1_b);
-        lds = acc_b + g.nd * dig1_b + fac_b;
+        lds = areas(g.nd);
     } else if (dig1_b + fac_b <= GEN_LDS_MAX) {
         g.nd = 1;
         g.acc_lds = -1;
@@ -444,8 +446,9 @@ int launch_br_gen(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
     } else {
         g.nd = 2 * c->p.l;
         g.acc_lds = g.dig_lds = g.fac_lds = -1;
-        glob = acc_b + g.nd * dig1_b + fac_b;
+        glob = areas(g.nd);
     }
+    g.fac_in_dig = g.nd == 2 * c->p.l;
     int block = (int)(N / 4);  // NC/2 butterflies per layer
     block = block < 64 ? 64 : (block > GEN_BR_BLOCK ? GEN_BR_BLOCK : block);
     const bool all_lds = glob == 0;
@@ -455,10 +458,11 @@ int launch_br_gen(tfhe_amd_ctx *c, const BlindRotateArgs<T> &a) {
     if (all_lds && N <= GEN_WAVE_MAX_N) {
         int nd_w = 0;
         for (int k = 0; k < 3 && !nd_w; k++)
-            if (4 * (acc_b + nd_try[k] * dig1_b + fac_b) <= GEN_LDS_MAX / 2) nd_w = nd_try[k];
+            if (4 * areas(nd_try[k]) <= GEN_LDS_MAX / 2) nd_w = nd_try[k];
         if (nd_w) {
             g.nd = nd_w;
-            g.wave_bytes = (long long)(acc_b + nd_w * dig1_b + fac_b);
+            g.fac_in_dig = nd_w == 2 * c->p.l;
+            g.wave_bytes = (long long)areas(nd_w);
             const size_t wg_lds = 4 * (size_t)g.wave_bytes;
             if (int rc = set_lds(c, kg_blind_rotate<T, true, true>, GEN_LDS_MAX)) return rc;
             int grid = 0;

@@ -36,6 +36,14 @@ TFHE_DEVICE GenC gen_ld(const double2 *buf, int j) {
     return GenC{v.x, v.y};
 }
 TFHE_DEVICE void gen_st(double2 *buf, int j, const GenC &v) { buf[j] = make_double2(v.r, v.i); }
+// WHERE point j of a polynomial sits in its work buffer: j with its low four bits XOR-ed by bits of j >> 3.  Unswizzled, the
+// pass on eight consecutive points per work-item (lane stride 128 bytes) is an 8-way LDS bank conflict in both directions and
+// the pass before it a 2-way one -- 56 % of all LDS cycles of the blind rotation at N = 512 were conflict cycles
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r06_generic_n.txt).  With this map every pass of every N is conflict-free
+// under the gfx950 banking rules for ds_read_b128 / ds_write_b128 (tools/lds_conflicts.py, generic part).  The map is linear
+// over GF(2) and touches bits 0..3 only, so for an index a + b whose parts share no bits, gen_sw(a + b) = gen_sw(a) ^ gen_sw(b):
+// a pass swizzles one index per item and XORs pass-uniform constants for the other points.
+TFHE_HOST_DEVICE int gen_sw(int j) { return j ^ (((j >> 3) & 7) ^ ((j >> 2) & 8) ^ ((j >> 6) & 1)); }
 // the two multiplication-free layers on one group of four consecutive points
 // inverse: size-4 (spqlios-ifft-fma.s:194-213) then size-2 (:247-263)
 TFHE_DEVICE void gen_ifft_tail4(GenC (&x)[4]) {
@@ -69,6 +77,19 @@ TFHE_DEVICE void gen_sync() {
         __syncthreads();
 }
 
+// How the `tpp` work-items of a team share a pass of `count` independent items (butterflies, groups of 4 or 8 points) on np
+// polynomials: while count >= tpp every work-item walks the items and takes all polynomials of each (one set of twiddles per
+// item); a shorter pass is cut into g = tpp / count sub-teams that take the polynomials s, s + g, ... -- instead of leaving
+// the work-items beyond `count` idle.  count and tpp are powers of two.
+struct GenSplit {
+    int tq, g, s, l2;  // work-items per polynomial, sub-teams, this work-item's sub-team and its number in it
+};
+TFHE_DEVICE GenSplit gen_split(int count, int lt, int tpp) {
+    if (count >= tpp) return GenSplit{tpp, 1, 0, lt};
+    const int sh = __builtin_ctz((unsigned)count);
+    return GenSplit{count, tpp >> sh, lt >> sh, lt & (count - 1)};
+}
+
 // Coefficient -> Lagrange, in place, for `np` polynomials `pstride` points apart; each is NC complex points holding
 // a_j + i a_{j+NC} on entry (the fold of spqlios-ifft-fma.s:40-44).  A team of `tpp` work-items (this one is number `lt`)
 // shares the work; EVERY work-item of the workgroup must call this (the barriers are workgroup barriers), `active` = false
@@ -82,18 +103,21 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
         const int h = NC >> 1;
         if (active) {
             const double2 *ts = tw + NC;  // 2 NC - 2 h
-            for (int bf = lt; bf < h; bf += tpp) {
+            const GenSplit S = gen_split(h, lt, tpp);
+            const int sh = gen_sw(h);
+            for (int bf = S.l2; bf < h; bf += S.tq) {
                 const double2 w = ts[bf], w1 = tw[bf], w2 = tw[bf + h];
-                for (int p = 0; p < np; p++) {
+                const int ia = gen_sw(bf), ib = ia ^ sh;
+                for (int p = S.s; p < np; p += S.g) {
                     double2 *x = buf + p * pstride;
-                    GenC a = gen_ld(x, bf), b = gen_ld(x, bf + h);
+                    GenC a = gen_ld(x, ia), b = gen_ld(x, ib);
                     const GenC ta{__builtin_fma(-a.i, w1.y, a.r * w1.x), __builtin_fma(a.i, w1.x, a.r * w1.y)};
                     const GenC tb{__builtin_fma(-b.i, w2.y, b.r * w2.x), __builtin_fma(b.i, w2.x, b.r * w2.y)};
                     a = ta;
                     b = tb;
                     dif_bfly(a.r, a.i, b.r, b.i, w.x, w.y);
-                    gen_st(x, bf, a);
-                    gen_st(x, bf + h, b);
+                    gen_st(x, ia, a);
+                    gen_st(x, ib, b);
                 }
             }
         }
@@ -105,10 +129,11 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
         if (layers & 1) {  // an odd one out: alone
             if (active) {
                 const double2 *ts = tw + (2 * NC - 2 * h);
-                for (int bf = lt; bf < (NC >> 1); bf += tpp) {
-                    const int off = bf & (h - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + h;
+                const GenSplit S = gen_split(NC >> 1, lt, tpp);
+                for (int bf = S.l2; bf < (NC >> 1); bf += S.tq) {
+                    const int off = bf & (h - 1), i1 = gen_sw(((bf - off) << 1) + off), i2 = i1 ^ gen_sw(h);
                     const double2 w = ts[off];
-                    for (int p = 0; p < np; p++) {
+                    for (int p = S.s; p < np; p += S.g) {
                         double2 *x = buf + p * pstride;
                         GenC a = gen_ld(x, i1), b = gen_ld(x, i2);
                         dif_bfly(a.r, a.i, b.r, b.i, w.x, w.y);
@@ -124,20 +149,23 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
             if (active) {
                 const int hh = h >> 1;
                 const double2 *ta = tw + (2 * NC - 2 * h), *tb = tw + (2 * NC - h);
-                for (int q4 = lt; q4 < (NC >> 2); q4 += tpp) {
-                    const int off = q4 & (hh - 1), base = ((q4 - off) << 2) + off;
+                const GenSplit S = gen_split(NC >> 2, lt, tpp);
+                const int s1 = gen_sw(hh), s2 = gen_sw(h), s3 = s1 ^ s2;
+                for (int q4 = S.l2; q4 < (NC >> 2); q4 += S.tq) {
+                    const int off = q4 & (hh - 1), base = gen_sw(((q4 - off) << 2) + off);
+                    const int j1 = base ^ s1, j2 = base ^ s2, j3 = base ^ s3;
                     const double2 wa0 = ta[off], wa1 = ta[off + hh], wb = tb[off];
-                    for (int p = 0; p < np; p++) {
+                    for (int p = S.s; p < np; p += S.g) {
                         double2 *x = buf + p * pstride;
-                        GenC x0 = gen_ld(x, base), x1 = gen_ld(x, base + hh), x2 = gen_ld(x, base + h), x3 = gen_ld(x, base + h + hh);
+                        GenC x0 = gen_ld(x, base), x1 = gen_ld(x, j1), x2 = gen_ld(x, j2), x3 = gen_ld(x, j3);
                         dif_bfly(x0.r, x0.i, x2.r, x2.i, wa0.x, wa0.y);
                         dif_bfly(x1.r, x1.i, x3.r, x3.i, wa1.x, wa1.y);
                         dif_bfly(x0.r, x0.i, x1.r, x1.i, wb.x, wb.y);
                         dif_bfly(x2.r, x2.i, x3.r, x3.i, wb.x, wb.y);
                         gen_st(x, base, x0);
-                        gen_st(x, base + hh, x1);
-                        gen_st(x, base + h, x2);
-                        gen_st(x, base + h + hh, x3);
+                        gen_st(x, j1, x1);
+                        gen_st(x, j2, x2);
+                        gen_st(x, j3, x3);
                     }
                 }
             }
@@ -147,11 +175,13 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
         if (active) {
             const double2 *t4 = tw + (2 * NC - 8);
             const double2 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
-            for (int g = lt; g < (NC >> 3); g += tpp) {
-                for (int p = 0; p < np; p++) {
-                    double2 *x = buf + p * pstride + 8 * g;
-                    GenC lo[4] = {gen_ld(x, 0), gen_ld(x, 1), gen_ld(x, 2), gen_ld(x, 3)};
-                    GenC hi[4] = {gen_ld(x, 4), gen_ld(x, 5), gen_ld(x, 6), gen_ld(x, 7)};
+            const GenSplit S = gen_split(NC >> 3, lt, tpp);
+            for (int g = S.l2; g < (NC >> 3); g += S.tq) {
+                const int g8 = gen_sw(8 * g);  // point 8 g + k sits at g8 ^ k
+                for (int p = S.s; p < np; p += S.g) {
+                    double2 *x = buf + p * pstride;
+                    GenC lo[4] = {gen_ld(x, g8), gen_ld(x, g8 ^ 1), gen_ld(x, g8 ^ 2), gen_ld(x, g8 ^ 3)};
+                    GenC hi[4] = {gen_ld(x, g8 ^ 4), gen_ld(x, g8 ^ 5), gen_ld(x, g8 ^ 6), gen_ld(x, g8 ^ 7)};
                     dif_bfly(lo[0].r, lo[0].i, hi[0].r, hi[0].i, w0.x, w0.y);
                     dif_bfly(lo[1].r, lo[1].i, hi[1].r, hi[1].i, w1.x, w1.y);
                     dif_bfly(lo[2].r, lo[2].i, hi[2].r, hi[2].i, w2.x, w2.y);
@@ -159,8 +189,8 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
                     gen_ifft_tail4(lo);
                     gen_ifft_tail4(hi);
                     for (int k = 0; k < 4; k++) {
-                        gen_st(x, k, lo[k]);
-                        gen_st(x, 4 + k, hi[k]);
+                        gen_st(x, g8 ^ k, lo[k]);
+                        gen_st(x, g8 ^ (4 + k), hi[k]);
                     }
                 }
             }
@@ -169,8 +199,9 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
         return;
     }
     if (active) {  // NC = 8: the fused first layer was h = 4
-        for (int g = lt; g < (NC >> 2); g += tpp)
-            for (int p = 0; p < np; p++) {
+        const GenSplit S = gen_split(NC >> 2, lt, tpp);
+        for (int g = S.l2; g < (NC >> 2); g += S.tq)
+            for (int p = S.s; p < np; p += S.g) {
                 double2 *x = buf + p * pstride + 4 * g;
                 GenC v[4] = {gen_ld(x, 0), gen_ld(x, 1), gen_ld(x, 2), gen_ld(x, 3)};
                 gen_ifft_tail4(v);
@@ -189,11 +220,13 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
         if (active) {
             const double2 *t4 = tw + (2 * NC - 8);
             const double2 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
-            for (int g = lt; g < (NC >> 3); g += tpp) {
-                for (int p = 0; p < np; p++) {
-                    double2 *x = buf + p * pstride + 8 * g;
-                    GenC lo[4] = {gen_ld(x, 0), gen_ld(x, 1), gen_ld(x, 2), gen_ld(x, 3)};
-                    GenC hi[4] = {gen_ld(x, 4), gen_ld(x, 5), gen_ld(x, 6), gen_ld(x, 7)};
+            const GenSplit S = gen_split(NC >> 3, lt, tpp);
+            for (int g = S.l2; g < (NC >> 3); g += S.tq) {
+                const int g8 = gen_sw(8 * g);  // point 8 g + k sits at g8 ^ k
+                for (int p = S.s; p < np; p += S.g) {
+                    double2 *x = buf + p * pstride;
+                    GenC lo[4] = {gen_ld(x, g8), gen_ld(x, g8 ^ 1), gen_ld(x, g8 ^ 2), gen_ld(x, g8 ^ 3)};
+                    GenC hi[4] = {gen_ld(x, g8 ^ 4), gen_ld(x, g8 ^ 5), gen_ld(x, g8 ^ 6), gen_ld(x, g8 ^ 7)};
                     gen_fft_head4(lo);
                     gen_fft_head4(hi);
                     dit_bfly(lo[0].r, lo[0].i, hi[0].r, hi[0].i, w0.x, w0.y);
@@ -201,8 +234,8 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
                     dit_bfly(lo[2].r, lo[2].i, hi[2].r, hi[2].i, -w2.x, w2.y);  // quarter turn: off == h/2
                     dit_bfly(lo[3].r, lo[3].i, hi[3].r, hi[3].i, w3.x, w3.y);
                     for (int k = 0; k < 4; k++) {
-                        gen_st(x, k, lo[k]);
-                        gen_st(x, 4 + k, hi[k]);
+                        gen_st(x, g8 ^ k, lo[k]);
+                        gen_st(x, g8 ^ (4 + k), hi[k]);
                     }
                 }
             }
@@ -215,22 +248,25 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
             if (active) {
                 const int h2 = h << 1;
                 const double2 *ta = tw + (2 * NC - 2 * h), *tb = tw + (2 * NC - 2 * h2);
-                for (int q4 = lt; q4 < (NC >> 2); q4 += tpp) {
-                    const int off = q4 & (h - 1), base = ((q4 - off) << 2) + off;
+                const GenSplit S = gen_split(NC >> 2, lt, tpp);
+                const int s1 = gen_sw(h), s2 = gen_sw(h2), s3 = s1 ^ s2;
+                for (int q4 = S.l2; q4 < (NC >> 2); q4 += S.tq) {
+                    const int off = q4 & (h - 1), base = gen_sw(((q4 - off) << 2) + off);
+                    const int j1 = base ^ s1, j2 = base ^ s2, j3 = base ^ s3;
                     const double2 wa = ta[off], wb0 = tb[off], wb1 = tb[off + h];
                     const double wac = flip_sign_if(wa.x, off == (h >> 1));
                     const double wb1c = flip_sign_if(wb1.x, off == 0);  // off + h == h2 / 2
-                    for (int p = 0; p < np; p++) {
+                    for (int p = S.s; p < np; p += S.g) {
                         double2 *x = buf + p * pstride;
-                        GenC x0 = gen_ld(x, base), x1 = gen_ld(x, base + h), x2 = gen_ld(x, base + h2), x3 = gen_ld(x, base + h2 + h);
+                        GenC x0 = gen_ld(x, base), x1 = gen_ld(x, j1), x2 = gen_ld(x, j2), x3 = gen_ld(x, j3);
                         dit_bfly(x0.r, x0.i, x1.r, x1.i, wac, wa.y);
                         dit_bfly(x2.r, x2.i, x3.r, x3.i, wac, wa.y);
                         dit_bfly(x0.r, x0.i, x2.r, x2.i, wb0.x, wb0.y);
                         dit_bfly(x1.r, x1.i, x3.r, x3.i, wb1c, wb1.y);
                         gen_st(x, base, x0);
-                        gen_st(x, base + h, x1);
-                        gen_st(x, base + h2, x2);
-                        gen_st(x, base + h2 + h, x3);
+                        gen_st(x, j1, x1);
+                        gen_st(x, j2, x2);
+                        gen_st(x, j3, x3);
                     }
                 }
             }
@@ -239,11 +275,12 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
         if (layers & 1) {  // the odd one out: h == NC/4
             if (active) {
                 const double2 *ts = tw + (2 * NC - 2 * h);
-                for (int bf = lt; bf < (NC >> 1); bf += tpp) {
-                    const int off = bf & (h - 1), i1 = ((bf - off) << 1) + off, i2 = i1 + h;
+                const GenSplit S = gen_split(NC >> 1, lt, tpp);
+                for (int bf = S.l2; bf < (NC >> 1); bf += S.tq) {
+                    const int off = bf & (h - 1), i1 = gen_sw(((bf - off) << 1) + off), i2 = i1 ^ gen_sw(h);
                     const double2 w = ts[off];
                     const double wc = flip_sign_if(w.x, off == (h >> 1));
-                    for (int p = 0; p < np; p++) {
+                    for (int p = S.s; p < np; p += S.g) {
                         double2 *x = buf + p * pstride;
                         GenC a = gen_ld(x, i1), b = gen_ld(x, i2);
                         dit_bfly(a.r, a.i, b.r, b.i, wc, w.y);
@@ -256,8 +293,9 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
         }
     } else {
         if (active) {
-            for (int g = lt; g < (NC >> 2); g += tpp)
-                for (int p = 0; p < np; p++) {
+            const GenSplit S = gen_split(NC >> 2, lt, tpp);
+            for (int g = S.l2; g < (NC >> 2); g += S.tq)
+                for (int p = S.s; p < np; p += S.g) {
                     double2 *x = buf + p * pstride + 4 * g;
                     GenC v[4] = {gen_ld(x, 0), gen_ld(x, 1), gen_ld(x, 2), gen_ld(x, 3)};
                     gen_fft_head4(v);
@@ -270,17 +308,19 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
         const int h = NC >> 1;
         if (active) {
             const double2 *ts = tw + NC;
-            for (int bf = lt; bf < h; bf += tpp) {
+            const GenSplit S = gen_split(h, lt, tpp);
+            for (int bf = S.l2; bf < h; bf += S.tq) {
                 const double2 w = ts[bf], w1 = tw[bf], w2 = tw[bf + h];
                 const double wc = flip_sign_if(w.x, bf == (h >> 1));
-                for (int p = 0; p < np; p++) {
+                const int ia = gen_sw(bf), ib = ia ^ gen_sw(h);
+                for (int p = S.s; p < np; p += S.g) {
                     double2 *x = buf + p * pstride;
-                    GenC a = gen_ld(x, bf), b = gen_ld(x, bf + h);
+                    GenC a = gen_ld(x, ia), b = gen_ld(x, ib);
                     dit_bfly(a.r, a.i, b.r, b.i, wc, w.y);
                     const double arc = a.r * w1.x, ars = a.r * w1.y, aic = a.i * w1.x, ais = a.i * w1.y;
                     const double brc = b.r * w2.x, brs = b.r * w2.y, bic = b.i * w2.x, bis = b.i * w2.y;
-                    gen_st(x, bf, GenC{arc + ais, aic - ars});
-                    gen_st(x, bf + h, GenC{brc + bis, bic - brs});
+                    gen_st(x, ia, GenC{arc + ais, aic - ars});
+                    gen_st(x, ib, GenC{brc + bis, bic - brs});
                 }
             }
         }
@@ -315,7 +355,7 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK_MAX)
         const bool active = b < batch;
         if (active) {
             const TIN *p = in + (size_t)b * N;
-            for (int j = lt; j < NC; j += tpp) buf[j] = make_double2((double)p[j], (double)p[j + NC]);
+            for (int j = lt; j < NC; j += tpp) buf[gen_sw(j)] = make_double2((double)p[j], (double)p[j + NC]);
         }
         __syncthreads();
         gen_ifft(buf, 1, 0, NC, tw, lt, tpp, active);
@@ -323,11 +363,14 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK_MAX)
             if (PACK) {
                 double2 *o = reinterpret_cast<double2 *>(out) + (size_t)b * NC;
                 const double scale = 2.0 / (double)N;  // exact: a power of two
-                for (int j = lt; j < NC; j += tpp) o[j] = make_double2(buf[j].x * scale, buf[j].y * scale);
+                for (int j = lt; j < NC; j += tpp) {
+                    const double2 v = buf[gen_sw(j)];
+                    o[j] = make_double2(v.x * scale, v.y * scale);
+                }
             } else {
                 double *o = out + (size_t)b * N;
                 for (int j = lt; j < NC; j += tpp) {
-                    const double2 v = buf[j];
+                    const double2 v = buf[gen_sw(j)];
                     o[j] = v.x;
                     o[NC + j] = v.y;
                 }
@@ -355,14 +398,14 @@ TFHE_GLOBAL void __launch_bounds__(GEN_BLOCK_MAX)
         const bool active = b < batch;
         if (active) {
             const double *p = in + (size_t)b * N;
-            for (int j = lt; j < NC; j += tpp) buf[j] = RAW ? make_double2(p[j], p[NC + j]) : make_double2(p[j] * scale, p[NC + j] * scale);
+            for (int j = lt; j < NC; j += tpp) buf[gen_sw(j)] = RAW ? make_double2(p[j], p[NC + j]) : make_double2(p[j] * scale, p[NC + j] * scale);
         }
         __syncthreads();
         gen_fft(buf, 1, 0, NC, tw, lt, tpp, active);
         if (active) {
             TOUT *o = out + (size_t)b * N;
             for (int j = lt; j < NC; j += tpp) {
-                const double2 v = buf[j];
+                const double2 v = buf[gen_sw(j)];
                 if constexpr (RAW) {
                     o[j] = v.x;
                     o[NC + j] = v.y;
@@ -404,6 +447,8 @@ struct GenBrPlace {
     unsigned char *work;
     int logn;
     int nd;  // gadget digits transformed together: 2l, l or 1 (dig holds nd polynomials)
+    int fac_in_dig;  // nd == 2l: no separate Fourier accumulator -- the multiply-accumulate of point j reads dig[0 .. 2l)[j] and
+                     // leaves its two results in dig[0][j] and dig[1][j] (same work-item), which the direct transforms then take
     long long wave_bytes;  // WAVE form: LDS bytes of one wavefront's three areas
 };
 
@@ -427,7 +472,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVE ? GEN_WAVE_BLOCK : GEN_BR_BLOCK) kg_blin
     if constexpr (ALL_LDS) {
         acc = reinterpret_cast<T *>(smem);
         dig = reinterpret_cast<double2 *>(smem + sizeof(T) * 2 * (size_t)N);
-        fac = dig + (size_t)nd * NC;
+        fac = G.fac_in_dig ? dig : dig + (size_t)nd * NC;
     } else {
         unsigned char *wsl = G.work ? G.work + (size_t)blockIdx.x * (size_t)G.work_stride : nullptr;
         size_t woff = 0;
@@ -439,7 +484,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVE ? GEN_WAVE_BLOCK : GEN_BR_BLOCK) kg_blin
         };
         acc = reinterpret_cast<T *>(place(G.acc_lds, sizeof(T) * 2 * (size_t)N));
         dig = reinterpret_cast<double2 *>(place(G.dig_lds, sizeof(double) * (size_t)nd * N));
-        fac = reinterpret_cast<double2 *>(place(G.fac_lds, sizeof(double) * 2 * (size_t)N));
+        fac = G.fac_in_dig ? dig : reinterpret_cast<double2 *>(place(G.fac_lds, sizeof(double) * 2 * (size_t)N));
     }
     const U offset = (U)A.gd.offset;
     const int Bgbit = A.gd.Bgbit, l = A.gd.l;
@@ -517,20 +562,21 @@ TFHE_GLOBAL void __launch_bounds__(WAVE ? GEN_WAVE_BLOCK : GEN_BR_BLOCK) kg_blin
                         }
                         return (double)((int32_t)(((U)(v + offset) >> decal) & mask) - halfBg);
                     };
-                    for (int j = tid; j < NC; j += nt) dg[j] = make_double2(digit(j), digit(j + NC));
+                    for (int j = tid; j < NC; j += nt) dg[gen_sw(j)] = make_double2(digit(j), digit(j + NC));
                 }
                 gen_sync<WAVE>();
                 gen_ifft<WAVE>(dig, nd, NC, NC, A.tw, tid, nt, true);
                 // tLweFFTAddMulRTo (tlwe_functions.cpp:318-325), both output polynomials, on an accumulator that starts as
                 // the +0 of tLweFFTClear (tgsw_functions.cpp:438)
                 for (int j = tid; j < NC; j += nt) {
+                    const int sj = gen_sw(j);  // position j of the work buffers
                     double2 f0 = make_double2(0.0, 0.0), f1 = make_double2(0.0, 0.0);
                     if (p0) {
-                        f0 = fac[j];
-                        f1 = fac[NC + j];
+                        f0 = fac[sj];
+                        f1 = fac[NC + sj];
                     }
                     for (int e = 0; e < nd; e++) {
-                        const double2 x = dig[(size_t)e * NC + j];
+                        const double2 x = dig[(size_t)e * NC + sj];
                         const double ar = x.x, ai = x.y;
                         const double2 *row = bkrow + (size_t)(p0 + e) * 2 * NC;
                         const double2 b0 = row[j], b1 = row[NC + j];
@@ -543,8 +589,8 @@ TFHE_GLOBAL void __launch_bounds__(WAVE ? GEN_WAVE_BLOCK : GEN_BR_BLOCK) kg_blin
                         const double u1 = __builtin_fma(ar, b1.y, f1.y);
                         f1.y = __builtin_fma(ai, b1.x, u1);
                     }
-                    fac[j] = f0;
-                    fac[NC + j] = f1;
+                    fac[sj] = f0;
+                    fac[NC + sj] = f1;
                 }
                 gen_sync<WAVE>();  // the next group's fill overwrites dig (not always from the work-item that read it: N < 2 x block)
             }
@@ -552,7 +598,7 @@ TFHE_GLOBAL void __launch_bounds__(WAVE ? GEN_WAVE_BLOCK : GEN_BR_BLOCK) kg_blin
             gen_fft<WAVE>(fac, 2, NC, NC, A.tw, tid, nt, true);
             for (int j = tid; j < N; j += nt) {  // point j of polynomial q = coefficients j and j + N/2
                 const int q = j >> (logn - 1), c = j & (NC - 1);
-                const double2 v = fac[j];
+                const double2 v = fac[q * NC + gen_sw(c)];
                 const U r0 = (U)Torus<T>::from_double(v.x), r1 = (U)Torus<T>::from_double(v.y);
                 T *pa = acc + q * N;
                 pa[c] = (T)(rotate ? (U)pa[c] + r0 : r0);

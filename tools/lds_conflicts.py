@@ -78,8 +78,67 @@ def main():
             if logn == 10:  # the layout the N=1024 kernel uses
                 ok &= (ww == 1 and rr == 1)
             print(f"N={1 << logn:5d} {name:12s} complex points: ds_write_b128 x{ww} ds_read_b128 x{rr}")
+    ok &= generic_part(worst128_cost, R128, W128)
     print("all conflict-free" if ok else "CONFLICTS / LAYOUT ERROR")
     return 0 if ok else 1
+
+
+def gen_sw(j):
+    """csrc/tfhe_kernels_generic.h gen_sw: where point j of a polynomial sits in its work buffer"""
+    return j ^ (((j >> 3) & 7) ^ ((j >> 2) & 8) ^ ((j >> 6) & 1))
+
+
+def worst128_cost(addr_of_lane, groups, nbanks):
+    """LDS cycles of one wave instruction on 16-byte elements: per lane group the largest number of distinct addresses on a bank"""
+    tot = 0
+    for lanes in groups:
+        banks = {}
+        for lane in lanes:
+            a = addr_of_lane(lane)
+            for q in range(0, 16, 4):
+                banks.setdefault(((a + q) // 4) % nbanks, set()).add(a)
+        tot += max(len(v) for v in banks.values())
+    return tot
+
+
+def generic_part(cost, R128, W128):
+    """The ring-degree-generic kernels (tfhe_kernels_generic.h): every pass of gen_ifft / gen_fft reads and writes the same points in
+    place; item t of a pass (consecutive lanes = consecutive items) touches
+      first / last / single layer of half-size h : runs of h consecutive points (two per item, h apart)
+      two layers (h, h/2)                        : base(t) + {0, 1, 2, 3} x h/2, base = 4 (t - t % (h/2)) + t % (h/2)
+      last three layers                          : 8 t + {0 .. 7}
+    Checked for every N the generic kernels serve in LDS, every wavefront of a team, with and without the swizzle."""
+    ok = True
+    for NC in (8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096):
+        if gen_sw(NC - 1) >= NC or sorted(gen_sw(j) for j in range(NC)) != list(range(NC)):
+            print(f"generic N={2 * NC}: gen_sw is not a permutation of the buffer")
+            ok = False
+        assert all(gen_sw(a + b) == gen_sw(a) ^ gen_sw(b) for a in range(0, NC, 8) for b in range(8)), "linearity the passes rely on"
+        worst = {False: 1.0, True: 1.0}
+        for swz in (False, True):
+            sw = gen_sw if swz else (lambda j: j)
+            # (count, points of item i): a pass shorter than the team is cut into sub-teams that take further polynomials (gen_split):
+            # lane t works on item t % count of polynomial t / count, NC points further on
+            pats = [("layer", NC // 2, [lambda i: i, lambda i: i + NC // 2])]
+            hh = NC // 8
+            while hh >= 8:
+                def mk(k, hh=hh):
+                    return lambda i: (((i - (i & (hh - 1))) << 2) + (i & (hh - 1))) + k * hh
+                pats.append((f"pair {hh}", NC // 4, [mk(k) for k in range(4)]))
+                hh //= 2
+            if NC >= 16:
+                pats.append(("eight", NC // 8, [(lambda i, k=k: 8 * i + k) for k in range(8)]))
+            for name, count, fns in pats:
+                for wave0 in range(0, max(64, count), 64):
+                    for f in fns:
+                        addr = lambda t: 16 * (((wave0 + t) // count) * NC + sw(f((wave0 + t) % count)))
+                        r = cost(addr, R128, 64) / len(R128)
+                        w = cost(addr, W128, 32) / len(W128)
+                        worst[swz] = max(worst[swz], r, w)
+        print(f"generic N={2 * NC:5d}: worst conflict multiplicity of a pass: x{worst[False]:.0f} unswizzled, x{worst[True]:.0f} with gen_sw")
+        # below N = 256 several polynomials share a wavefront's pass (their buffers are a multiple of 256 bytes apart): not pursued
+        ok &= worst[True] == 1.0 or NC < 128
+    return ok
 
 
 if __name__ == "__main__":
