@@ -90,6 +90,37 @@ TFHE_DEVICE GenSplit gen_split(int count, int lt, int tpp) {
     return GenSplit{count, tpp >> sh, lt >> sh, lt & (count - 1)};
 }
 
+// One item of a pass on the polynomials of this work-item's sub-team: its NPT points (idx: their swizzled positions, the same in
+// every polynomial) are read, f does the butterflies on GenC (&)[NPT], and they are written back.
+// LD / ST (GenNone: the buffer): the caller's source of the points (ld(p, k): point k of the item in polynomial p) and sink of the
+// results (st(p, k, value)) -- how the blind rotation feeds the first layer from the accumulator's digits and takes the last layer's
+// output into the accumulator without a pass through the buffer.
+// (Several polynomials in flight per item -- all loads, all butterflies, all stores -- was measured SLOWER at 2 and at 4: N = 512
+// 2.33 -> 2.39 / 2.51 ms per 4096 x 64 CMux, registers 147 -> 200; profiles/r06_generic_n.txt.)
+struct GenNone {};
+template <int NPT, class F, class LD = GenNone, class ST = GenNone>
+TFHE_DEVICE void gen_item(double2 *buf, int np, long pstride, const GenSplit &S, const int (&idx)[NPT], F &&f, LD ld = LD(), ST st = ST()) {
+    for (int p = S.s; p < np; p += S.g) {
+        double2 *x = buf + p * pstride;
+        GenC v[NPT];
+#pragma unroll
+        for (int k = 0; k < NPT; k++) {
+            if constexpr (std::is_same<LD, GenNone>::value)
+                v[k] = gen_ld(x, idx[k]);
+            else
+                v[k] = ld(p, k);
+        }
+        f(v);
+#pragma unroll
+        for (int k = 0; k < NPT; k++) {
+            if constexpr (std::is_same<ST, GenNone>::value)
+                gen_st(x, idx[k], v[k]);
+            else
+                st(p, k, v[k]);
+        }
+    }
+}
+
 // Coefficient -> Lagrange, in place, for `np` polynomials `pstride` points apart; each is NC complex points holding
 // a_j + i a_{j+NC} on entry (the fold of spqlios-ifft-fma.s:40-44).  A team of `tpp` work-items (this one is number `lt`)
 // shares the work; EVERY work-item of the workgroup must call this (the barriers are workgroup barriers), `active` = false
@@ -97,8 +128,10 @@ TFHE_DEVICE GenSplit gen_split(int count, int lt, int tpp) {
 // 2 NC - 2 h).  The caller has synchronised its writes; on return every result is visible to the whole workgroup.
 // Barriers: the layers are the reference's radix-2 layers, node for node, but a work-item carries its points through
 // TWO layers (four points) between barriers, and through the last three (h = 4, size 4, size 2: eight consecutive points).
-template <bool WAVE = false>
-TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active) {
+// FIRST (GenNone: the buffer holds them): first(p, j) = point j of polynomial p, asked for exactly once.
+template <bool WAVE = false, class FIRST = GenNone>
+TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active,
+                          FIRST first = FIRST()) {
     {  // layer h = NC/2 with the twist by omega^j (spqlios-ifft-fma.s:63-78) fused: its butterfly owns both points
         const int h = NC >> 1;
         if (active) {
@@ -107,18 +140,19 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
             const int sh = gen_sw(h);
             for (int bf = S.l2; bf < h; bf += S.tq) {
                 const double2 w = ts[bf], w1 = tw[bf], w2 = tw[bf + h];
-                const int ia = gen_sw(bf), ib = ia ^ sh;
-                for (int p = S.s; p < np; p += S.g) {
-                    double2 *x = buf + p * pstride;
-                    GenC a = gen_ld(x, ia), b = gen_ld(x, ib);
-                    const GenC ta{__builtin_fma(-a.i, w1.y, a.r * w1.x), __builtin_fma(a.i, w1.x, a.r * w1.y)};
-                    const GenC tb{__builtin_fma(-b.i, w2.y, b.r * w2.x), __builtin_fma(b.i, w2.x, b.r * w2.y)};
-                    a = ta;
-                    b = tb;
-                    dif_bfly(a.r, a.i, b.r, b.i, w.x, w.y);
-                    gen_st(x, ia, a);
-                    gen_st(x, ib, b);
-                }
+                const int ia = gen_sw(bf);
+                const int idx[2] = {ia, ia ^ sh};
+                auto twist_bfly = [&](GenC(&v)[2]) {
+                    const GenC ta{__builtin_fma(-v[0].i, w1.y, v[0].r * w1.x), __builtin_fma(v[0].i, w1.x, v[0].r * w1.y)};
+                    const GenC tb{__builtin_fma(-v[1].i, w2.y, v[1].r * w2.x), __builtin_fma(v[1].i, w2.x, v[1].r * w2.y)};
+                    v[0] = ta;
+                    v[1] = tb;
+                    dif_bfly(v[0].r, v[0].i, v[1].r, v[1].i, w.x, w.y);
+                };
+                if constexpr (std::is_same<FIRST, GenNone>::value)
+                    gen_item<2>(buf, np, pstride, S, idx, twist_bfly);
+                else
+                    gen_item<2>(buf, np, pstride, S, idx, twist_bfly, [&](int p, int k) { return first(p, k ? bf + h : bf); });
             }
         }
         gen_sync<WAVE>();
@@ -130,16 +164,12 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
             if (active) {
                 const double2 *ts = tw + (2 * NC - 2 * h);
                 const GenSplit S = gen_split(NC >> 1, lt, tpp);
+                const int sh = gen_sw(h);
                 for (int bf = S.l2; bf < (NC >> 1); bf += S.tq) {
-                    const int off = bf & (h - 1), i1 = gen_sw(((bf - off) << 1) + off), i2 = i1 ^ gen_sw(h);
+                    const int off = bf & (h - 1), i1 = gen_sw(((bf - off) << 1) + off);
                     const double2 w = ts[off];
-                    for (int p = S.s; p < np; p += S.g) {
-                        double2 *x = buf + p * pstride;
-                        GenC a = gen_ld(x, i1), b = gen_ld(x, i2);
-                        dif_bfly(a.r, a.i, b.r, b.i, w.x, w.y);
-                        gen_st(x, i1, a);
-                        gen_st(x, i2, b);
-                    }
+                    const int idx[2] = {i1, i1 ^ sh};
+                    gen_item<2>(buf, np, pstride, S, idx, [&](GenC(&v)[2]) { dif_bfly(v[0].r, v[0].i, v[1].r, v[1].i, w.x, w.y); });
                 }
             }
             gen_sync<WAVE>();
@@ -153,20 +183,14 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
                 const int s1 = gen_sw(hh), s2 = gen_sw(h), s3 = s1 ^ s2;
                 for (int q4 = S.l2; q4 < (NC >> 2); q4 += S.tq) {
                     const int off = q4 & (hh - 1), base = gen_sw(((q4 - off) << 2) + off);
-                    const int j1 = base ^ s1, j2 = base ^ s2, j3 = base ^ s3;
                     const double2 wa0 = ta[off], wa1 = ta[off + hh], wb = tb[off];
-                    for (int p = S.s; p < np; p += S.g) {
-                        double2 *x = buf + p * pstride;
-                        GenC x0 = gen_ld(x, base), x1 = gen_ld(x, j1), x2 = gen_ld(x, j2), x3 = gen_ld(x, j3);
-                        dif_bfly(x0.r, x0.i, x2.r, x2.i, wa0.x, wa0.y);
-                        dif_bfly(x1.r, x1.i, x3.r, x3.i, wa1.x, wa1.y);
-                        dif_bfly(x0.r, x0.i, x1.r, x1.i, wb.x, wb.y);
-                        dif_bfly(x2.r, x2.i, x3.r, x3.i, wb.x, wb.y);
-                        gen_st(x, base, x0);
-                        gen_st(x, j1, x1);
-                        gen_st(x, j2, x2);
-                        gen_st(x, j3, x3);
-                    }
+                    const int idx[4] = {base, base ^ s1, base ^ s2, base ^ s3};
+                    gen_item<4>(buf, np, pstride, S, idx, [&](GenC(&v)[4]) {
+                        dif_bfly(v[0].r, v[0].i, v[2].r, v[2].i, wa0.x, wa0.y);
+                        dif_bfly(v[1].r, v[1].i, v[3].r, v[3].i, wa1.x, wa1.y);
+                        dif_bfly(v[0].r, v[0].i, v[1].r, v[1].i, wb.x, wb.y);
+                        dif_bfly(v[2].r, v[2].i, v[3].r, v[3].i, wb.x, wb.y);
+                    });
                 }
             }
             gen_sync<WAVE>();
@@ -178,43 +202,42 @@ TFHE_DEVICE void gen_ifft(double2 *buf, int np, long pstride, int NC, const doub
             const GenSplit S = gen_split(NC >> 3, lt, tpp);
             for (int g = S.l2; g < (NC >> 3); g += S.tq) {
                 const int g8 = gen_sw(8 * g);  // point 8 g + k sits at g8 ^ k
-                for (int p = S.s; p < np; p += S.g) {
-                    double2 *x = buf + p * pstride;
-                    GenC lo[4] = {gen_ld(x, g8), gen_ld(x, g8 ^ 1), gen_ld(x, g8 ^ 2), gen_ld(x, g8 ^ 3)};
-                    GenC hi[4] = {gen_ld(x, g8 ^ 4), gen_ld(x, g8 ^ 5), gen_ld(x, g8 ^ 6), gen_ld(x, g8 ^ 7)};
-                    dif_bfly(lo[0].r, lo[0].i, hi[0].r, hi[0].i, w0.x, w0.y);
-                    dif_bfly(lo[1].r, lo[1].i, hi[1].r, hi[1].i, w1.x, w1.y);
-                    dif_bfly(lo[2].r, lo[2].i, hi[2].r, hi[2].i, w2.x, w2.y);
-                    dif_bfly(lo[3].r, lo[3].i, hi[3].r, hi[3].i, w3.x, w3.y);
+                const int idx[8] = {g8, g8 ^ 1, g8 ^ 2, g8 ^ 3, g8 ^ 4, g8 ^ 5, g8 ^ 6, g8 ^ 7};
+                gen_item<8>(buf, np, pstride, S, idx, [&](GenC(&v)[8]) {
+                    dif_bfly(v[0].r, v[0].i, v[4].r, v[4].i, w0.x, w0.y);
+                    dif_bfly(v[1].r, v[1].i, v[5].r, v[5].i, w1.x, w1.y);
+                    dif_bfly(v[2].r, v[2].i, v[6].r, v[6].i, w2.x, w2.y);
+                    dif_bfly(v[3].r, v[3].i, v[7].r, v[7].i, w3.x, w3.y);
+                    GenC lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
                     gen_ifft_tail4(lo);
                     gen_ifft_tail4(hi);
+#pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        gen_st(x, g8 ^ k, lo[k]);
-                        gen_st(x, g8 ^ (4 + k), hi[k]);
+                        v[k] = lo[k];
+                        v[4 + k] = hi[k];
                     }
-                }
+                });
             }
         }
         gen_sync<WAVE>();
         return;
     }
-    if (active) {  // NC = 8: the fused first layer was h = 4
+    if (active) {  // NC = 8: the fused first layer was h = 4 (gen_sw is the identity below 8)
         const GenSplit S = gen_split(NC >> 2, lt, tpp);
-        for (int g = S.l2; g < (NC >> 2); g += S.tq)
-            for (int p = S.s; p < np; p += S.g) {
-                double2 *x = buf + p * pstride + 4 * g;
-                GenC v[4] = {gen_ld(x, 0), gen_ld(x, 1), gen_ld(x, 2), gen_ld(x, 3)};
-                gen_ifft_tail4(v);
-                for (int k = 0; k < 4; k++) gen_st(x, k, v[k]);
-            }
+        for (int g = S.l2; g < (NC >> 2); g += S.tq) {
+            const int idx[4] = {4 * g, 4 * g + 1, 4 * g + 2, 4 * g + 3};
+            gen_item<4>(buf, np, pstride, S, idx, [&](GenC(&v)[4]) { gen_ifft_tail4(v); });
+        }
     }
     gen_sync<WAVE>();
 }
 
 // Lagrange -> coefficient, in place (the caller has applied the 2/N scale); same calling rules as gen_ifft.
 // (the reference's fft table is the conjugate of its ifft table except cos at the quarter turn: flip_sign_if)
-template <bool WAVE = false>
-TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active) {
+// LAST (GenNone: left in the buffer): last(p, j, value) takes point j of polynomial p instead.
+template <bool WAVE = false, class LAST = GenNone>
+TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const double2 *__restrict__ tw, int lt, int tpp, bool active,
+                         LAST last = LAST()) {
     if (NC > 8) {
         // size 2, size 4, then layer h = 4, on eight consecutive points
         if (active) {
@@ -222,22 +245,22 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
             const double2 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
             const GenSplit S = gen_split(NC >> 3, lt, tpp);
             for (int g = S.l2; g < (NC >> 3); g += S.tq) {
-                const int g8 = gen_sw(8 * g);  // point 8 g + k sits at g8 ^ k
-                for (int p = S.s; p < np; p += S.g) {
-                    double2 *x = buf + p * pstride;
-                    GenC lo[4] = {gen_ld(x, g8), gen_ld(x, g8 ^ 1), gen_ld(x, g8 ^ 2), gen_ld(x, g8 ^ 3)};
-                    GenC hi[4] = {gen_ld(x, g8 ^ 4), gen_ld(x, g8 ^ 5), gen_ld(x, g8 ^ 6), gen_ld(x, g8 ^ 7)};
+                const int g8 = gen_sw(8 * g);
+                const int idx[8] = {g8, g8 ^ 1, g8 ^ 2, g8 ^ 3, g8 ^ 4, g8 ^ 5, g8 ^ 6, g8 ^ 7};
+                gen_item<8>(buf, np, pstride, S, idx, [&](GenC(&v)[8]) {
+                    GenC lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
                     gen_fft_head4(lo);
                     gen_fft_head4(hi);
                     dit_bfly(lo[0].r, lo[0].i, hi[0].r, hi[0].i, w0.x, w0.y);
                     dit_bfly(lo[1].r, lo[1].i, hi[1].r, hi[1].i, w1.x, w1.y);
                     dit_bfly(lo[2].r, lo[2].i, hi[2].r, hi[2].i, -w2.x, w2.y);  // quarter turn: off == h/2
                     dit_bfly(lo[3].r, lo[3].i, hi[3].r, hi[3].i, w3.x, w3.y);
+#pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        gen_st(x, g8 ^ k, lo[k]);
-                        gen_st(x, g8 ^ (4 + k), hi[k]);
+                        v[k] = lo[k];
+                        v[4 + k] = hi[k];
                     }
-                }
+                });
             }
         }
         gen_sync<WAVE>();
@@ -252,22 +275,16 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
                 const int s1 = gen_sw(h), s2 = gen_sw(h2), s3 = s1 ^ s2;
                 for (int q4 = S.l2; q4 < (NC >> 2); q4 += S.tq) {
                     const int off = q4 & (h - 1), base = gen_sw(((q4 - off) << 2) + off);
-                    const int j1 = base ^ s1, j2 = base ^ s2, j3 = base ^ s3;
                     const double2 wa = ta[off], wb0 = tb[off], wb1 = tb[off + h];
                     const double wac = flip_sign_if(wa.x, off == (h >> 1));
                     const double wb1c = flip_sign_if(wb1.x, off == 0);  // off + h == h2 / 2
-                    for (int p = S.s; p < np; p += S.g) {
-                        double2 *x = buf + p * pstride;
-                        GenC x0 = gen_ld(x, base), x1 = gen_ld(x, j1), x2 = gen_ld(x, j2), x3 = gen_ld(x, j3);
-                        dit_bfly(x0.r, x0.i, x1.r, x1.i, wac, wa.y);
-                        dit_bfly(x2.r, x2.i, x3.r, x3.i, wac, wa.y);
-                        dit_bfly(x0.r, x0.i, x2.r, x2.i, wb0.x, wb0.y);
-                        dit_bfly(x1.r, x1.i, x3.r, x3.i, wb1c, wb1.y);
-                        gen_st(x, base, x0);
-                        gen_st(x, j1, x1);
-                        gen_st(x, j2, x2);
-                        gen_st(x, j3, x3);
-                    }
+                    const int idx[4] = {base, base ^ s1, base ^ s2, base ^ s3};
+                    gen_item<4>(buf, np, pstride, S, idx, [&](GenC(&v)[4]) {
+                        dit_bfly(v[0].r, v[0].i, v[1].r, v[1].i, wac, wa.y);
+                        dit_bfly(v[2].r, v[2].i, v[3].r, v[3].i, wac, wa.y);
+                        dit_bfly(v[0].r, v[0].i, v[2].r, v[2].i, wb0.x, wb0.y);
+                        dit_bfly(v[1].r, v[1].i, v[3].r, v[3].i, wb1c, wb1.y);
+                    });
                 }
             }
             gen_sync<WAVE>();
@@ -276,17 +293,13 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
             if (active) {
                 const double2 *ts = tw + (2 * NC - 2 * h);
                 const GenSplit S = gen_split(NC >> 1, lt, tpp);
+                const int sh = gen_sw(h);
                 for (int bf = S.l2; bf < (NC >> 1); bf += S.tq) {
-                    const int off = bf & (h - 1), i1 = gen_sw(((bf - off) << 1) + off), i2 = i1 ^ gen_sw(h);
+                    const int off = bf & (h - 1), i1 = gen_sw(((bf - off) << 1) + off);
                     const double2 w = ts[off];
                     const double wc = flip_sign_if(w.x, off == (h >> 1));
-                    for (int p = S.s; p < np; p += S.g) {
-                        double2 *x = buf + p * pstride;
-                        GenC a = gen_ld(x, i1), b = gen_ld(x, i2);
-                        dit_bfly(a.r, a.i, b.r, b.i, wc, w.y);
-                        gen_st(x, i1, a);
-                        gen_st(x, i2, b);
-                    }
+                    const int idx[2] = {i1, i1 ^ sh};
+                    gen_item<2>(buf, np, pstride, S, idx, [&](GenC(&v)[2]) { dit_bfly(v[0].r, v[0].i, v[1].r, v[1].i, wc, w.y); });
                 }
             }
             gen_sync<WAVE>();
@@ -294,13 +307,10 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
     } else {
         if (active) {
             const GenSplit S = gen_split(NC >> 2, lt, tpp);
-            for (int g = S.l2; g < (NC >> 2); g += S.tq)
-                for (int p = S.s; p < np; p += S.g) {
-                    double2 *x = buf + p * pstride + 4 * g;
-                    GenC v[4] = {gen_ld(x, 0), gen_ld(x, 1), gen_ld(x, 2), gen_ld(x, 3)};
-                    gen_fft_head4(v);
-                    for (int k = 0; k < 4; k++) gen_st(x, k, v[k]);
-                }
+            for (int g = S.l2; g < (NC >> 2); g += S.tq) {
+                const int idx[4] = {4 * g, 4 * g + 1, 4 * g + 2, 4 * g + 3};
+                gen_item<4>(buf, np, pstride, S, idx, [&](GenC(&v)[4]) { gen_fft_head4(v); });
+            }
         }
         gen_sync<WAVE>();
     }
@@ -309,19 +319,23 @@ TFHE_DEVICE void gen_fft(double2 *buf, int np, long pstride, int NC, const doubl
         if (active) {
             const double2 *ts = tw + NC;
             const GenSplit S = gen_split(h, lt, tpp);
+            const int sh = gen_sw(h);
             for (int bf = S.l2; bf < h; bf += S.tq) {
                 const double2 w = ts[bf], w1 = tw[bf], w2 = tw[bf + h];
                 const double wc = flip_sign_if(w.x, bf == (h >> 1));
-                const int ia = gen_sw(bf), ib = ia ^ gen_sw(h);
-                for (int p = S.s; p < np; p += S.g) {
-                    double2 *x = buf + p * pstride;
-                    GenC a = gen_ld(x, ia), b = gen_ld(x, ib);
-                    dit_bfly(a.r, a.i, b.r, b.i, wc, w.y);
-                    const double arc = a.r * w1.x, ars = a.r * w1.y, aic = a.i * w1.x, ais = a.i * w1.y;
-                    const double brc = b.r * w2.x, brs = b.r * w2.y, bic = b.i * w2.x, bis = b.i * w2.y;
-                    gen_st(x, ia, GenC{arc + ais, aic - ars});
-                    gen_st(x, ib, GenC{brc + bis, bic - brs});
-                }
+                const int ia = gen_sw(bf);
+                const int idx[2] = {ia, ia ^ sh};
+                auto bfly_twist = [&](GenC(&v)[2]) {
+                    dit_bfly(v[0].r, v[0].i, v[1].r, v[1].i, wc, w.y);
+                    const double arc = v[0].r * w1.x, ars = v[0].r * w1.y, aic = v[0].i * w1.x, ais = v[0].i * w1.y;
+                    const double brc = v[1].r * w2.x, brs = v[1].r * w2.y, bic = v[1].i * w2.x, bis = v[1].i * w2.y;
+                    v[0] = GenC{arc + ais, aic - ars};
+                    v[1] = GenC{brc + bis, bic - brs};
+                };
+                if constexpr (std::is_same<LAST, GenNone>::value)
+                    gen_item<2>(buf, np, pstride, S, idx, bfly_twist);
+                else
+                    gen_item<2>(buf, np, pstride, S, idx, bfly_twist, GenNone(), [&](int p, int k, const GenC &v) { last(p, k ? bf + h : bf, v); });
             }
         }
         gen_sync<WAVE>();
@@ -546,26 +560,25 @@ TFHE_GLOBAL void __launch_bounds__(WAVE ? GEN_WAVE_BLOCK : GEN_BR_BLOCK) kg_blin
             // rows p = q*l + d (tgsw_functions.cpp:435-443) in groups of nd: extract, transform together, multiply-accumulate
             // in row order (the chain of lagrangehalfc_impl_fma.s:96-107 is sequential in p for every point)
             for (int p0 = 0; p0 < 2 * l; p0 += nd) {
-                for (int e = 0; e < nd; e++) {
-                    const int q = (p0 + e) / l, d = (p0 + e) - q * l;
+                // digit d of polynomial q of (X^a - 1) * acc (numeric_functions.cpp:304-323), or of acc itself; decomposition
+                // tgsw_functions.cpp:224-337 / poc:492-515 (offset from the host); point j = (coefficient j, coefficient j + N/2).
+                // The first layer of the transform asks for every point once: the digits never sit in the buffer untransformed.
+                auto digit_point = [&](int e, int j) {
+                    const int q = (p0 + e) >= l ? 1 : 0, d = (p0 + e) - q * l;
                     const T *pa = acc + q * N;
-                    double2 *dg = dig + (size_t)e * NC;
                     const int decal = BITS - (d + 1) * Bgbit;
-                    // digit d of polynomial q of (X^a - 1) * acc (numeric_functions.cpp:304-323), or of acc itself;
-                    // decomposition tgsw_functions.cpp:224-337 / poc:492-515 (offset from the host); point j = (coef j, coef j + N/2)
-                    auto digit = [&](int j) {
-                        U v = (U)pa[j];
+                    auto digit = [&](int c) {
+                        U v = (U)pa[c];
                         if (rotate) {
-                            const int idx = (j - a) & (2 * N - 1);
+                            const int idx = (c - a) & (2 * N - 1);
                             const U src = (U)pa[idx & (N - 1)];
                             v = ((idx & N) ? (U)(0 - src) : src) - v;
                         }
                         return (double)((int32_t)(((U)(v + offset) >> decal) & mask) - halfBg);
                     };
-                    for (int j = tid; j < NC; j += nt) dg[gen_sw(j)] = make_double2(digit(j), digit(j + NC));
-                }
-                gen_sync<WAVE>();
-                gen_ifft<WAVE>(dig, nd, NC, NC, A.tw, tid, nt, true);
+                    return GenC{digit(j), digit(j + NC)};
+                };
+                gen_ifft<WAVE>(dig, nd, NC, NC, A.tw, tid, nt, true, digit_point);
                 // tLweFFTAddMulRTo (tlwe_functions.cpp:318-325), both output polynomials, on an accumulator that starts as
                 // the +0 of tLweFFTClear (tgsw_functions.cpp:438)
                 for (int j = tid; j < NC; j += nt) {
@@ -592,19 +605,16 @@ TFHE_GLOBAL void __launch_bounds__(WAVE ? GEN_WAVE_BLOCK : GEN_BR_BLOCK) kg_blin
                     fac[sj] = f0;
                     fac[NC + sj] = f1;
                 }
-                gen_sync<WAVE>();  // the next group's fill overwrites dig (not always from the work-item that read it: N < 2 x block)
+                gen_sync<WAVE>();  // the transforms read fac / the next group's first layer overwrites dig
             }
-            // tLweFromFFTConvert (key rows carry the 2/N scale) + tLweAddTo
-            gen_fft<WAVE>(fac, 2, NC, NC, A.tw, tid, nt, true);
-            for (int j = tid; j < N; j += nt) {  // point j of polynomial q = coefficients j and j + N/2
-                const int q = j >> (logn - 1), c = j & (NC - 1);
-                const double2 v = fac[q * NC + gen_sw(c)];
-                const U r0 = (U)Torus<T>::from_double(v.x), r1 = (U)Torus<T>::from_double(v.y);
+            // tLweFromFFTConvert (key rows carry the 2/N scale) + tLweAddTo: the last layer hands point j of polynomial q
+            // (coefficients j and j + N/2) over as it is finished; every coefficient belongs to one work-item
+            gen_fft<WAVE>(fac, 2, NC, NC, A.tw, tid, nt, true, [&](int q, int j, const GenC &v) {
+                const U r0 = (U)Torus<T>::from_double(v.r), r1 = (U)Torus<T>::from_double(v.i);
                 T *pa = acc + q * N;
-                pa[c] = (T)(rotate ? (U)pa[c] + r0 : r0);
-                pa[c + NC] = (T)(rotate ? (U)pa[c + NC] + r1 : r1);
-            }
-            gen_sync<WAVE>();
+                pa[j] = (T)(rotate ? (U)pa[j] + r0 : r0);
+                pa[j + NC] = (T)(rotate ? (U)pa[j + NC] + r1 : r1);
+            });
         }
 
         // ---- output
