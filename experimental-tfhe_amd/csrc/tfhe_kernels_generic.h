@@ -96,7 +96,7 @@ TFHE_DEVICE GenSplit gen_split(int count, int lt, int tpp) {
 // results (st(p, k, value)) -- how the blind rotation feeds the first layer from the accumulator's digits and takes the last layer's
 // output into the accumulator without a pass through the buffer.
 // (Several polynomials in flight per item -- all loads, all butterflies, all stores -- was measured SLOWER at 2 and at 4: N = 512
-// 2.33 -> 2.39 / 2.51 ms per 4096 x 64 CMux, registers 147 -> 200; profiles/r06_generic_n.txt.)
+// 2.33 -> 2.43 / 2.54 ms per 4096 x 64 CMux, registers 147 -> 200; profiles/r06_generic_n.txt.)
 struct GenNone {};
 template <int NPT, class F, class LD = GenNone, class ST = GenNone>
 TFHE_DEVICE void gen_item(double2 *buf, int np, long pstride, const GenSplit &S, const int (&idx)[NPT], F &&f, LD ld = LD(), ST st = ST()) {
