@@ -563,20 +563,19 @@ TFHE_GLOBAL void __launch_bounds__(WAVE ? GEN_WAVE_BLOCK : GEN_BR_BLOCK) kg_blin
                 // digit d of polynomial q of (X^a - 1) * acc (numeric_functions.cpp:304-323), or of acc itself; decomposition
                 // tgsw_functions.cpp:224-337 / poc:492-515 (offset from the host); point j = (coefficient j, coefficient j + N/2).
                 // The first layer of the transform asks for every point once: the digits never sit in the buffer untransformed.
+                // (all four reads of a point are issued before the first is used, and `rotate` is a select, not a branch: a branch per
+                // coefficient made every read wait for the one before it)
                 auto digit_point = [&](int e, int j) {
                     const int q = (p0 + e) >= l ? 1 : 0, d = (p0 + e) - q * l;
                     const T *pa = acc + q * N;
                     const int decal = BITS - (d + 1) * Bgbit;
-                    auto digit = [&](int c) {
-                        U v = (U)pa[c];
-                        if (rotate) {
-                            const int idx = (c - a) & (2 * N - 1);
-                            const U src = (U)pa[idx & (N - 1)];
-                            v = ((idx & N) ? (U)(0 - src) : src) - v;
-                        }
-                        return (double)((int32_t)(((U)(v + offset) >> decal) & mask) - halfBg);
-                    };
-                    return GenC{digit(j), digit(j + NC)};
+                    const int i0 = (j - a) & (2 * N - 1), i1 = (i0 + NC) & (2 * N - 1);  // a == 0 without rotation
+                    const U c0 = (U)pa[j], c1 = (U)pa[j + NC], s0 = (U)pa[i0 & (N - 1)], s1 = (U)pa[i1 & (N - 1)];
+                    U v0 = ((i0 & N) ? (U)(0 - s0) : s0) - c0, v1 = ((i1 & N) ? (U)(0 - s1) : s1) - c1;
+                    v0 = rotate ? v0 : c0;
+                    v1 = rotate ? v1 : c1;
+                    return GenC{(double)((int32_t)(((U)(v0 + offset) >> decal) & mask) - halfBg),
+                                (double)((int32_t)(((U)(v1 + offset) >> decal) & mask) - halfBg)};
                 };
                 gen_ifft<WAVE>(dig, nd, NC, NC, A.tw, tid, nt, true, digit_point);
                 // tLweFFTAddMulRTo (tlwe_functions.cpp:318-325), both output polynomials, on an accumulator that starts as
@@ -588,19 +587,36 @@ TFHE_GLOBAL void __launch_bounds__(WAVE ? GEN_WAVE_BLOCK : GEN_BR_BLOCK) kg_blin
                         f0 = fac[sj];
                         f1 = fac[NC + sj];
                     }
-                    for (int e = 0; e < nd; e++) {
-                        const double2 x = dig[(size_t)e * NC + sj];
-                        const double ar = x.x, ai = x.y;
-                        const double2 *row = bkrow + (size_t)(p0 + e) * 2 * NC;
-                        const double2 b0 = row[j], b1 = row[NC + j];
-                        const double t0 = __builtin_fma(ai, b0.y, -f0.x);
-                        f0.x = __builtin_fma(ar, b0.x, -t0);
-                        const double u0 = __builtin_fma(ar, b0.y, f0.y);
-                        f0.y = __builtin_fma(ai, b0.x, u0);
-                        const double t1 = __builtin_fma(ai, b1.y, -f1.x);
-                        f1.x = __builtin_fma(ar, b1.x, -t1);
-                        const double u1 = __builtin_fma(ar, b1.y, f1.y);
-                        f1.y = __builtin_fma(ai, b1.x, u1);
+                    // rows in chunks of MC: every load of a chunk (digit from the buffer, two key values from global memory) is issued
+                    // before the chain starts.  Wave form, row by row: each row's key values were waited for with nothing else in flight;
+                    // two rows per chunk +2 ... 4 % at N = 64 ... 512, four rows cost the third wave per SIMD its registers (N = 256: -8 %);
+                    // the workgroup form (four waves per SIMD) measured equal or slower with chunks
+                    constexpr int MC = WAVE ? 2 : 1;
+                    for (int e0 = 0; e0 < nd; e0 += MC) {
+                        double2 x[MC], b0[MC], b1[MC];
+#pragma unroll
+                        for (int u = 0; u < MC; u++) {
+                            if (u == 0 || e0 + u < nd) {
+                                x[u] = dig[(size_t)(e0 + u) * NC + sj];
+                                const double2 *row = bkrow + (size_t)(p0 + e0 + u) * 2 * NC;
+                                b0[u] = row[j];
+                                b1[u] = row[NC + j];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < MC; u++) {
+                            if (u == 0 || e0 + u < nd) {
+                                const double ar = x[u].x, ai = x[u].y;
+                                const double t0 = __builtin_fma(ai, b0[u].y, -f0.x);
+                                f0.x = __builtin_fma(ar, b0[u].x, -t0);
+                                const double u0 = __builtin_fma(ar, b0[u].y, f0.y);
+                                f0.y = __builtin_fma(ai, b0[u].x, u0);
+                                const double t1 = __builtin_fma(ai, b1[u].y, -f1.x);
+                                f1.x = __builtin_fma(ar, b1[u].x, -t1);
+                                const double u1 = __builtin_fma(ar, b1[u].y, f1.y);
+                                f1.y = __builtin_fma(ai, b1[u].x, u1);
+                            }
+                        }
                     }
                     fac[sj] = f0;
                     fac[NC + sj] = f1;
