@@ -52,8 +52,8 @@ enum {
  * (CB/poc_types.h:267-283).  Supported: N = every power of two from 16 to 2^20 -- what the reference's plugin accepts
  * (new_fft_table / FFT_Processor_Spqlios(N): a power of two >= 16, CB/spqlios/spqlios-fft-impl.cpp:157-160,
  * fft_processor_spqlios.cpp:18-25); 1024 and 2048, the two the reference instantiates, run the wave-per-polynomial
- * kernels, every other degree the team-per-polynomial kernels of csrc/tfhe_kernels_generic.h (same bits, about a third
- * of the tuned kernels' rate: profiles/r06_generic_n.txt).  k = 1, l in [1,8], l*Bgbit <= torus_bits - 1,
+ * kernels, every other degree the team-per-polynomial kernels of csrc/tfhe_kernels_generic.h (same bits, a little under
+ * half the tuned kernels' rate: profiles/r06_generic_n.txt).  k = 1, l in [1,8], l*Bgbit <= torus_bits - 1,
  * torus_bits in {32, 64}.  (Real96 transforms, tfhe_amd_hp_*: N in {1024, 2048} only.) */
 typedef struct tfhe_amd_params {
     int32_t torus_bits; /* 32: Torus32 accumulator (gate bootstrap); 64: Torus64 (circuit bootstrap lvl2) */
