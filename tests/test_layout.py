@@ -31,3 +31,18 @@ def test_lds_budgets_fit_160k():
     assert br(8, 1024, 4) <= 163840
     assert br(8, 2048, 4) == 32768 + 4 * 17408 + 64 <= 163840
     assert 2 * (2 * 8 * 4096) <= 163840  # k_ks_mfma: two workgroups per CU, double-buffered key slices of 8 K-steps
+
+
+def test_generic_swizzle_of_the_tool_is_the_kernels():
+    """tools/lds_conflicts.py checks ITS gen_sw: the expression must be the one in csrc/tfhe_kernels_generic.h"""
+    import importlib.util
+    import re
+    src = open(os.path.join(ROOT, "experimental-tfhe_amd", "csrc", "tfhe_kernels_generic.h")).read()
+    m = re.search(r"int gen_sw\(int j\) \{ return (.*?); \}", src)
+    assert m, "gen_sw not found in the kernel header"
+    spec = importlib.util.spec_from_file_location("lds_conflicts", os.path.join(ROOT, "tools", "lds_conflicts.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    expr = compile(m.group(1), "gen_sw", "eval")  # shifts, masks and XORs read the same in C and Python for j >= 0
+    for j in range(1 << 14):
+        assert eval(expr, {"j": j}) == tool.gen_sw(j), j
